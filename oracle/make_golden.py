@@ -1,0 +1,269 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself (authoring container only).
+
+TEST INFRASTRUCTURE.  Imports /root/reference/team_code/mmfn_utils read-only at run time
+(nothing is copied) and records inputs-recipe -> outputs vectors that pin oracle/model.py
+and, through it, the HIP product.  Skips with a message when /root/reference is absent
+(e.g. on the GPU box).
+
+Two import shims are needed because the container lacks the reference's pinned third-party
+stack (Dockerfile:41: torch 1.10.2 / torchvision 0.11.3):
+  * ``torchvision.models`` -> the BasicBlock ResNet-18/34 from oracle/model.py (torchvision is a
+    third-party dependency, not reference code; its published architecture is restated there),
+  * ``torch._six.string_classes`` -> (str, bytes) for data_utils.py:5.
+Everything MMFN-specific (GPT, VectorNet, GAT, Encoder orchestration, GRU head, collate,
+histogram, crop, radar_to_size, PID) executes the reference's own source.
+
+Usage:  python oracle/make_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import fixtures  # noqa: E402
+from oracle.model import _ResNetTrunk  # noqa: E402
+
+
+def install_shims():
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvm.resnet34 = lambda pretrained=False, **kw: _ResNetTrunk((3, 4, 6, 3), 3)
+    tvm.resnet18 = lambda pretrained=False, **kw: _ResNetTrunk((2, 2, 2, 2), 3)
+    tv.models = tvm
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tvm
+    six = types.ModuleType("torch._six")
+    six.string_classes = (str, bytes)
+    sys.modules["torch._six"] = six
+    sys.path.insert(0, os.path.join(REF, "team_code"))
+
+
+def reference_inputs(batch, ref_dl):
+    """Turn a synthetic batch into the reference's forward() arguments using ITS preprocessing."""
+    rgb = batch["rgb_u8"].numpy()
+
+    class _Img:  # duck-typed PIL image for scale_and_crop_image (dataloader.py:296-308)
+        def __init__(self, arr):
+            self.arr, self.height, self.width = arr, arr.shape[0], arr.shape[1]
+
+        def resize(self, size):
+            return self.arr
+
+    fronts = np.stack([ref_dl.scale_and_crop_image(_Img(im), scale=1, crop=256) for im in rgb])
+    bev = np.stack([ref_dl.lidar_to_histogram_features(p[:, :3].numpy().astype(np.float64), crop=256)
+                    for p in batch["lidar_pts"]])
+    # contiguous(): the reference's histogram comes back channels-last strided (np.transpose +
+    # astype keeps 'K' order); oneDNN then takes an NHWC conv path whose rounding differs by ~2e-6.
+    # The collated training batch is plain NCHW, so pin the vectors on that layout.
+    return torch.from_numpy(fronts.copy()).float(), torch.from_numpy(bev).float().contiguous()
+
+
+def run_variant(variant, ref_models, ref_dl, ref_cfg, out_dir):
+    torch.manual_seed(0)
+    cfg = ref_cfg.GlobalConfig()
+    model = getattr(ref_models, "model_" + variant).MMFN(cfg, "cpu")
+    fixtures.fill_module(model)
+    keys = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    pnames = [k for k, _ in model.named_parameters()]
+
+    b = 2
+    batch = fixtures.synthetic_batch(b, variant, seed=42, n_lidar=16384, lanes=9 if variant != "img" else 4)
+    fronts, bev = reference_inputs(batch, ref_dl)
+    maps = batch["map_u8"].float()
+    vm = [[batch["lane"]], [batch["lane_num"].float()], int(batch["lane_num"].max())]
+    args = ([fronts], [bev], [maps], vm, [batch["radar"]], [batch["radar_adj"]],
+            batch["target_point"], batch["velocity"])
+
+    res = {"bev": bev.numpy(), "fronts_crop_sum": np.float64(fronts.double().sum().item())}
+    # ---- disable dropout everywhere (the reference's RNG stream cannot be matched) ----
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if hasattr(m, "dropout") and isinstance(getattr(m, "dropout"), float):
+            m.dropout = 0.0
+    # ---- eval forward.  The closed-form running stats are far from the statistics of raw 0..255
+    # inputs, so eval mode would be ill-conditioned (|wp| ~ 1e13).  Calibrate first: one train-mode
+    # forward with BatchNorm momentum 1.0 makes running stats == batch stats; then eval. ----
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        model(*args)
+    model.eval()
+    with torch.no_grad():
+        res["eval_pred_wp"] = model(*args).numpy()
+        res["eval_loss"] = np.float32(torch.nn.functional.l1_loss(
+            torch.from_numpy(res["eval_pred_wp"]), batch["gt_wp"], reduction="none").mean().item())
+    # agent-style vectormap packing (e2e_agent/mmfn_vectornet.py:287-293): data[2] is a tensor
+    if variant != "img":
+        with torch.no_grad():
+            one = [[batch["lane"][:1]], [batch["lane_num"][:1].int()], batch["lane_num"][:1].int().view(1, 1)]
+            a1 = ([fronts[:1]], [bev[:1]], None, one, [batch["radar"][:1]], [batch["radar_adj"][:1]],
+                  batch["target_point"][:1], batch["velocity"][:1])
+            res["eval_pred_wp_b1_agent"] = model(*a1).numpy()
+    for m in bns:
+        m.momentum = 0.1
+    fixtures.fill_module(model)  # restore closed-form running stats for the train-step vectors
+
+    # ---- one full train step (dropout disabled above) ----
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)  # phase2_train_net.py:256
+    taps = {}
+    hooks = []
+    enc = model.encoder
+    hooks.append(enc.register_forward_hook(lambda m, i, o: taps.__setitem__("fused", o.detach().clone())))
+    if variant != "img":
+        hooks.append(enc.vectornet_encoder.register_forward_hook(
+            lambda m, i, o: taps.__setitem__("vectornet", o.detach().clone())))
+    for i in range(1, 5):
+        hooks.append(getattr(enc, "transformer%d" % i).register_forward_hook(
+            lambda m, inp, o, i=i: taps.__setitem__("gpt%d_img" % i, o[0].detach().clone())))
+    pred = model(*args)
+    loss = torch.nn.functional.l1_loss(pred, batch["gt_wp"], reduction="none").mean()  # phase2:104
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    res["train_pred_wp"] = pred.detach().numpy()
+    res["train_loss"] = np.float32(loss.item())
+    for k, v in taps.items():
+        v = v.double()
+        res["tap_%s_sum" % k] = np.float64(v.sum().item())
+        res["tap_%s_abs" % k] = np.float64(v.abs().sum().item())
+        res["tap_%s_head" % k] = v.flatten()[:16].float().numpy()
+    gnorm, ghead, gnone = [], [], []
+    params = dict(model.named_parameters())
+    for k in pnames:
+        g = params[k].grad
+        gnone.append(g is None)
+        if g is None:
+            gnorm.append(0.0)
+            ghead.append(np.zeros(8, np.float32))
+        else:
+            gnorm.append(float(g.double().norm().item()))
+            h8 = np.zeros(8, np.float32)
+            flat = g.flatten()[:8].numpy()
+            h8[:flat.size] = flat
+            ghead.append(h8)
+    res["grad_norm"] = np.array(gnorm, np.float64)
+    res["grad_head"] = np.stack(ghead)
+    res["grad_none"] = np.array(gnone)
+    opt.step()
+    phead = []
+    for k in pnames:
+        h8 = np.zeros(8, np.float32)
+        flat = params[k].detach().flatten()[:8].numpy()
+        h8[:flat.size] = flat
+        phead.append(h8)
+    res["param_head_after_step"] = np.stack(phead)
+    sd = model.state_dict()
+    bn_keys = [k for k in sd if k.endswith("running_mean") or k.endswith("running_var")]
+    res["bn_keys"] = np.array(bn_keys)
+    res["bn_head_after_step"] = np.stack([sd[k].flatten()[:8].numpy().copy() for k in bn_keys])
+    res["keys"] = np.array([k for k, _ in keys])
+    res["shapes"] = np.array([",".join(map(str, s)) for _, s in keys])
+    res["param_names"] = np.array(pnames)
+    np.savez_compressed(os.path.join(out_dir, "mmfn_%s_b2.npz" % variant), **res)
+    print(variant, "keys", len(keys), "params", sum(p.numel() for p in model.parameters()),
+          "eval_loss", res["eval_loss"], "train_loss", res["train_loss"])
+
+
+def preprocessing_vectors(ref_dl, ref_du, out_dir):
+    res = {}
+    # histogram edge cases: bin edges, z == -2.0 boundary, clip > 5, out of range, right-closed last bin
+    pts = np.array([
+        [-16.0, -24.0, -2.0], [16.0, 8.0, -2.0], [15.999, 7.999, 0.0], [16.001, 0.0, 0.0],
+        [0.0, 0.0, -1.9999], [0.0, 0.0, -2.0001], [-16.0001, 0.0, 0.0], [0.124, -0.126, 1.0],
+        [1e6, 0.0, 0.0], [0.125, -0.125, 1.0],
+    ] + [[3.3, -3.3, 0.5]] * 7 + [[-5.01, 2.2, -2.5]] * 5, dtype=np.float64)
+    res["hist_pts"] = pts
+    res["hist_out"] = ref_dl.lidar_to_histogram_features(pts, crop=256)
+    rng = np.random.RandomState(7)
+    big = np.stack([rng.uniform(-20, 20, 4096), rng.uniform(-28, 12, 4096), rng.uniform(-3, 1, 4096)], 1)
+    big32 = big.astype(np.float32)
+    res["hist_rand_pts"] = big32
+    res["hist_rand_out"] = ref_dl.lidar_to_histogram_features(big32.astype(np.float64), crop=256)
+
+    ramp = (np.arange(300 * 400 * 3, dtype=np.int64) % 251).astype(np.uint8).reshape(300, 400, 3)
+
+    class _Img:
+        height, width = 300, 400
+
+        def resize(self, size):
+            return ramp
+
+    res["crop_out"] = ref_dl.scale_and_crop_image(_Img(), scale=1, crop=256)
+    r_small = rng.randn(50, 5)
+    r_big = rng.randn(100, 5)
+    r_big[:, 3] = np.abs(r_big[:, 3]) + 0.5
+    res["radar_small"], res["radar_big"] = r_small, r_big
+    res["radar_small_out"] = ref_dl.radar_to_size(r_small, (81, 5))
+    res["radar_big_out"] = ref_dl.radar_to_size(r_big, (81, 5))
+    # collate structure (data_utils.py:9-67)
+    samples = []
+    for n in (5, 9, 3):
+        samples.append({"vectormaps": [torch.from_numpy(rng.randn(n, 10, 5))],
+                        "velocity": float(n), "target_point": (1.0 * n, 2.0 * n),
+                        "fronts": [torch.full((3, 4, 4), n, dtype=torch.uint8)]})
+    col = ref_du.collate_single_cpu(samples)
+    res["collate_lane"] = col["vectormaps"][0][0].numpy()
+    res["collate_lane_num"] = col["vectormaps"][0][1].numpy()
+    res["collate_lmax"] = np.int64(col["vectormaps"][0][2])
+    res["collate_velocity"] = col["velocity"].numpy()
+    res["collate_target"] = np.stack([t.numpy() for t in col["target_point"]])
+    res["collate_fronts"] = col["fronts"][0].numpy()
+    res["collate_src"] = np.concatenate([s["vectormaps"][0].numpy().reshape(-1) for s in samples])
+    np.savez_compressed(os.path.join(out_dir, "preprocess.npz"), **res)
+
+
+def pid_vectors(ref_models, ref_cfg, out_dir):
+    cfg = ref_cfg.GlobalConfig()
+    # control_pid only touches config + the two PID controllers; avoid building a 105 M-param net
+    net = ref_models.model_vec.MMFN.__new__(ref_models.model_vec.MMFN)
+    torch.nn.Module.__init__(net)
+    net.config = cfg
+    P = ref_models.model_vec.PIDController
+    net.turn_controller = P(cfg.turn_KP, cfg.turn_KI, cfg.turn_KD, cfg.turn_n)
+    net.speed_controller = P(cfg.speed_KP, cfg.speed_KI, cfg.speed_KD, cfg.speed_n)
+    rng = np.random.RandomState(3)
+    wps = rng.randn(5, 1, 4, 2).astype(np.float32) * 2.0
+    vels = np.abs(rng.randn(5, 1)).astype(np.float32) * 3.0
+    vels[2] = 0.0
+    outs = []
+    for wp, v in zip(wps, vels):
+        s, t, b, meta = net.control_pid(torch.from_numpy(wp.copy()), torch.from_numpy(v.copy()))
+        outs.append([float(s), float(t), float(b), meta["angle"], meta["desired_speed"], meta["delta"]])
+    np.savez_compressed(os.path.join(out_dir, "pid.npz"), wps=wps, vels=vels, outs=np.array(outs))
+
+
+def main():
+    if not os.path.isdir(REF):
+        print("reference mount %s absent: golden vectors can only be generated in the authoring "
+              "container; keeping the committed fixtures" % REF)
+        return
+    install_shims()
+    import importlib
+    ref_models = types.SimpleNamespace(
+        model_vec=importlib.import_module("mmfn_utils.models.model_vec"),
+        model_img=importlib.import_module("mmfn_utils.models.model_img"),
+        model_rad=importlib.import_module("mmfn_utils.models.model_rad"))
+    ref_dl = importlib.import_module("mmfn_utils.datasets.dataloader")
+    ref_du = importlib.import_module("mmfn_utils.datasets.data_utils")
+    ref_cfg = importlib.import_module("mmfn_utils.datasets.config")
+    out_dir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(out_dir, exist_ok=True)
+    torch.set_num_threads(8)
+    preprocessing_vectors(ref_dl, ref_du, out_dir)
+    pid_vectors(ref_models, ref_cfg, out_dir)
+    for variant in ("vec", "img", "rad"):
+        run_variant(variant, ref_models, ref_dl, ref_cfg, out_dir)
+
+
+if __name__ == "__main__":
+    main()

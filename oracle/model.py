@@ -1,0 +1,441 @@
+"""Plain-PyTorch fp32 restatement of the MMFN network (test oracle, CPU).
+
+TEST INFRASTRUCTURE — see oracle/__init__.py.  Every class cites the reference
+file:line (relative to /root/reference/team_code/mmfn_utils/models/) whose
+behaviour it restates.  The module tree is laid out so that ``state_dict()``
+yields exactly the reference's keys, shapes and ordering,
+which is what lets one deterministic parameter fill drive reference, oracle and
+the HIP product identically.
+
+Variants: "vec" (model_vec.py), "img" (model_img.py), "rad" (model_rad.py).
+"""
+import math
+from collections import deque
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+# --------------------------------------------------------------------------
+# ResNet-18/34 trunk with torchvision's attribute names.  torchvision 0.11.3 is
+# a third-party dependency absent from /root/reference (Dockerfile:41); its
+# BasicBlock ResNet is restated here: conv7x7s2-bn-relu-maxpool3x3s2, then
+# stages of BasicBlocks [3,4,6,3] / [2,2,2,2]; all convs bias-free.
+# Call sites: model_vec.py:22,58 and the stage-wise calls at :509-521,539-593.
+# --------------------------------------------------------------------------
+class _BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(
+                nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        skip = x if self.downsample is None else self.downsample(x)
+        return self.relu(y + skip)
+
+
+class _ResNetTrunk(nn.Module):
+    def __init__(self, depths, in_channels=3):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        widths = (64, 128, 256, 512)
+        cin = 64
+        for i, (w, d) in enumerate(zip(widths, depths)):
+            blocks = []
+            for j in range(d):
+                blocks.append(_BasicBlock(cin, w, 2 if (j == 0 and i > 0) else 1))
+                cin = w
+            setattr(self, "layer%d" % (i + 1), nn.Sequential(*blocks))
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Sequential()  # reference strips fc (model_vec.py:23,59)
+
+    def stem(self, x):
+        return self.maxpool(self.relu(self.bn1(self.conv1(x))))
+
+
+class _ImageBranch(nn.Module):
+    """model_vec.py:11-31 (ImageCNN): resnet34 under the attribute ``features``."""
+
+    def __init__(self, normalize=True):
+        super().__init__()
+        self.normalize = normalize
+        self.features = _ResNetTrunk((3, 4, 6, 3), 3)
+
+
+class _LidarBranch(nn.Module):
+    """model_vec.py:47-70 (LidarEncoder): resnet18, 2-channel stem, under ``_model``."""
+
+    def __init__(self):
+        super().__init__()
+        self._model = _ResNetTrunk((2, 2, 2, 2), 2)
+
+
+def normalize_imagenet(x):
+    """model_vec.py:33-44: per-channel (x-mean)/std on raw 0..255 values (no /255)."""
+    # python-scalar arithmetic per channel, exactly as the reference writes it (ATen evaluates
+    # tensor / python_scalar as tensor * (1/scalar); a broadcast tensor divide differs by 1 ulp)
+    return torch.stack([(x[:, c] - IMAGENET_MEAN[c]) / IMAGENET_STD[c] for c in range(3)], dim=1)
+
+
+# --------------------------------------------------------------------------
+# GPT fusion transformer: model_vec.py:73-246 (RadarGPT model_rad.py:887-1001
+# differs only in carrying a 4th modality, i.e. 256 tokens).
+# --------------------------------------------------------------------------
+class _SelfAttention(nn.Module):
+    def __init__(self, c, heads, attn_p, resid_p):
+        super().__init__()
+        self.key = nn.Linear(c, c)
+        self.query = nn.Linear(c, c)
+        self.value = nn.Linear(c, c)
+        self.attn_drop = nn.Dropout(attn_p)
+        self.resid_drop = nn.Dropout(resid_p)
+        self.proj = nn.Linear(c, c)
+        self.n_head = heads
+
+    def forward(self, x):
+        b, t, c = x.shape
+        hs = c // self.n_head
+        split = lambda y: y.view(b, t, self.n_head, hs).transpose(1, 2)
+        k, q, v = split(self.key(x)), split(self.query(x)), split(self.value(x))
+        att = torch.softmax((q @ k.transpose(-2, -1)) * (1.0 / math.sqrt(hs)), dim=-1)
+        y = (self.attn_drop(att) @ v).transpose(1, 2).reshape(b, t, c)
+        return self.resid_drop(self.proj(y))
+
+
+class _Block(nn.Module):
+    def __init__(self, c, heads, exp, attn_p, resid_p):
+        super().__init__()
+        self.ln1 = nn.LayerNorm(c)
+        self.ln2 = nn.LayerNorm(c)
+        self.attn = _SelfAttention(c, heads, attn_p, resid_p)
+        self.mlp = nn.Sequential(nn.Linear(c, exp * c), nn.ReLU(True),
+                                 nn.Linear(exp * c, c), nn.Dropout(resid_p))
+
+    def forward(self, x):
+        x = x + self.attn(self.ln1(x))
+        return x + self.mlp(self.ln2(x))
+
+
+class _GPT(nn.Module):
+    def __init__(self, c, cfg, n_modal):
+        super().__init__()
+        self.n_embd = c
+        self.n_modal = n_modal
+        self.anchors = cfg.vert_anchors * cfg.horz_anchors
+        self.grid = (cfg.vert_anchors, cfg.horz_anchors)
+        self.pos_emb = nn.Parameter(torch.zeros(1, n_modal * cfg.seq_len * self.anchors, c))
+        self.vel_emb = nn.Linear(1, c)
+        self.drop = nn.Dropout(cfg.embd_pdrop)
+        self.blocks = nn.Sequential(*[
+            _Block(c, cfg.n_head, cfg.block_exp, cfg.attn_pdrop, cfg.resid_pdrop)
+            for _ in range(cfg.n_layer)])
+        self.ln_f = nn.LayerNorm(c)
+        for m in self.modules():  # model_vec.py:170-177
+            if isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0.0, 0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
+
+    def forward(self, maps, velocity):
+        """maps: list of [B,C,8,8] pooled feature maps (token order = list order)."""
+        b = maps[0].shape[0]
+        tok = torch.cat([m.flatten(2).transpose(1, 2) for m in maps], dim=1)  # [B, n*64, C]
+        x = self.drop(self.pos_emb + tok + self.vel_emb(velocity.unsqueeze(1)).unsqueeze(1))
+        x = self.ln_f(self.blocks(x))
+        x = x.view(b, len(maps), self.grid[0], self.grid[1], self.n_embd).permute(0, 1, 4, 2, 3)
+        return [x[:, i].contiguous() for i in range(len(maps))]
+
+
+# --------------------------------------------------------------------------
+# VectorNet lane encoder: model_vec.py:248-416.
+# --------------------------------------------------------------------------
+class _PolyMLP(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(cin, cout), nn.LayerNorm(cout), nn.ReLU())
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class _Subgraph(nn.Module):
+    def __init__(self, cin, hidden, n_layers):
+        super().__init__()
+        self.layers = nn.Sequential()
+        for i in range(n_layers):
+            self.layers.add_module("mlp_%d" % i, _PolyMLP(cin, hidden))
+            cin = 2 * hidden
+
+    def forward(self, x):  # [B, L, V, d]; padded rows are NOT masked
+        for layer in self.layers:
+            y = layer(x)
+            pooled = y.max(dim=-2, keepdim=True).values.expand_as(y)
+            x = torch.cat([y, pooled], dim=-1)
+        return x.max(dim=-2).values
+
+
+class _MaskSelfAttention(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.heads = heads
+        self.scale = (dim // heads) ** -0.5
+        self.attend = nn.Softmax(dim=-1)
+        self.to_qkv = nn.Linear(dim, 3 * dim, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(dim, dim), nn.Dropout(0.0))
+
+    def forward(self, x, mask):
+        b, n, d = x.shape
+        hd = d // self.heads
+        q, k, v = (t.view(b, n, self.heads, hd).transpose(1, 2)
+                   for t in self.to_qkv(x).chunk(3, dim=-1))
+        dots = (q @ k.transpose(-1, -2)) * self.scale
+        dots = dots.masked_fill(mask.unsqueeze(1) == 0, -1e9)
+        out = (self.attend(dots) @ v).transpose(1, 2).reshape(b, n, d)
+        return self.to_out(out)
+
+
+class _VectornetEncoder(nn.Module):
+    def __init__(self, lane_channels=7, hidden=64, layers=3, pos_dim=64, heads=2, fusion_dim=128):
+        super().__init__()
+        self.lane_subgraph = _Subgraph(lane_channels, hidden, layers)
+        self.pos_emb = nn.Sequential(nn.Linear(2, pos_dim), nn.LayerNorm(pos_dim), nn.GELU(),
+                                     nn.Linear(pos_dim, pos_dim))
+        self.L2L = _MaskSelfAttention(2 * hidden, heads)
+        self.agent_fusion = nn.Sequential(nn.Linear(pos_dim + 2 * hidden, fusion_dim),
+                                          nn.LayerNorm(fusion_dim), nn.GELU(),
+                                          nn.Linear(fusion_dim, 2 * hidden))
+        self.generator = nn.Sequential(nn.Linear(2 * hidden, hidden), nn.LayerNorm(hidden),
+                                       nn.GELU(), nn.Linear(hidden, 64 * 64 * 64))
+
+    @staticmethod
+    def lane_to_vector(lane):
+        """model_vec.py:368-381: [.., n, 5] nodes -> [.., n-1, 7] vectors."""
+        return torch.cat([lane[..., :-1, 0:2], lane[..., 1:, 0:2], lane[..., 1:, 2:]], dim=-1).float()
+
+    def forward(self, data):
+        lane, lane_num, max_lane = data[0][0], data[1][0], data[2]
+        max_lane = int(max_lane.reshape(-1)[0]) if torch.is_tensor(max_lane) else int(max_lane)
+        b = lane.shape[0]
+        tok = self.lane_subgraph(self.lane_to_vector(lane))
+        counts = lane_num.reshape(b).to(torch.int64)
+        mask = (torch.arange(max_lane, device=lane.device)[None, :] < counts[:, None]).float()[:, None, :]
+        tok = self.L2L(tok, mask)
+        pos = self.pos_emb(torch.zeros(b, tok.shape[1], 2, device=lane.device))
+        fused = self.agent_fusion(torch.cat([tok, pos], dim=-1))
+        return self.generator(fused[:, 0, :]).view(b, 64, 64, 64)
+
+
+# --------------------------------------------------------------------------
+# Radar GAT: model_rad.py:778-884.
+# --------------------------------------------------------------------------
+class _GATLayer(nn.Module):
+    def __init__(self, nfeat, nhid, dropout, alpha):
+        super().__init__()
+        self.W = nn.Parameter(torch.zeros(nfeat, 2 * nhid))
+        nn.init.xavier_normal_(self.W.data, gain=1.414)
+        self.a = nn.Parameter(torch.zeros(2 * nhid, nhid))
+        nn.init.xavier_normal_(self.a.data, gain=1.414)
+        self.dropout = dropout
+        self.alpha = alpha
+
+    def forward(self, h, adj):
+        wh = h @ self.W
+        e = F.leaky_relu(wh @ self.a, self.alpha)
+        att = torch.softmax(torch.where(adj > 0, e, torch.full_like(e, -9e15)), dim=-1)
+        att = F.dropout(att, self.dropout, self.training)
+        return F.elu(att @ wh)
+
+
+class _SpGAT(nn.Module):
+    def __init__(self, nfeat, nhid, dropout, alpha, nheads):
+        super().__init__()
+        self.dropout = dropout
+        self.nheads = nheads
+        for i in range(nheads):
+            self.add_module("attention_%d" % i, _GATLayer(nfeat, nhid, dropout, alpha))
+        self.mlp_1 = nn.Sequential(nn.Linear(nheads * nhid, 256), nn.Dropout(dropout))
+        self.mlp_2 = nn.Sequential(nn.Linear(nheads * nhid, 128), nn.Dropout(dropout))
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+
+    def forward(self, x, adj):
+        x = F.dropout(x, self.dropout, self.training)
+        x = torch.cat([getattr(self, "attention_%d" % i)(x, adj) for i in range(self.nheads)], dim=1)
+        x = F.dropout(x, self.dropout, self.training)
+        x = self.mlp_1(F.elu(x))
+        x = self.mlp_2(x.transpose(1, 2))
+        x = x.reshape(x.shape[0], 8, 8, 512).transpose(1, 3)
+        return F.log_softmax(x, dim=1)
+
+
+# --------------------------------------------------------------------------
+# Encoder: model_vec.py:418-598, model_img.py:249-423, model_rad.py:419-611.
+# --------------------------------------------------------------------------
+class _Encoder(nn.Module):
+    def __init__(self, cfg, variant):
+        super().__init__()
+        self.config = cfg
+        self.variant = variant
+        self.avgpool = nn.AdaptiveAvgPool2d((cfg.vert_anchors, cfg.horz_anchors))
+        self.image_encoder = _ImageBranch(True)
+        self.img_map_encoder = _ImageBranch(True)
+        self.lidar_encoder = _LidarBranch()
+        if variant in ("vec", "rad"):
+            self.vectornet_encoder = _VectornetEncoder()
+        if variant == "rad":
+            self.radar_encoder = _SpGAT(5, cfg.hidden, cfg.attn_pdrop, cfg.alpha, cfg.nb_heads)
+        n_modal = cfg.n_views + 2
+        for i, c in enumerate((64, 128, 256, 512)):
+            extra = 1 if (variant == "rad" and i == 3) else 0
+            setattr(self, "transformer%d" % (i + 1), _GPT(c, cfg, n_modal + extra))
+
+    def forward(self, image_list, lidar_list, maps_list, vectormaps, radar_list, radar_adj, velocity,
+                taps=None):
+        cfg = self.config
+        images = [normalize_imagenet(im) for im in image_list]
+        bz, _, h, w = lidar_list[0].shape
+        cfg.n_views = len(images) // cfg.seq_len  # reference mutates config (model_vec.py:504)
+        img_t = torch.stack(images, dim=1).view(-1, 3, h, w)
+        lid_t = torch.stack(lidar_list, dim=1).view(-1, lidar_list[0].shape[1], h, w)
+        img_net, map_net, lid_net = (self.image_encoder.features, self.img_map_encoder.features,
+                                     self.lidar_encoder._model)
+        f_img = img_net.layer1(img_net.stem(img_t))
+        f_lid = lid_net.layer1(lid_net.stem(lid_t))
+        if self.variant == "img":
+            map_t = torch.stack(maps_list, dim=1).view(-1, 3, h, w)
+            f_map = map_net.layer1(map_net.stem(map_t))  # maps are NOT normalised (model_img.py:337)
+        else:
+            f_map = self.vectornet_encoder(vectormaps)
+        if taps is not None:
+            taps["stage1"] = (f_img, f_lid, f_map)
+        f_rad = None
+        for s in range(4):
+            if s > 0:
+                f_img = getattr(img_net, "layer%d" % (s + 1))(f_img)
+                f_map = getattr(map_net, "layer%d" % (s + 1))(f_map)
+                f_lid = getattr(lid_net, "layer%d" % (s + 1))(f_lid)
+            pooled = [self.avgpool(f_img), self.avgpool(f_lid), self.avgpool(f_map)]
+            if self.variant == "rad" and s == 3:
+                rad_t = torch.stack(radar_list, dim=1).view(bz * cfg.seq_len, 81, 5)
+                f_rad = self.radar_encoder(rad_t, radar_adj[0])
+                pooled.append(f_rad)
+            outs = getattr(self, "transformer%d" % (s + 1))(pooled, velocity)
+            scale = 8 >> s
+            if scale > 1:
+                outs = [F.interpolate(o, scale_factor=scale, mode="bilinear", align_corners=True)
+                        for o in outs]
+            f_img, f_lid, f_map = f_img + outs[0], f_lid + outs[1], f_map + outs[2]
+            if f_rad is not None:
+                f_rad = f_rad + outs[3]
+            if taps is not None:
+                taps["fused%d" % (s + 1)] = (f_img, f_lid, f_map)
+        gap = lambda net, f: torch.flatten(net.avgpool(f), 1)
+        feats = [gap(img_net, f_img), gap(lid_net, f_lid), gap(map_net, f_map)]
+        if f_rad is not None:
+            feats.append(gap(self.radar_encoder, f_rad))
+        return torch.stack(feats, dim=1).sum(dim=1)
+
+
+class PIDController(object):
+    """model_vec.py:601-623."""
+
+    def __init__(self, K_P=1.0, K_I=0.0, K_D=0.0, n=20):
+        self._K_P, self._K_I, self._K_D = K_P, K_I, K_D
+        self._window = deque([0 for _ in range(n)], maxlen=n)
+        self._max = 0.0
+        self._min = 0.0
+
+    def step(self, error):
+        self._window.append(error)
+        self._max = max(self._max, abs(error))
+        self._min = -abs(self._max)
+        if len(self._window) >= 2:
+            integral = np.mean(self._window)
+            derivative = self._window[-1] - self._window[-2]
+        else:
+            integral, derivative = 0.0, 0.0
+        return self._K_P * error + self._K_I * integral + self._K_D * derivative
+
+
+class OracleMMFN(nn.Module):
+    """model_vec.py:626-726 (MMFN): encoder -> join MLP -> 4 GRU steps -> waypoints."""
+
+    def __init__(self, config, device="cpu", variant="vec"):
+        super().__init__()
+        self.device = device
+        self.config = config
+        self.variant = variant
+        self.pred_len = config.pred_len
+        self.turn_controller = PIDController(config.turn_KP, config.turn_KI, config.turn_KD, config.turn_n)
+        self.speed_controller = PIDController(config.speed_KP, config.speed_KI, config.speed_KD, config.speed_n)
+        self.encoder = _Encoder(config, variant).to(device)
+        self.join = nn.Sequential(nn.Linear(512, 256), nn.ReLU(inplace=True),
+                                  nn.Linear(256, 128), nn.ReLU(inplace=True),
+                                  nn.Linear(128, 64), nn.ReLU(inplace=True)).to(device)
+        self.decoder = nn.GRUCell(input_size=2, hidden_size=64).to(device)
+        self.output = nn.Linear(64, 2).to(device)
+
+    def forward(self, image_list, lidar_list, maps_list, vectormaps_list, radar_list, radar_adj,
+                target_point, velocity, taps=None):
+        fused = self.encoder(image_list, lidar_list, maps_list, vectormaps_list, radar_list,
+                             radar_adj, velocity, taps=taps)
+        if taps is not None:
+            taps["fused"] = fused
+        z = self.join(fused)
+        x = torch.zeros(z.shape[0], 2, dtype=z.dtype, device=z.device)
+        wps = []
+        for _ in range(self.pred_len):
+            z = self.decoder(x + target_point, z)  # target point is ADDED (model_vec.py:674)
+            x = x + self.output(z)
+            wps.append(x)
+        return torch.stack(wps, dim=1)
+
+    def control_pid(self, waypoints, velocity):
+        """model_vec.py:684-726."""
+        assert waypoints.size(0) == 1
+        wp = waypoints[0].data.cpu().numpy()
+        wp[:, 1] *= -1
+        speed = velocity[0].data.cpu().numpy()
+        desired_speed = np.linalg.norm(wp[0] - wp[1]) * 2.0
+        brake = desired_speed < self.config.brake_speed or (speed / desired_speed) > self.config.brake_ratio
+        aim = (wp[1] + wp[0]) / 2.0
+        angle = np.degrees(np.pi / 2 - np.arctan2(aim[1], aim[0])) / 90
+        if speed < 0.01:
+            angle = np.array(0.0)
+        steer = np.clip(self.turn_controller.step(angle), -1.0, 1.0)
+        delta = np.clip(desired_speed - speed, 0.0, self.config.clip_delta)
+        throttle = np.clip(self.speed_controller.step(delta), 0.0, self.config.max_throttle)
+        throttle = throttle if not brake else 0.0
+        metadata = {
+            "speed": float(speed.astype(np.float64)), "steer": float(steer),
+            "throttle": float(throttle), "brake": float(brake),
+            "wp_2": tuple(wp[1].astype(np.float64)), "wp_1": tuple(wp[0].astype(np.float64)),
+            "desired_speed": float(desired_speed.astype(np.float64)),
+            "angle": float(angle.astype(np.float64)), "aim": tuple(aim.astype(np.float64)),
+            "delta": float(delta.astype(np.float64)),
+        }
+        return steer, throttle, brake, metadata
+
+
+def l1_waypoint_loss(pred_wp, gt_wp):
+    """run_steps/phase2_train_net.py:104."""
+    return F.l1_loss(pred_wp, gt_wp, reduction="none").mean()
