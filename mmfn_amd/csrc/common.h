@@ -1,0 +1,63 @@
+// Shared device/host helpers for the MMFN gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mmfn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MMFN_LAUNCH_CHECK()                        \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Counter-based RNG (splitmix64 finaliser).  One 32-bit draw per (seed, step, stream, index);
+// the backward pass regenerates the same mask instead of storing it.
+__device__ __forceinline__ uint32_t mmfn_rng_u32(uint64_t key, uint64_t idx) {
+  uint64_t z = key + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ uint64_t mmfn_rng_key(const uint64_t* state, uint32_t stream) {
+  // state[0] = seed, state[1] = step counter
+  uint64_t k = state[0] * 0xD1342543DE82EF95ull + state[1] * 0xA24BAED4963EE407ull;
+  return k ^ ((uint64_t)stream << 40) ^ (uint64_t)stream * 0x9E3779B1ull;
+}
+// keep-mask scale: 0 if dropped, 1/(1-p) if kept
+__device__ __forceinline__ float mmfn_dropout_scale(uint64_t key, uint64_t idx, float p, float inv_keep) {
+  float u = (float)(mmfn_rng_u32(key, idx) >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.0f;
+}
+
+__device__ __forceinline__ float mmfn_gelu(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float mmfn_gelu_grad(float x) {
+  const float kInvSqrt2Pi = 0.39894228040143267794f;
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  return cdf + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,102 @@
+"""GPU parity of the fp32 MFMA GEMM / implicit-conv kernel vs plain torch fp32 on CPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, tol=2e-4):
+    got = got.detach().cpu().double()
+    ref = ref.double()
+    scale = ref.abs().max().item() + 1e-6
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, "max err %g vs scale %g" % (err, scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (128, 128, 64), (100, 70, 36), (6144, 192, 64),
+                                   (333, 257, 129), (32, 256, 512), (2048, 512, 4608), (37, 64, 7), (8, 3, 1)])
+@pytest.mark.parametrize("tile", [0, 1, 2])
+def test_linear_forms(M, N, K, tile):
+    from mmfn_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g)
+    b = torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    xd, wd, bd, dyd = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
+    _close(ops.linear_fwd(xd, wd, bd, tile=tile), x @ w.t() + b)
+    _close(ops.linear_fwd(xd, wd, bd, relu=True, tile=tile), torch.relu(x @ w.t() + b))
+    _close(ops.linear_dx(dyd, wd, tile=tile), dy @ w)
+    _close(ops.linear_dw(dyd, xd, tile=tile), dy.t() @ x)
+    # forced split-K must agree
+    _close(ops.linear_dw(dyd, xd, tile=tile, splitk=3), dy.t() @ x)
+    _close(ops.linear_fwd(xd, wd, bd, tile=tile, splitk=2), x @ w.t() + b)
+
+
+def test_epilogue_flags():
+    from mmfn_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 192, 128, 64
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    r, aux = torch.randn(M, N, generator=g), torch.randn(M, N, generator=g)
+    c0 = torch.randn(M, N, generator=g)
+    xd, wd, bd, rd, auxd = (t.to(dev) for t in (x, w, b, r, aux))
+    _close(ops.linear_fwd(xd, wd, bd, res=rd, ldr=N), x @ w.t() + b + r)
+    _close(ops.linear_fwd(xd, wd, bd, gelu=True), F.gelu(x @ w.t() + b))
+    _close(ops.linear_fwd(xd, wd, None, aux=auxd, ldaux=N), (x @ w.t()) * (aux > 0))
+    out = c0.to(dev).clone()
+    _close(ops.linear_fwd(xd, wd, bd, out=out, accum=True), x @ w.t() + b + c0)
+    # dropout: kept entries are scaled by 1/(1-p), drop rate ~ p, same mask when re-run
+    state = torch.tensor([1234, 7], dtype=torch.int64, device=dev)
+    y1 = ops.linear_fwd(xd, wd, bd, drop_p=0.25, rng_state=state, rng_stream=3).cpu()
+    y2 = ops.linear_fwd(xd, wd, bd, drop_p=0.25, rng_state=state, rng_stream=3).cpu()
+    assert torch.equal(y1, y2)
+    ref = x @ w.t() + b
+    kept = y1 != 0
+    assert 0.70 < kept.float().mean().item() < 0.80
+    _close(y1[kept], (ref / 0.75)[kept])
+    y3 = ops.linear_fwd(xd, wd, bd, drop_p=0.25, rng_state=state, rng_stream=4).cpu()
+    assert not torch.equal(y1 != 0, y3 != 0)
+
+
+CONVS = [  # B, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 16, 64, 64, 3, 1, 1), (2, 16, 16, 64, 128, 3, 2, 1), (2, 16, 16, 64, 128, 1, 2, 0),
+    (1, 8, 8, 256, 512, 3, 2, 1), (3, 9, 11, 16, 32, 3, 1, 1), (2, 32, 32, 3, 64, 7, 2, 3),
+    (2, 32, 32, 2, 64, 7, 2, 3), (2, 8, 8, 512, 512, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+@pytest.mark.parametrize("tile", [0, 1, 2])
+def test_conv_forms(cfg, tile):
+    from mmfn_amd import ops
+    dev = _dev()
+    B, H, W, Cin, Cout, k, s, p = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.1
+    y_ref = F.conv2d(x, w, stride=s, padding=p)
+    dy = torch.randn(y_ref.shape, generator=g)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    w_ohwi = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    dy_nhwc = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    y = ops.conv2d_fwd(x_nhwc, w_ohwi, s, p, tile=tile)
+    _close(y.permute(0, 3, 1, 2), y_ref)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(xr, wr, stride=s, padding=p).backward(dy)
+    if Cin % 4 == 0:
+        dx = ops.conv2d_dgrad(dy_nhwc, w_ohwi, tuple(x_nhwc.shape), s, p, tile=tile)
+        _close(dx.permute(0, 3, 1, 2), xr.grad)
+    dw = ops.conv2d_wgrad(dy_nhwc, x_nhwc, tuple(w_ohwi.shape), s, p, tile=tile)
+    _close(dw.permute(0, 3, 1, 2), wr.grad)
+    dw2 = ops.conv2d_wgrad(dy_nhwc, x_nhwc, tuple(w_ohwi.shape), s, p, tile=tile, splitk=4)
+    _close(dw2.permute(0, 3, 1, 2), wr.grad)
