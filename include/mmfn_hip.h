@@ -88,6 +88,106 @@ int mmfn_gemm_f32(const mmfn_gemm_desc* d, void* stream);
 /* bytes of split-K workspace mmfn_gemm_f32 needs for this descriptor (0 if none) */
 int64_t mmfn_gemm_workspace_bytes(const mmfn_gemm_desc* d);
 
+/* ---- normalisation ------------------------------------------------------------------- */
+/* scratch for the norm kernels below (bytes); one buffer of this size for the largest C suffices */
+int64_t mmfn_norm_workspace_bytes(int C);
+/* BatchNorm2d training statistics over x[M,C] (NHWC rows): mean/rstd (biased var, eps) for the
+ * normalisation, running stats updated with momentum and the UNBIASED variance, and
+ * num_batches_tracked += 1.  Replaces aten native_batch_norm(training=True) under every
+ * torchvision BasicBlock / stem bn1 (model_vec.py:510,516,520-521,539-541,...). */
+int mmfn_bn_train_stats_f32(const float* x, int64_t M, int C, float eps, float momentum, float* mean, float* rstd,
+                            float* running_mean, float* running_var, int64_t* num_batches_tracked, void* workspace,
+                            void* stream);
+/* eval mode: mean = running_mean, rstd = 1/sqrt(running_var + eps) */
+int mmfn_bn_eval_prepare_f32(const float* running_mean, const float* running_var, float eps, int C, float* mean,
+                             float* rstd, void* stream);
+/* y = [relu]( (x - mean) * rstd * weight + bias [+ res] ) */
+int mmfn_bn_apply_f32(const float* x, const float* res, float* y, int64_t M, int C, const float* mean, const float* rstd,
+                      const float* weight, const float* bias, int relu, void* stream);
+/* backward of y = relu?(bn(x) [+res]): g = dL/dy; if y != NULL the ReLU mask (y > 0) is applied first.
+ * Writes dx, dweight, dbias and (optionally) ge_out = masked g, the gradient of the residual branch. */
+int mmfn_bn_bwd_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean, const float* rstd,
+                    const float* weight, float* dx, float* ge_out, float* dweight, float* dbias, void* workspace,
+                    void* stream);
+/* LayerNorm over rows of x[M,C] (C % 64 == 0, C <= 512), optional fused activation on the output
+ * (act: 0 none, 1 ReLU, 2 exact GELU).  Replaces aten native_layer_norm (+relu/gelu) of
+ * model_vec.py:117-118,162 (GPT) and :252,335-336,345-346,352-353 (VectorNet). */
+int mmfn_layernorm_fwd_f32(const float* x, const float* weight, const float* bias, float* y, float* mean, float* rstd,
+                           int M, int C, float eps, int act, void* stream);
+/* dx = LN'(g * act'(.)) [+ dres]; dweight, dbias reduced over rows */
+int mmfn_layernorm_bwd_f32(const float* g, const float* x, const float* weight, const float* bias, const float* mean,
+                           const float* rstd, const float* dres, float* dx, float* dweight, float* dbias, int M, int C,
+                           int act, void* workspace, void* stream);
+/* out[c] = sum_r in[r*ld + c]   (bias gradients) */
+int64_t mmfn_colsum_workspace_bytes(int64_t M, int C);
+int mmfn_colsum_f32(const float* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream);
+
+/* ---- pooling / token assembly / upsampling on NHWC maps ----------------------------------- */
+/* MaxPool2d(3,2,1) with first-max argmax (uint8 tap index) — torchvision stem (model_vec.py:512,518) */
+int mmfn_maxpool3x3s2_fwd_f32(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
+int mmfn_maxpool3x3s2_bwd_f32(const float* gy, const uint8_t* idx, float* gx, int B, int H, int W, int C, void* stream);
+/* tok[b, m*64+a, :] = dropout(pos_emb + AdaptiveAvgPool2d(8,8)(F_m)[b,a,:] + vel_emb(velocity[b]))
+ * for n_modal feature maps F_m[B,S,S,C]: model_vec.py:527-529 + GPT.forward :223-235 in one pass. */
+int mmfn_tokens_fwd_f32(const float* const* feats, int n_modal, int B, int S, int C, const float* pos, const float* vel_w,
+                        const float* vel_b, const float* velocity, float* tok, float drop_p, const uint64_t* rng_state,
+                        uint32_t rng_stream, void* stream);
+int64_t mmfn_tokens_bwd_workspace_bytes(int T, int C);
+/* in place: gtok *= dropout mask; dpos[T,C], dvel_w[C], dvel_b[C] */
+int mmfn_tokens_bwd_f32(float* gtok, int B, int T, int C, const float* velocity, float* dpos, float* dvel_w, float* dvel_b,
+                        float drop_p, const uint64_t* rng_state, uint32_t rng_stream, void* workspace, void* stream);
+/* out = feat + bilinear_upsample(align_corners=True)(tok[:, m*64:(m+1)*64, :] as 8x8xC)   (model_vec.py:531-536) */
+int mmfn_upsample_add_fwd_f32(const float* feat, const float* tok, float* out, int B, int S, int C, int T, int m,
+                              void* stream);
+/* adjoint of the upsample: gtok[:, m*64+a, :] = sum_pixels w(a,pixel) G[b,pixel,:] */
+int mmfn_upsample_adj_f32(const float* G, float* gtok, int B, int S, int C, int T, int m, void* stream);
+/* dF = G + avgpool-adjoint(gtok[:, m*64.., :]) */
+int mmfn_pool_bcast_add_f32(const float* G, const float* gtok, float* dF, int B, int S, int C, int T, int m, void* stream);
+/* out[b,c] = sum_m mean_p feats[m][b,p,c]   (model_vec.py:585-596) and its backward */
+int mmfn_gap_sum_fwd_f32(const float* const* feats, int n, int B, int P, int C, float* out, void* stream);
+int mmfn_gap_sum_bwd_f32(const float* g, float* const* outs, int n, int B, int P, int C, void* stream);
+/* in[B,R,Cc] -> out[B,Cc,R] */
+int mmfn_transpose_f32(const float* in, float* out, int B, int R, int Cc, void* stream);
+
+/* ---- fused attention --------------------------------------------------------------------- */
+/* o = softmax(q k^T * scale [keys >= kv_len[b] masked]) (dropout) v per (batch, head); q/k/v rows
+ * have stride ld, head h at columns [h*HS, (h+1)*HS); T <= 256, HS in {16,32,64,128}.
+ * Replaces the bmm/softmax/dropout/bmm + transposes of SelfAttention.forward (model_vec.py:96-105)
+ * and MaskSelfAttention.forward (model_vec.py:308-322).  lse[B,NH,T] is saved for the backward. */
+int mmfn_attention_fwd_f32(const float* q, const float* k, const float* v, int ld, float* o, int ldo, float* lse, int B,
+                           int T, int NH, int HS, float scale, const int32_t* kv_len, float drop_p,
+                           const uint64_t* rng_state, uint32_t rng_stream, void* stream);
+int mmfn_attention_bwd_f32(const float* q, const float* k, const float* v, int ld, const float* o, const float* dO, int ldo,
+                           const float* lse, float* delta, float* dq, float* dk, float* dv, int ldg, int B, int T, int NH,
+                           int HS, float scale, const int32_t* kv_len, float drop_p, const uint64_t* rng_state,
+                           uint32_t rng_stream, void* stream);
+
+/* ---- waypoint head: GRUCell x steps + Linear(64,2) + L1 loss (model_vec.py:666-680, phase2:104) ---- */
+int64_t mmfn_gru_head_part_floats(void);
+int mmfn_gru_head_fwd_f32(const float* z0, const float* target, const float* w_ih, const float* w_hh, const float* b_ih,
+                          const float* b_hh, const float* w_out, const float* b_out, const float* gt, float* pred,
+                          float* hs, float* gates, float* xin, float* loss_terms, float* loss, int B, int steps,
+                          void* stream);
+int mmfn_gru_head_bwd_f32(const float* pred, const float* gt, const float* dpred, float gscale, const float* w_ih,
+                          const float* w_hh, const float* w_out, const float* hs, const float* gates, const float* xin,
+                          float* dz0, float* part, int B, int steps, void* stream);
+
+/* ---- optimizer (torch.optim.AdamW semantics, phase2_train_net.py:110,256) ---------------------- */
+int mmfn_step_advance(int64_t* step, void* stream);
+int mmfn_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, const int64_t* step, float grad_scale, void* stream);
+
+/* ---- sensor ingest (dataloader.py:271-308, model_vec.py:33-44,368-381) ------------------------- */
+int mmfn_ingest_rgb_u8(const uint8_t* in, float* out, int B, int H, int W, int crop, void* stream);
+int mmfn_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int P, const float* mean, const float* inv_std,
+                          void* stream);
+int mmfn_lidar_splat_f32(const float* pts, int B, int N, int stride_floats, float* out, int flip_y, void* stream);
+int mmfn_lane_to_vector_f32(const float* lane, float* vec, int64_t R, int n, void* stream);
+
+/* ---- VectorNet polyline max-pool + concat (model_vec.py:269-282) -------------------------------- */
+int mmfn_polyline_pool_fwd_f32(const float* y, float* out, uint8_t* arg, int R, int V, int H, int last, void* stream);
+int mmfn_polyline_pool_bwd_f32(const float* gout, const uint8_t* arg, float* gy, int R, int V, int H, int last,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

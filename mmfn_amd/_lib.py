@@ -41,18 +41,34 @@ class MMFNLibraryError(RuntimeError):
 
 _lib = None
 
-# name -> (restype, argtypes); every symbol declared in include/mmfn_hip.h is listed here and
-# tests/test_abi.py checks the two stay in sync.
-_SIGNATURES = {
-    "mmfn_abi_version": (_i32, []),
-    "mmfn_sizeof_gemm_desc": (_i32, []),
-    "mmfn_device_selftest": (_i32, [_vp]),
-    "mmfn_fill_f32": (_i32, [_vp, _f32, _i64, _vp]),
-    "mmfn_axpby_f32": (_i32, [_vp, _vp, _f32, _f32, _i64, _vp]),
-    "mmfn_rng_advance": (_i32, [_vp, _vp]),
-    "mmfn_gemm_f32": (_i32, [ctypes.POINTER(GemmDesc), _vp]),
-    "mmfn_gemm_workspace_bytes": (_i64, [ctypes.POINTER(GemmDesc)]),
-}
+HEADER_PATH = os.path.join(_HERE, "..", "include", "mmfn_hip.h")
+
+_CTYPES = {"int": _i32, "int32_t": _i32, "int64_t": _i64, "float": _f32, "uint32_t": ctypes.c_uint32,
+           "void": None}
+
+
+def _parse_header(path=HEADER_PATH):
+    """Derive ctypes signatures from the C declarations so the binding cannot drift from the ABI."""
+    import re
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    sigs = {}
+    for m in re.finditer(r"\b(int64_t|int)\s+(mmfn_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.POINTER(GemmDesc) if "mmfn_gemm_desc" in a else _vp)
+                else:
+                    base = a.replace("const", "").split()[0]
+                    argtypes.append(_CTYPES[base])
+        sigs[name] = (_CTYPES[ret], argtypes)
+    return sigs
+
+
+_SIGNATURES = _parse_header()
 
 
 def lib():

@@ -1,0 +1,364 @@
+// Fused multi-head attention for the GPT fusion transformers and VectorNet's lane attention,
+// fp32 on v_mfma_f32_32x32x2_f32 (model_vec.py:92-109 SelfAttention, :301-324 MaskSelfAttention).
+//
+// Shapes are tiny by GEMM standards (T = 192 or 256 tokens, head size 16..128, B*heads = 128
+// problems), so the unit of work is one wave = one 32-query tile against ALL keys:
+//   S^T[key, q] = K . Q^T      keys land in accumulator ROWS, queries in LANES, so the softmax
+//                              of a query is a register-local reduction (+ one cross-half swap),
+//   O^T[d, q]   = V^T . P^T    the accumulator tile of P^T is already laid out as the MFMA B
+//                              operand (row index <-> k slot), so probabilities never leave
+//                              registers: no LDS, no barriers, no [B,h,T,T] tensor in HBM.
+// K/V/Q fragments stream straight from L2 (the whole qkv of a sample is 1.2 MB).  The backward
+// runs two such passes (query-owned: dQ; key-owned: dK, dV) that recompute P from the saved
+// row log-sum-exp instead of storing it; dropout masks are regenerated from the counter RNG.
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+  const float* q; const float* k; const float* v;  // row stride ld, head h at column h*HS
+  float* o;                                         // [B*T, ldo]
+  float* lse;                                       // [B, NH, T]
+  const float* dO;                                  // backward: grad of o (ldo)
+  float* delta;                                     // [B, NH, T]  rowsum(dO * O)
+  float* dq; float* dk; float* dv;                  // row stride ldg
+  const int* kv_len;                                // optional [B]: keys >= kv_len[b] are masked
+  const uint64_t* rng_state;
+  int B, T, NH, ld, ldo, ldg;
+  float scale, drop_p;
+  uint32_t rng_stream;
+};
+
+__device__ __forceinline__ int rowmap(int r) { return (r & 3) + 8 * (r >> 2); }
+__device__ __forceinline__ f32x4 ld4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+template <int HS, int NKT>
+__global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnArgs a) {
+  constexpr int NC = HS / 8;
+  constexpr int ND = (HS + 31) / 32;
+  const int qt = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+  const int T = a.T;
+  const int q = qt * 32 + l31;
+  const bool qvalid = q < T;
+  const int kvlen = a.kv_len ? min(T, a.kv_len[b]) : T;
+  const size_t rowbase = (size_t)b * T;
+  const float* Qp = a.q + (rowbase + min(q, T - 1)) * a.ld + hd * HS + 4 * h;
+  f32x4 qf[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) qf[c] = ld4g(Qp + 8 * c);
+
+  f32x16 s[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+    const float* Kp = a.k + (rowbase + min(kt * 32 + l31, T - 1)) * a.ld + hd * HS + 4 * h;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const f32x4 kf = ld4g(Kp + 8 * c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[c][j], s[kt], 0, 0, 0);
+    }
+  }
+  // ---- softmax over keys (rows of S^T): register-local + one cross-half exchange
+  float mx = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + rowmap(r) + 4 * h;
+      const float v = key < kvlen ? s[kt][r] * a.scale : -INFINITY;
+      s[kt][r] = v;
+      mx = fmaxf(mx, v);
+    }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = expf(s[kt][r] - mx);
+      s[kt][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  if (qvalid && h == 0 && a.lse) a.lse[((size_t)b * a.NH + hd) * T + q] = mx + logf(sum);
+  const bool drop = a.drop_p > 0.f;
+  uint64_t key64 = 0;
+  float inv_keep = 1.f;
+  if (drop) { key64 = mmfn_rng_key(a.rng_state, a.rng_stream); inv_keep = 1.0f / (1.0f - a.drop_p); }
+  const uint64_t pbase = (((uint64_t)b * a.NH + hd) * T + q) * (uint64_t)T;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float p = s[kt][r] / sum;
+      if (drop) p *= mmfn_dropout_scale(key64, pbase + (uint64_t)(kt * 32 + rowmap(r) + 4 * h), a.drop_p, inv_keep);
+      s[kt][r] = p;
+    }
+  // ---- O^T = V^T . P^T
+  f32x16 o[ND];
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = min(kt * 32 + rowmap(r) + 4 * h, T - 1);
+      const float* Vp = a.v + (rowbase + key) * a.ld + hd * HS;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        const int d = dt * 32 + l31;
+        const float vv = d < HS ? Vp[d] : 0.f;
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[kt][r], o[dt], 0, 0, 0);
+      }
+    }
+  if (qvalid) {
+    float* Op = a.o + (rowbase + q) * a.ldo + hd * HS;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = dt * 32 + rowmap(r) + 4 * h;
+        if (d < HS) Op[d] = o[dt][r];
+      }
+  }
+}
+
+// query-owned backward pass: delta = rowsum(dO*O), dQ
+template <int HS, int NKT>
+__global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const AttnArgs a) {
+  constexpr int NC = HS / 8;
+  constexpr int ND = (HS + 31) / 32;
+  const int qt = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+  const int T = a.T;
+  const int q = qt * 32 + l31;
+  const bool qvalid = q < T;
+  const int qc = min(q, T - 1);
+  const int kvlen = a.kv_len ? min(T, a.kv_len[b]) : T;
+  const size_t rowbase = (size_t)b * T;
+  const float* Qp = a.q + (rowbase + qc) * a.ld + hd * HS + 4 * h;
+  const float* dOp = a.dO + (rowbase + qc) * a.ldo + hd * HS + 4 * h;
+  const float* Op = a.o + (rowbase + qc) * a.ldo + hd * HS + 4 * h;
+  f32x4 qf[NC], dof[NC];
+  float dl = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    qf[c] = ld4g(Qp + 8 * c);
+    dof[c] = ld4g(dOp + 8 * c);
+    const f32x4 of = ld4g(Op + 8 * c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dl += dof[c][j] * of[j];
+  }
+  const float delta = dl + __shfl_xor(dl, 32, 64);
+  const size_t statoff = ((size_t)b * a.NH + hd) * T + qc;
+  if (qvalid && h == 0) a.delta[statoff] = delta;
+  const float lse = a.lse[statoff];
+  const bool drop = a.drop_p > 0.f;
+  uint64_t key64 = 0;
+  float inv_keep = 1.f;
+  if (drop) { key64 = mmfn_rng_key(a.rng_state, a.rng_stream); inv_keep = 1.0f / (1.0f - a.drop_p); }
+  const uint64_t pbase = (((uint64_t)b * a.NH + hd) * T + q) * (uint64_t)T;
+
+  f32x16 ds[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    f32x16 st, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+    const size_t krow = (rowbase + min(kt * 32 + l31, T - 1)) * a.ld + hd * HS + 4 * h;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const f32x4 kf = ld4g(a.k + krow + 8 * c);
+      const f32x4 vf = ld4g(a.v + krow + 8 * c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[c][j], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[j], dof[c][j], dp, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + rowmap(r) + 4 * h;
+      const float p = key < kvlen ? expf(st[r] * a.scale - lse) : 0.f;
+      float dpt = dp[r];
+      if (drop) dpt *= mmfn_dropout_scale(key64, pbase + (uint64_t)key, a.drop_p, inv_keep);
+      ds[kt][r] = p * (dpt - delta) * a.scale;
+    }
+  }
+  f32x16 dq[ND];
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = min(kt * 32 + rowmap(r) + 4 * h, T - 1);
+      const float* Kp = a.k + (rowbase + key) * a.ld + hd * HS;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        const int d = dt * 32 + l31;
+        const float kk = d < HS ? Kp[d] : 0.f;
+        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk, ds[kt][r], dq[dt], 0, 0, 0);
+      }
+    }
+  if (qvalid) {
+    float* Gp = a.dq + (rowbase + q) * a.ldg + hd * HS;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = dt * 32 + rowmap(r) + 4 * h;
+        if (d < HS) Gp[d] = dq[dt][r];
+      }
+  }
+}
+
+// key-owned backward pass: dK, dV
+template <int HS, int NKT>
+__global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const AttnArgs a) {
+  constexpr int NC = HS / 8;
+  constexpr int ND = (HS + 31) / 32;
+  const int kt0 = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x, l31 = lane & 31, h = lane >> 5;
+  const int T = a.T;
+  const int key = kt0 * 32 + l31;
+  const bool kvalid = key < T;
+  const int kvlen = a.kv_len ? min(T, a.kv_len[b]) : T;
+  const bool kin = key < kvlen;
+  const size_t rowbase = (size_t)b * T;
+  const size_t krow = (rowbase + min(key, T - 1)) * a.ld + hd * HS + 4 * h;
+  f32x4 kf[NC], vf[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { kf[c] = ld4g(a.k + krow + 8 * c); vf[c] = ld4g(a.v + krow + 8 * c); }
+  const bool drop = a.drop_p > 0.f;
+  uint64_t key64 = 0;
+  float inv_keep = 1.f;
+  if (drop) { key64 = mmfn_rng_key(a.rng_state, a.rng_stream); inv_keep = 1.0f / (1.0f - a.drop_p); }
+  f32x16 dk[ND], dv[ND];
+#pragma unroll
+  for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[dt][r] = 0.f; dv[dt][r] = 0.f; }
+  const size_t statbase = ((size_t)b * a.NH + hd) * T;
+  for (int qt = 0; qt < NKT; ++qt) {
+    if (qt * 32 >= T) break;
+    f32x16 st, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+    const int qa = min(qt * 32 + l31, T - 1);
+    const float* Qp = a.q + (rowbase + qa) * a.ld + hd * HS + 4 * h;
+    const float* dOp = a.dO + (rowbase + qa) * a.ldo + hd * HS + 4 * h;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const f32x4 qf = ld4g(Qp + 8 * c);
+      const f32x4 dof = ld4g(dOp + 8 * c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        st = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j], kf[c][j], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dof[j], vf[c][j], dp, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qrow = qt * 32 + rowmap(r) + 4 * h;
+      const bool valid = qrow < T;
+      const int qc = min(qrow, T - 1);
+      const float lse = a.lse[statbase + qc];
+      const float delta = a.delta[statbase + qc];
+      const float p = (valid && kin) ? expf(st[r] * a.scale - lse) : 0.f;
+      float msc = 1.f;
+      if (drop) msc = mmfn_dropout_scale(key64, (statbase + qc) * (uint64_t)T + (uint64_t)key, a.drop_p, inv_keep);
+      const float pd = p * msc;
+      const float dsv = p * (dp[r] * msc - delta) * a.scale;
+      const float* dOr = a.dO + (rowbase + qc) * a.ldo + hd * HS;
+      const float* Qr = a.q + (rowbase + qc) * a.ld + hd * HS;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        const int d = dt * 32 + l31;
+        const float a1 = d < HS ? dOr[d] : 0.f;
+        const float a2 = d < HS ? Qr[d] : 0.f;
+        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, pd, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, dsv, dk[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (kvalid) {
+    float* Kg = a.dk + (rowbase + key) * a.ldg + hd * HS;
+    float* Vg = a.dv + (rowbase + key) * a.ldg + hd * HS;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = dt * 32 + rowmap(r) + 4 * h;
+        if (d < HS) { Kg[d] = dk[dt][r]; Vg[d] = dv[dt][r]; }
+      }
+  }
+}
+
+template <int HS, int NKT>
+int launch_attn(int which, const AttnArgs& a, hipStream_t s) {
+  dim3 grid(ceil_div(a.T, 32), a.NH, a.B);
+  if (which == 0) hipLaunchKernelGGL((attn_fwd_kernel<HS, NKT>), grid, dim3(64), 0, s, a);
+  else if (which == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<HS, NKT>), grid, dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<HS, NKT>), grid, dim3(64), 0, s, a);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int HS>
+int dispatch_nkt(int which, const AttnArgs& a, hipStream_t s) {
+  const int nkt = ceil_div(a.T, 32);
+  if (nkt <= 2) return launch_attn<HS, 2>(which, a, s);
+  if (nkt <= 4) return launch_attn<HS, 4>(which, a, s);
+  if (nkt <= 6) return launch_attn<HS, 6>(which, a, s);
+  if (nkt <= 8) return launch_attn<HS, 8>(which, a, s);
+  return MMFN_EINVAL;
+}
+
+int dispatch(int which, int hs, const AttnArgs& a, hipStream_t s) {
+  if (a.B <= 0 || a.T <= 0 || a.T > 256 || a.NH <= 0) return MMFN_EINVAL;
+  if ((a.ld & 3) || (a.ldo & 3) || ((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.v & 15)) return MMFN_EINVAL;
+  switch (hs) {
+    case 16: return dispatch_nkt<16>(which, a, s);
+    case 32: return dispatch_nkt<32>(which, a, s);
+    case 64: return dispatch_nkt<64>(which, a, s);
+    case 128: return dispatch_nkt<128>(which, a, s);
+  }
+  return MMFN_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int mmfn_attention_fwd_f32(const float* q, const float* k, const float* v, int ld, float* o, int ldo, float* lse,
+                                      int B, int T, int NH, int HS, float scale, const int32_t* kv_len, float drop_p,
+                                      const uint64_t* rng_state, uint32_t rng_stream, void* stream) {
+  AttnArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.o = o; a.lse = lse; a.kv_len = kv_len; a.rng_state = rng_state;
+  a.B = B; a.T = T; a.NH = NH; a.ld = ld; a.ldo = ldo; a.ldg = ld;
+  a.scale = scale; a.drop_p = drop_p; a.rng_stream = rng_stream;
+  if (drop_p > 0.f && !rng_state) return MMFN_EINVAL;
+  return dispatch(0, HS, a, (hipStream_t)stream);
+}
+
+extern "C" int mmfn_attention_bwd_f32(const float* q, const float* k, const float* v, int ld, const float* o, const float* dO,
+                                      int ldo, const float* lse, float* delta, float* dq, float* dk, float* dv, int ldg, int B,
+                                      int T, int NH, int HS, float scale, const int32_t* kv_len, float drop_p,
+                                      const uint64_t* rng_state, uint32_t rng_stream, void* stream) {
+  AttnArgs a = {};
+  a.q = q; a.k = k; a.v = v; a.o = const_cast<float*>(o); a.lse = const_cast<float*>(lse); a.dO = dO; a.delta = delta;
+  a.dq = dq; a.dk = dk; a.dv = dv; a.kv_len = kv_len; a.rng_state = rng_state;
+  a.B = B; a.T = T; a.NH = NH; a.ld = ld; a.ldo = ldo; a.ldg = ldg;
+  a.scale = scale; a.drop_p = drop_p; a.rng_stream = rng_stream;
+  if (drop_p > 0.f && !rng_state) return MMFN_EINVAL;
+  if ((ldg & 3) || !lse || !delta) return MMFN_EINVAL;
+  int rc = dispatch(1, HS, a, (hipStream_t)stream);
+  if (rc) return rc;
+  return dispatch(2, HS, a, (hipStream_t)stream);
+}

@@ -1,0 +1,412 @@
+// BatchNorm2d (training statistics, apply, backward) and LayerNorm (fwd/bwd) for [rows, C]
+// channels-last matrices.  HBM-bound: every kernel streams its operands once with 16-byte
+// loads; statistics are accumulated in fp64 so the fp32 result matches a double-accumulating
+// CPU reference to the last bits that matter for the 1e-4 loss tolerance.
+//
+// Reference semantics restated: BatchNorm2d eps 1e-5, momentum 0.1, biased
+// variance for normalisation, unbiased for the running update (model_vec.py:510,516 and every
+// torchvision BasicBlock); LayerNorm eps 1e-5 biased variance (model_vec.py:117-118,162,252).
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ------------------------------------------------------------------ column statistics
+// MODE 0: s1 = sum x,        s2 = sum x^2                      (BN forward statistics)
+// MODE 1: s1 = sum ge,       s2 = sum ge * xhat                (BN backward reductions)
+//         ge = g * (y > 0) when y != null else g;  xhat = (x - mean) * rstd
+template <int MODE>
+__global__ __launch_bounds__(NT) void col_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ y, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, int64_t M, int C,
+                                                         int64_t rows_per_block, double* __restrict__ partials) {
+  const int cq = C >> 2;           // float4 columns
+  const int tid = threadIdx.x;
+  const int col4 = tid % cq;       // requires cq <= 256 and 256 % cq == 0
+  const int rl = tid / cq;
+  const int RL = NT / cq;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  f32x4 mu = {0, 0, 0, 0}, rs = {0, 0, 0, 0};
+  if (MODE == 1) {
+    mu = *reinterpret_cast<const f32x4*>(mean + col4 * 4);
+    rs = *reinterpret_cast<const f32x4*>(rstd + col4 * 4);
+  }
+  for (int64_t r = r0 + rl; r < r1; r += RL) {
+    const size_t off = (size_t)r * C + col4 * 4;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+    if (MODE == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const double v = xv[e]; s1[e] += v; s2[e] += v * v; }
+    } else {
+      f32x4 gv = *reinterpret_cast<const f32x4*>(g + off);
+      if (y) {
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.0f ? gv[e] : 0.0f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xv[e] - mu[e]) * rs[e];
+        s1[e] += (double)gv[e];
+        s2[e] += (double)gv[e] * (double)xh;
+      }
+    }
+  }
+  __shared__ double red[2][NT][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][tid][e] = s1[e]; red[1][tid][e] = s2[e]; }
+  __syncthreads();
+  if (rl == 0) {
+    for (int k = 1; k < RL; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += red[0][k * cq + col4][e]; s2[e] += red[1][k * cq + col4][e]; }
+    double* p = partials + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { p[col4 * 4 + e] = s1[e]; p[C + col4 * 4 + e] = s2[e]; }
+  }
+}
+
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ partials, int nblk, int64_t M, int C, float eps,
+                                         float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var,
+                                         int64_t* __restrict__ num_batches_tracked) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int b = 0; b < nblk; ++b) { s1 += partials[(size_t)b * 2 * C + c]; s2 += partials[(size_t)b * 2 * C + C + c]; }
+  const double mu = s1 / (double)M;
+  double var = s2 / (double)M - mu * mu;
+  if (var < 0) var = 0;
+  mean[c] = (float)mu;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+}
+
+__global__ void bn_eval_prepare_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float eps, int C,
+                                       float* __restrict__ mean, float* __restrict__ rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rm[c];
+  rstd[c] = 1.0f / sqrtf(rv[c] + eps);
+}
+
+// y = [relu]( x * alpha + beta [+ res] ), alpha = w * rstd, beta = b - mean * alpha
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                      float* __restrict__ y, int64_t total4, int C,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ w, const float* __restrict__ b, int relu) {
+  const int cq = C >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % cq) * 4;
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float alpha = w[c4 + e] * rstd[c4 + e];
+      const float beta = b[c4 + e] - mean[c4 + e] * alpha;
+      o[e] = xv[e] * alpha + beta;
+    }
+    if (res) {
+      const f32x4 rv = *reinterpret_cast<const f32x4*>(res + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += rv[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.0f);
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int nblk, int64_t M, int C,
+                                       float* __restrict__ dweight, float* __restrict__ dbias,
+                                       float* __restrict__ means /* [2][C]: s1/M, s2/M */) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int b = 0; b < nblk; ++b) { s1 += partials[(size_t)b * 2 * C + c]; s2 += partials[(size_t)b * 2 * C + C + c]; }
+  dbias[c] = (float)s1;
+  dweight[c] = (float)s2;
+  means[c] = (float)(s1 / (double)M);
+  means[C + c] = (float)(s2 / (double)M);
+}
+
+// dx = w * rstd * (ge - mean(ge) - xhat * mean(ge * xhat));  optionally ge_out = ge
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                          const float* __restrict__ x, float* __restrict__ dx,
+                                                          float* __restrict__ ge_out, int64_t total4, int C,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ w, const float* __restrict__ means) {
+  const int cq = C >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % cq) * 4;
+    f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+    if (y) {
+      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.0f ? gv[e] : 0.0f;
+    }
+    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float rs = rstd[c4 + e];
+      const float xh = (xv[e] - mean[c4 + e]) * rs;
+      o[e] = (gv[e] - means[c4 + e] - xh * means[C + c4 + e]) * (w[c4 + e] * rs);
+    }
+    *reinterpret_cast<f32x4*>(dx + i * 4) = o;
+    if (ge_out) *reinterpret_cast<f32x4*>(ge_out + i * 4) = gv;
+  }
+}
+
+int bn_grid(int64_t M, int C, int64_t* rows_per_block) {
+  // aim for ~2 blocks per CU, at least 64 rows each
+  int64_t rpb = std::max<int64_t>(64, ceil_div64(M, 512));
+  *rows_per_block = rpb;
+  return (int)ceil_div64(M, rpb);
+}
+
+// ------------------------------------------------------------------ LayerNorm
+// One wave per row, lane owns columns lane, lane+64, ... (C <= 512 -> <= 8 per lane).
+template <int MAXPL>
+__global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ y,
+                                                           float* __restrict__ mean, float* __restrict__ rstd, int M, int C,
+                                                           float eps, int act) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int pl = C >> 6;
+  float v[MAXPL];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i)
+    if (i < pl) { v[i] = x[(size_t)row * C + lane + 64 * i]; s += v[i]; }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i)
+    if (i < pl) { const float d = v[i] - mu; q += d * d; }
+  const float rs = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i)
+    if (i < pl) {
+      const int c = lane + 64 * i;
+      float o = (v[i] - mu) * rs * w[c] + b[c];
+      if (act == 1) o = fmaxf(o, 0.f);
+      else if (act == 2) o = mmfn_gelu(o);
+      y[(size_t)row * C + c] = o;
+    }
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <int MAXPL>
+__global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ dres, float* __restrict__ dx,
+                                                           float* __restrict__ partials /* [grid][2][C] */, int M, int C,
+                                                           int act, int rows_per_block) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pl = C >> 6;
+  float dw[MAXPL], db[MAXPL];
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) { dw[i] = 0.f; db[i] = 0.f; }
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(M, r0 + rows_per_block);
+  for (int row = r0 + wave; row < r1; row += NT / 64) {
+    const float mu = mean[row], rs = rstd[row];
+    float a[MAXPL], xh[MAXPL];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i)
+      if (i < pl) {
+        const int c = lane + 64 * i;
+        const size_t off = (size_t)row * C + c;
+        xh[i] = (x[off] - mu) * rs;
+        float gg = g[off];
+        if (act != 0) {
+          const float pre = xh[i] * w[c] + b[c];
+          if (act == 1) gg = pre > 0.f ? gg : 0.f;
+          else gg *= mmfn_gelu_grad(pre);
+        }
+        dw[i] += gg * xh[i];
+        db[i] += gg;
+        a[i] = gg * w[c];
+        c1 += a[i];
+        c2 += a[i] * xh[i];
+      }
+    c1 = wave_sum(c1) / (float)C;
+    c2 = wave_sum(c2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < MAXPL; ++i)
+      if (i < pl) {
+        const size_t off = (size_t)row * C + lane + 64 * i;
+        float o = rs * (a[i] - c1 - xh[i] * c2);
+        if (dres) o += dres[off];
+        dx[off] = o;
+      }
+  }
+  __shared__ float red[2][NT / 64][64 * MAXPL];
+#pragma unroll
+  for (int i = 0; i < MAXPL; ++i) { red[0][wave][lane + 64 * i] = dw[i]; red[1][wave][lane + 64 * i] = db[i]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += NT) {
+    float sw = 0.f, sb = 0.f;
+#pragma unroll
+    for (int k = 0; k < NT / 64; ++k) { sw += red[0][k][c]; sb += red[1][k][c]; }
+    partials[(size_t)blockIdx.x * 2 * C + c] = sw;
+    partials[(size_t)blockIdx.x * 2 * C + C + c] = sb;
+  }
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ partials, int nblk, int C, float* __restrict__ out0,
+                                       float* __restrict__ out1) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0, s1 = 0;
+  for (int b = 0; b < nblk; ++b) { s0 += partials[(size_t)b * 2 * C + c]; s1 += partials[(size_t)b * 2 * C + C + c]; }
+  out0[c] = (float)s0;
+  if (out1) out1[c] = (float)s1;
+}
+
+// generic column sum: out[c] = sum_r in[r, c]   (bias gradients)
+__global__ __launch_bounds__(NT) void colsum_partial_kernel(const float* __restrict__ in, int64_t M, int C, int ld,
+                                                            int64_t rows_per_block, float* __restrict__ partials) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
+  for (int c = blockIdx.y * NT + threadIdx.x; c < C; c += gridDim.y * NT) {
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += in[(size_t)r * ld + c];
+    partials[(size_t)blockIdx.x * C + c] = s;
+  }
+}
+
+__global__ void colsum_finalize1_kernel(const float* __restrict__ partials, int nblk, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0;
+  for (int b = 0; b < nblk; ++b) s0 += partials[(size_t)b * C + c];
+  out[c] = (float)s0;
+}
+
+}  // namespace
+
+extern "C" int64_t mmfn_norm_workspace_bytes(int C) { return (int64_t)1024 * 2 * C * (int64_t)sizeof(double); }
+
+extern "C" int mmfn_bn_train_stats_f32(const float* x, int64_t M, int C, float eps, float momentum, float* mean,
+                                       float* rstd, float* running_mean, float* running_var,
+                                       int64_t* num_batches_tracked, void* workspace, void* stream) {
+  if (C % 4 || C > 1024 || (NT % (C / 4)) || M <= 0 || !workspace) return MMFN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t rpb;
+  const int nblk = bn_grid(M, C, &rpb);
+  hipLaunchKernelGGL(col_partial_kernel<0>, dim3(nblk), dim3(NT), 0, s, x, nullptr, nullptr, nullptr, nullptr, M, C, rpb,
+                     (double*)workspace);
+  MMFN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, (const double*)workspace, nblk, M, C,
+                     eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_bn_eval_prepare_f32(const float* running_mean, const float* running_var, float eps, int C, float* mean,
+                                        float* rstd, void* stream) {
+  hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, (hipStream_t)stream, running_mean,
+                     running_var, eps, C, mean, rstd);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_bn_apply_f32(const float* x, const float* res, float* y, int64_t M, int C, const float* mean,
+                                 const float* rstd, const float* weight, const float* bias, int relu, void* stream) {
+  if (C % 4 || M <= 0) return MMFN_EINVAL;
+  const int64_t total4 = M * (C / 4);
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total4, NT), 8192);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, res, y, total4, C, mean, rstd,
+                     weight, bias, relu);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_bn_bwd_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean,
+                               const float* rstd, const float* weight, float* dx, float* ge_out, float* dweight,
+                               float* dbias, void* workspace, void* stream) {
+  if (C % 4 || C > 1024 || (NT % (C / 4)) || M <= 0 || !workspace) return MMFN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t rpb;
+  const int nblk = bn_grid(M, C, &rpb);
+  double* partials = (double*)workspace;
+  float* means = (float*)(partials + (size_t)nblk * 2 * C);
+  hipLaunchKernelGGL(col_partial_kernel<1>, dim3(nblk), dim3(NT), 0, s, x, g, y, mean, rstd, M, C, rpb, partials);
+  MMFN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, partials, nblk, M, C, dweight, dbias,
+                     means);
+  MMFN_LAUNCH_CHECK();
+  const int64_t total4 = M * (C / 4);
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total4, NT), 8192);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(NT), 0, s, g, y, x, dx, ge_out, total4, C, mean, rstd, weight,
+                     means);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_layernorm_fwd_f32(const float* x, const float* weight, const float* bias, float* y, float* mean,
+                                      float* rstd, int M, int C, float eps, int act, void* stream) {
+  if (C % 64 || C > 512 || M <= 0) return MMFN_EINVAL;
+  hipLaunchKernelGGL(layernorm_fwd_kernel<8>, dim3(ceil_div(M, NT / 64)), dim3(NT), 0, (hipStream_t)stream, x, weight, bias, y,
+                     mean, rstd, M, C, eps, act);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_layernorm_bwd_f32(const float* g, const float* x, const float* weight, const float* bias,
+                                      const float* mean, const float* rstd, const float* dres, float* dx, float* dweight,
+                                      float* dbias, int M, int C, int act, void* workspace, void* stream) {
+  if (C % 64 || C > 512 || M <= 0 || !workspace) return MMFN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int rpb = std::max(16, ceil_div(M, 512));
+  const int nblk = ceil_div(M, rpb);
+  float* partials = (float*)workspace;
+  hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(nblk), dim3(NT), 0, s, g, x, weight, bias, mean, rstd, dres, dx, partials,
+                     M, C, act, rpb);
+  MMFN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, partials, nblk, C, dweight, dbias);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+static int colsum_blocks(int64_t M, int64_t* rpb) {
+  *rpb = std::max<int64_t>(8, ceil_div64(M, 256));
+  return (int)ceil_div64(M, *rpb);
+}
+
+extern "C" int64_t mmfn_colsum_workspace_bytes(int64_t M, int C) {
+  int64_t rpb;
+  return (int64_t)colsum_blocks(M, &rpb) * C * (int64_t)sizeof(float);
+}
+
+extern "C" int mmfn_colsum_f32(const float* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream) {
+  if (M <= 0 || C <= 0 || !workspace) return MMFN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t rpb;
+  const int nblk = colsum_blocks(M, &rpb);
+  float* partials = (float*)workspace;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, std::min(ceil_div(C, NT), 1024)), dim3(NT), 0, s, in, M, C, ld, rpb,
+                     partials);
+  MMFN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colsum_finalize1_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, s, partials, nblk, C, out);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}

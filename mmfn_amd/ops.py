@@ -141,3 +141,229 @@ def conv2d_wgrad(dy, x, w_shape, stride, pad, out=None, **epi):
     B, OH, OW, Cout = oshape
     N = g[6] * g[7] * g[2]
     return gemm(dy, x, out, Cout, N, B * OH * OW, Cout, 0, N, A_COLMAJOR, B_IM2COL, conv=g, **epi)
+
+
+# ---------------------------------------------------------------- small helpers
+def _call(name, *args):
+    check(getattr(lib(), name)(*args), name)
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+_norm_ws = {}
+
+
+def norm_workspace(device, nbytes=None):
+    """Scratch for norm / colsum / token-bwd reductions (grow-only, fp64-aligned)."""
+    key = str(device)
+    need = max(nbytes or 0, lib().mmfn_norm_workspace_bytes(1024) + 8192)
+    buf = _norm_ws.get(key)
+    if buf is None or buf.numel() * 8 < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("norm workspace must be sized before graph capture")
+        buf = torch.empty(need // 8 + 1, dtype=torch.float64, device=device)
+        _norm_ws[key] = buf
+    return buf
+
+
+def fill(t, value):
+    _call("mmfn_fill_f32", ptr(t), float(value), t.numel(), stream())
+    return t
+
+
+def axpby(y, x, a=1.0, b=1.0):
+    _call("mmfn_axpby_f32", ptr(y), ptr(x), float(a), float(b), y.numel(), stream())
+    return y
+
+
+# ---------------------------------------------------------------- BatchNorm / LayerNorm
+def bn_train_stats(x2d, mean, rstd, running_mean, running_var, nbt, eps=1e-5, momentum=0.1):
+    M, C = x2d.shape
+    _call("mmfn_bn_train_stats_f32", ptr(x2d), M, C, eps, momentum, ptr(mean), ptr(rstd), ptr(running_mean),
+          ptr(running_var), ptr(nbt), ptr(norm_workspace(x2d.device)), stream())
+
+
+def bn_eval_prepare(running_mean, running_var, mean, rstd, eps=1e-5):
+    _call("mmfn_bn_eval_prepare_f32", ptr(running_mean), ptr(running_var), eps, mean.numel(), ptr(mean), ptr(rstd), stream())
+
+
+def bn_apply(x2d, y2d, mean, rstd, weight, bias, relu, res=None):
+    M, C = x2d.shape
+    _call("mmfn_bn_apply_f32", ptr(x2d), ptr(res), ptr(y2d), M, C, ptr(mean), ptr(rstd), ptr(weight), ptr(bias),
+          1 if relu else 0, stream())
+    return y2d
+
+
+def bn_bwd(g2d, y2d, x2d, mean, rstd, weight, dx, dweight, dbias, ge_out=None):
+    M, C = x2d.shape
+    _call("mmfn_bn_bwd_f32", ptr(g2d), ptr(y2d), ptr(x2d), M, C, ptr(mean), ptr(rstd), ptr(weight), ptr(dx), ptr(ge_out),
+          ptr(dweight), ptr(dbias), ptr(norm_workspace(x2d.device)), stream())
+    return dx
+
+
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+
+
+def layernorm_fwd(x, w, b, y, mean, rstd, act=ACT_NONE, eps=1e-5):
+    M, C = x.shape
+    _call("mmfn_layernorm_fwd_f32", ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), M, C, eps, act, stream())
+    return y
+
+
+def layernorm_bwd(g, x, w, b, mean, rstd, dx, dw, db, act=ACT_NONE, dres=None):
+    M, C = x.shape
+    _call("mmfn_layernorm_bwd_f32", ptr(g), ptr(x), ptr(w), ptr(b), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dw),
+          ptr(db), M, C, act, ptr(norm_workspace(x.device)), stream())
+    return dx
+
+
+def colsum(x2d, out, M=None, C=None, ld=None):
+    M = x2d.shape[0] if M is None else M
+    C = x2d.shape[1] if C is None else C
+    ld = x2d.stride(0) if ld is None else ld
+    need = lib().mmfn_colsum_workspace_bytes(M, C)
+    _call("mmfn_colsum_f32", ptr(x2d), M, C, ld, ptr(out), ptr(norm_workspace(x2d.device, need)), stream())
+    return out
+
+
+# ---------------------------------------------------------------- pooling / tokens / upsample
+def maxpool_fwd(x, y, idx):
+    B, H, W, C = x.shape
+    _call("mmfn_maxpool3x3s2_fwd_f32", ptr(x), ptr(y), ptr(idx), B, H, W, C, stream())
+    return y
+
+
+def maxpool_bwd(gy, idx, gx):
+    B, H, W, C = gx.shape
+    _call("mmfn_maxpool3x3s2_bwd_f32", ptr(gy), ptr(idx), ptr(gx), B, H, W, C, stream())
+    return gx
+
+
+def tokens_fwd(feats, pos, vel_w, vel_b, velocity, tok, drop_p=0.0, rng_state=None, rng_stream=0):
+    B, S, _, C = feats[0].shape
+    arr = _ptr_array(feats)
+    _call("mmfn_tokens_fwd_f32", arr, len(feats), B, S, C, ptr(pos), ptr(vel_w), ptr(vel_b), ptr(velocity), ptr(tok),
+          float(drop_p), ptr(rng_state), rng_stream, stream())
+    return tok
+
+
+def tokens_bwd(gtok, velocity, dpos, dvel_w, dvel_b, drop_p=0.0, rng_state=None, rng_stream=0):
+    B, T, C = gtok.shape
+    need = lib().mmfn_tokens_bwd_workspace_bytes(T, C)
+    _call("mmfn_tokens_bwd_f32", ptr(gtok), B, T, C, ptr(velocity), ptr(dpos), ptr(dvel_w), ptr(dvel_b), float(drop_p),
+          ptr(rng_state), rng_stream, ptr(norm_workspace(gtok.device, need)), stream())
+
+
+def upsample_add_fwd(feat, tok, out, m):
+    B, S, _, C = feat.shape
+    T = tok.shape[1]
+    _call("mmfn_upsample_add_fwd_f32", ptr(feat), ptr(tok), ptr(out), B, S, C, T, m, stream())
+    return out
+
+
+def upsample_adj(G, gtok, m):
+    B, S, _, C = G.shape
+    T = gtok.shape[1]
+    _call("mmfn_upsample_adj_f32", ptr(G), ptr(gtok), B, S, C, T, m, stream())
+
+
+def pool_bcast_add(G, gtok, dF, m):
+    B, S, _, C = G.shape
+    T = gtok.shape[1]
+    _call("mmfn_pool_bcast_add_f32", ptr(G), ptr(gtok), ptr(dF), B, S, C, T, m, stream())
+    return dF
+
+
+def gap_sum_fwd(feats, out):
+    B, H, W, C = feats[0].shape
+    _call("mmfn_gap_sum_fwd_f32", _ptr_array(feats), len(feats), B, H * W, C, ptr(out), stream())
+    return out
+
+
+def gap_sum_bwd(g, outs):
+    B, H, W, C = outs[0].shape
+    _call("mmfn_gap_sum_bwd_f32", ptr(g), _ptr_array(outs), len(outs), B, H * W, C, stream())
+
+
+def transpose(inp, out, B, R, Cc):
+    _call("mmfn_transpose_f32", ptr(inp), ptr(out), B, R, Cc, stream())
+    return out
+
+
+# ---------------------------------------------------------------- attention
+def attention_fwd(q, k, v, ld, o, ldo, lse, B, T, NH, HS, scale, kv_len=None, drop_p=0.0, rng_state=None, rng_stream=0):
+    _call("mmfn_attention_fwd_f32", ptr(q), ptr(k), ptr(v), ld, ptr(o), ldo, ptr(lse), B, T, NH, HS, float(scale),
+          ptr(kv_len), float(drop_p), ptr(rng_state), rng_stream, stream())
+    return o
+
+
+def attention_bwd(q, k, v, ld, o, dO, ldo, lse, delta, dq, dk, dv, ldg, B, T, NH, HS, scale, kv_len=None, drop_p=0.0,
+                  rng_state=None, rng_stream=0):
+    _call("mmfn_attention_bwd_f32", ptr(q), ptr(k), ptr(v), ld, ptr(o), ptr(dO), ldo, ptr(lse), ptr(delta), ptr(dq),
+          ptr(dk), ptr(dv), ldg, B, T, NH, HS, float(scale), ptr(kv_len), float(drop_p), ptr(rng_state), rng_stream, stream())
+
+
+# ---------------------------------------------------------------- head / optimizer / ingest / vectornet
+def gru_head_fwd(z0, target, w_ih, w_hh, b_ih, b_hh, w_out, b_out, gt, pred, hs, gates, xin, loss_terms, loss, steps):
+    B = z0.shape[0]
+    _call("mmfn_gru_head_fwd_f32", ptr(z0), ptr(target), ptr(w_ih), ptr(w_hh), ptr(b_ih), ptr(b_hh), ptr(w_out), ptr(b_out),
+          ptr(gt), ptr(pred), ptr(hs), ptr(gates), ptr(xin), ptr(loss_terms), ptr(loss), B, steps, stream())
+
+
+def gru_head_bwd(pred, gt, dpred, gscale, w_ih, w_hh, w_out, hs, gates, xin, dz0, part, steps):
+    B = dz0.shape[0]
+    _call("mmfn_gru_head_bwd_f32", ptr(pred), ptr(gt), ptr(dpred), float(gscale), ptr(w_ih), ptr(w_hh), ptr(w_out), ptr(hs),
+          ptr(gates), ptr(xin), ptr(dz0), ptr(part), B, steps, stream())
+
+
+def step_advance(step):
+    _call("mmfn_step_advance", ptr(step), stream())
+
+
+def rng_advance(state):
+    _call("mmfn_rng_advance", ptr(state), stream())
+
+
+def adamw(p, g, m, v, step, lr=1e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-2, grad_scale=1.0, n=None):
+    n = p.numel() if n is None else n
+    _call("mmfn_adamw_f32", ptr(p), ptr(g), ptr(m), ptr(v), n, lr, beta1, beta2, eps, weight_decay, ptr(step),
+          float(grad_scale), stream())
+
+
+def ingest_rgb_u8(img_u8, out, crop=256):
+    B, H, W, _ = img_u8.shape
+    _call("mmfn_ingest_rgb_u8", ptr(img_u8), ptr(out), B, H, W, crop, stream())
+    return out
+
+
+def nchw_to_nhwc(inp, out, mean=None, inv_std=None):
+    B, C = inp.shape[0], inp.shape[1]
+    P = inp.numel() // (B * C)
+    _call("mmfn_nchw_to_nhwc_f32", ptr(inp), ptr(out), B, C, P, ptr(mean), ptr(inv_std), stream())
+    return out
+
+
+def lidar_splat(pts, out, flip_y=False):
+    B, N, S = pts.shape
+    _call("mmfn_lidar_splat_f32", ptr(pts), B, N, S, ptr(out), 1 if flip_y else 0, stream())
+    return out
+
+
+def lane_to_vector(lane, vec):
+    n = lane.shape[-2]
+    R = lane.numel() // (n * 5)
+    _call("mmfn_lane_to_vector_f32", ptr(lane), ptr(vec), R, n, stream())
+    return vec
+
+
+def polyline_pool_fwd(y, out, arg, R, V, H, last):
+    _call("mmfn_polyline_pool_fwd_f32", ptr(y), ptr(out), ptr(arg), R, V, H, 1 if last else 0, stream())
+    return out
+
+
+def polyline_pool_bwd(gout, arg, gy, R, V, H, last):
+    _call("mmfn_polyline_pool_bwd_f32", ptr(gout), ptr(arg), ptr(gy), R, V, H, 1 if last else 0, stream())
+    return gy

@@ -1,0 +1,377 @@
+"""GPU parity of every non-GEMM HIP kernel against plain torch fp32 (CPU) / the oracle."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _close(got, ref, tol=2e-5, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().double()
+    scale = ref.abs().max().item() + 1e-6
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, "%s max err %g vs scale %g" % (what, err, scale)
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------ BatchNorm
+@pytest.mark.parametrize("M,C", [(2 * 16 * 16, 64), (3 * 8 * 8, 512), (1000, 128), (77, 256)])
+def test_batchnorm_train_and_backward(M, C):
+    from mmfn_amd import ops
+    g = _g(M + C)
+    x = torch.randn(M, C, generator=g) * 3 + 1.5
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    res = torch.randn(M, C, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    gy = torch.randn(M, C, generator=g)
+    # reference through torch BatchNorm on NCHW view [1,C,M,1]
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(w); bn.bias.copy_(b); bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn.train()
+    xr = x.t().reshape(1, C, M, 1).clone().requires_grad_(True)
+    rr = res.t().reshape(1, C, M, 1).clone().requires_grad_(True)
+    y_ref = torch.relu(bn(xr) + rr)
+    y_ref.backward(gy.t().reshape(1, C, M, 1))
+
+    xd, wd, bd, resd, gyd = (t.to(DEV) for t in (x, w, b, res, gy))
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_train_stats(xd, mean, rstd, rmd, rvd, nbt)
+    y = ops.bn_apply(xd, torch.empty_like(xd), mean, rstd, wd, bd, True, res=resd)
+    _close(y, y_ref.reshape(C, M).t(), 1e-5, "bn fwd")
+    _close(rmd, bn.running_mean, 1e-6, "running_mean")
+    _close(rvd, bn.running_var, 1e-6, "running_var")
+    assert int(nbt.item()) == 1
+    dx, ge = torch.empty_like(xd), torch.empty_like(xd)
+    dw, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_bwd(gyd, y, xd, mean, rstd, wd, dx, dw, db, ge_out=ge)
+    _close(dx, xr.grad.reshape(C, M).t(), 2e-5, "bn dx")
+    _close(ge, rr.grad.reshape(C, M).t(), 1e-6, "bn residual grad")
+    _close(dw, bn.weight.grad, 2e-5, "bn dweight")
+    _close(db, bn.bias.grad, 2e-5, "bn dbias")
+    # eval mode
+    bn.eval()
+    ops.bn_eval_prepare(rmd, rvd, mean, rstd)
+    y2 = ops.bn_apply(xd, torch.empty_like(xd), mean, rstd, wd, bd, False)
+    _close(y2, bn(x.t().reshape(1, C, M, 1)).reshape(C, M).t(), 1e-5, "bn eval")
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("M,C,act", [(384, 64, 0), (100, 128, 1), (6144, 512, 0), (37, 256, 2), (18, 64, 2)])
+def test_layernorm(M, C, act):
+    from mmfn_amd import ops
+    g = _g(M * 3 + C + act)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.3)
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.2
+    gy, dres = torch.randn(M, C, generator=g), torch.randn(M, C, generator=g)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.layer_norm(xr, (C,), wr, br, 1e-5)
+    y_ref = [y_ref, torch.relu(y_ref), F.gelu(y_ref)][act]
+    y_ref.backward(gy)
+    xd, wd, bd, gyd, dresd = (t.to(DEV) for t in (x, w, b, gy, dres))
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    y = ops.layernorm_fwd(xd, wd, bd, torch.empty_like(xd), mean, rstd, act)
+    _close(y, y_ref, 1e-5, "ln fwd")
+    dx, dw, db = torch.empty_like(xd), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.layernorm_bwd(gyd, xd, wd, bd, mean, rstd, dx, dw, db, act, dres=dresd)
+    _close(dx, xr.grad + dres, 2e-5, "ln dx")
+    _close(dw, wr.grad, 2e-5, "ln dw")
+    _close(db, br.grad, 2e-5, "ln db")
+
+
+def test_colsum():
+    from mmfn_amd import ops
+    x = torch.randn(777, 300, generator=_g(1))
+    _close(ops.colsum(x.to(DEV), torch.empty(300, device=DEV)), x.sum(0), 1e-5)
+    x = torch.randn(32, 70000, generator=_g(2))
+    _close(ops.colsum(x.to(DEV), torch.empty(70000, device=DEV)), x.sum(0), 1e-5)
+
+
+# ------------------------------------------------------------------ pooling family
+def test_maxpool_ties_and_backward():
+    from mmfn_amd import ops
+    g = _g(3)
+    x = torch.relu(torch.randn(2, 64, 18, 22, generator=g))  # many exact-zero ties, like post-ReLU maps
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 3, 2, 1)
+    gy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(gy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    B, H, W, C = xd.shape
+    y = torch.empty(B, y_ref.shape[2], y_ref.shape[3], C, device=DEV)
+    idx = torch.empty(y.shape, dtype=torch.uint8, device=DEV)
+    ops.maxpool_fwd(xd, y, idx)
+    assert torch.equal(y.cpu().permute(0, 3, 1, 2), y_ref.detach())
+    gx = ops.maxpool_bwd(gy.permute(0, 2, 3, 1).contiguous().to(DEV), idx, torch.empty_like(xd))
+    _close(gx.permute(0, 3, 1, 2), xr.grad, 1e-6, "maxpool bwd")
+
+
+@pytest.mark.parametrize("S,C", [(64, 64), (32, 128), (16, 256), (8, 512)])
+def test_tokens_and_upsample(S, C):
+    from mmfn_amd import ops
+    g = _g(S + C)
+    B, n = 2, 3
+    feats = [torch.randn(B, C, S, S, generator=g) for _ in range(n)]
+    pos = torch.randn(1, n * 64, C, generator=g)
+    vw, vb, vel = torch.randn(C, 1, generator=g), torch.randn(C, generator=g), torch.rand(B, generator=g) * 8
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    posr, vwr, vbr = pos.clone().requires_grad_(True), vw.clone().requires_grad_(True), vb.clone().requires_grad_(True)
+    pooled = [F.adaptive_avg_pool2d(f, (8, 8)) for f in fr]
+    tok_ref = torch.cat([p.flatten(2).transpose(1, 2) for p in pooled], 1)
+    tok_ref = posr + tok_ref + F.linear(vel.unsqueeze(1), vwr, vbr).unsqueeze(1)
+    gt = torch.randn(tok_ref.shape, generator=g)
+    tok_ref.backward(gt)
+    fd = [f.permute(0, 2, 3, 1).contiguous().to(DEV) for f in feats]
+    tok = ops.tokens_fwd(fd, pos[0].contiguous().to(DEV), vw[:, 0].contiguous().to(DEV), vb.to(DEV), vel.to(DEV),
+                         torch.empty(B, n * 64, C, device=DEV))
+    _close(tok, tok_ref, 1e-5, "tokens fwd")
+    gtd = gt.to(DEV).clone()
+    dpos, dvw, dvb = torch.empty(n * 64, C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.tokens_bwd(gtd, vel.to(DEV), dpos, dvw, dvb)
+    _close(dpos, posr.grad[0], 1e-5, "dpos")
+    _close(dvw, vwr.grad[:, 0], 2e-5, "dvel_w")
+    _close(dvb, vbr.grad, 2e-5, "dvel_b")
+    # upsample-add forward, adjoint and the pooled-grad broadcast for modality m
+    for m in range(n):
+        t = torch.randn(B, n * 64, C, generator=g)
+        tr = t.clone().requires_grad_(True)
+        fm = feats[m].clone().requires_grad_(True)
+        grid = tr[:, m * 64:(m + 1) * 64].view(B, 8, 8, C).permute(0, 3, 1, 2)
+        up = grid if S == 8 else F.interpolate(grid, scale_factor=S // 8, mode="bilinear", align_corners=True)
+        out_ref = fm + up
+        G = torch.randn(out_ref.shape, generator=g)
+        out_ref.backward(G)
+        out = ops.upsample_add_fwd(fd[m], t.to(DEV), torch.empty_like(fd[m]), m)
+        _close(out.permute(0, 3, 1, 2), out_ref, 1e-5, "upsample fwd")
+        Gd = G.permute(0, 2, 3, 1).contiguous().to(DEV)
+        gtok = torch.zeros(B, n * 64, C, device=DEV)
+        ops.upsample_adj(Gd, gtok, m)
+        _close(gtok[:, m * 64:(m + 1) * 64], tr.grad[:, m * 64:(m + 1) * 64], 2e-5, "upsample adjoint")
+        # dF = G + avgpool adjoint of the token gradient
+        dF = ops.pool_bcast_add(Gd, gt.to(DEV), torch.empty_like(Gd), m)
+        _close(dF.permute(0, 3, 1, 2), G + fr[m].grad, 1e-5, "pool bcast add")
+
+
+def test_gap_and_transpose():
+    from mmfn_amd import ops
+    g = _g(9)
+    feats = [torch.randn(3, 512, 8, 8, generator=g) for _ in range(3)]
+    ref = sum(f.mean(dim=(2, 3)) for f in feats)
+    fd = [f.permute(0, 2, 3, 1).contiguous().to(DEV) for f in feats]
+    _close(ops.gap_sum_fwd(fd, torch.empty(3, 512, device=DEV)), ref, 1e-5)
+    gg = torch.randn(3, 512, generator=g)
+    outs = [torch.empty_like(f) for f in fd]
+    ops.gap_sum_bwd(gg.to(DEV), outs)
+    for o in outs:
+        _close(o, (gg / 64)[:, None, None, :].expand(3, 8, 8, 512), 1e-6)
+    x = torch.randn(2, 70, 4096, generator=g)
+    _close(ops.transpose(x.to(DEV), torch.empty(2, 4096, 70, device=DEV), 2, 70, 4096), x.transpose(1, 2), 0.0)
+
+
+# ------------------------------------------------------------------ attention
+@pytest.mark.parametrize("T,NH,HS", [(192, 4, 16), (192, 4, 32), (192, 4, 64), (192, 4, 128), (256, 4, 128),
+                                     (64, 2, 64), (9, 2, 64), (50, 2, 64)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_attention(T, NH, HS, masked):
+    from mmfn_amd import ops
+    if masked and T > 64:
+        pytest.skip("key mask only used by the lane attention")
+    g = _g(T * 5 + HS)
+    B, C = 3, NH * HS
+    qkv = torch.randn(B, T, 3 * C, generator=g)
+    dO = torch.randn(B, T, C, generator=g)
+    scale = 1.0 / math.sqrt(HS)
+    kv_len = torch.tensor([T, max(1, T // 3), max(1, T - 1)], dtype=torch.int32) if masked else None
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = (t.view(B, T, NH, HS).transpose(1, 2) for t in qr.chunk(3, dim=-1))
+    att = (q @ k.transpose(-1, -2)) * scale
+    if masked:
+        keep = (torch.arange(T)[None, :] < kv_len[:, None]).view(B, 1, 1, T)
+        att = att.masked_fill(~keep, -1e9)
+    o_ref = (torch.softmax(att, -1) @ v).transpose(1, 2).reshape(B, T, C)
+    o_ref.backward(dO)
+    qd = qkv.to(DEV).view(B * T, 3 * C)
+    o = torch.empty(B * T, C, device=DEV)
+    lse = torch.empty(B, NH, T, device=DEV)
+    kvd = kv_len.to(DEV) if masked else None
+    ops.attention_fwd(qd, qd[:, C:], qd[:, 2 * C:], 3 * C, o, C, lse, B, T, NH, HS, scale, kv_len=kvd)
+    _close(o.view(B, T, C), o_ref, 2e-5, "attn fwd")
+    dqkv = torch.zeros(B * T, 3 * C, device=DEV)
+    delta = torch.empty(B, NH, T, device=DEV)
+    ops.attention_bwd(qd, qd[:, C:], qd[:, 2 * C:], 3 * C, o, dO.to(DEV).view(B * T, C), C, lse, delta, dqkv, dqkv[:, C:],
+                      dqkv[:, 2 * C:], 3 * C, B, T, NH, HS, scale, kv_len=kvd)
+    _close(dqkv.view(B, T, 3 * C), qr.grad, 5e-5, "attn bwd")
+
+
+def test_attention_dropout_consistency():
+    """Dropout mask is a pure function of (state, stream, index): fwd and bwd see the same mask."""
+    from mmfn_amd import ops
+    B, T, NH, HS = 2, 192, 4, 32
+    C = NH * HS
+    g = _g(11)
+    qkv = torch.randn(B * T, 3 * C, generator=g).to(DEV)
+    dO = torch.randn(B * T, C, generator=g).to(DEV)
+    state = torch.tensor([99, 3], dtype=torch.int64, device=DEV)
+    scale = 1.0 / math.sqrt(HS)
+    p = 0.1
+
+    def run(x):
+        o = torch.empty(B * T, C, device=DEV)
+        lse = torch.empty(B, NH, T, device=DEV)
+        ops.attention_fwd(x, x[:, C:], x[:, 2 * C:], 3 * C, o, C, lse, B, T, NH, HS, scale, drop_p=p, rng_state=state,
+                          rng_stream=5)
+        return o, lse
+
+    o, lse = run(qkv)
+    o2, _ = run(qkv)
+    assert torch.equal(o, o2)
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.empty(B, NH, T, device=DEV)
+    ops.attention_bwd(qkv, qkv[:, C:], qkv[:, 2 * C:], 3 * C, o, dO, C, lse, delta, dqkv, dqkv[:, C:], dqkv[:, 2 * C:],
+                      3 * C, B, T, NH, HS, scale, drop_p=p, rng_state=state, rng_stream=5)
+    # directional finite difference of <o, dO> against the analytic gradient
+    d = torch.randn(qkv.shape, generator=_g(12)).to(DEV)
+    eps = 1e-2
+    op, _ = run(qkv + eps * d)
+    om, _ = run(qkv - eps * d)
+    fd = ((op.double() - om.double()) * dO.double()).sum().item() / (2 * eps)
+    an = (dqkv.double() * d.double()).sum().item()
+    assert abs(fd - an) <= 2e-2 * max(1.0, abs(an)), (fd, an)
+    # the mask drops ~p of the probabilities: outputs differ from the no-dropout ones
+    o3 = torch.empty_like(o)
+    ops.attention_fwd(qkv, qkv[:, C:], qkv[:, 2 * C:], 3 * C, o3, C, lse, B, T, NH, HS, scale)
+    assert not torch.allclose(o, o3)
+
+
+# ------------------------------------------------------------------ GRU head
+def test_gru_head():
+    from mmfn_amd import ops
+    g = _g(21)
+    B, steps = 5, 4
+    gru = torch.nn.GRUCell(2, 64)
+    out = torch.nn.Linear(64, 2)
+    z0 = torch.randn(B, 64, generator=g).requires_grad_(True)
+    target = torch.randn(B, 2, generator=g) * 5
+    gt = torch.randn(B, steps, 2, generator=g) * 3
+    x = torch.zeros(B, 2)
+    h = z0
+    wps = []
+    for _ in range(steps):
+        h = gru(x + target, h)
+        x = x + out(h)
+        wps.append(x)
+    pred_ref = torch.stack(wps, 1)
+    loss_ref = F.l1_loss(pred_ref, gt, reduction="none").mean()
+    loss_ref.backward()
+    P = {k: v.detach().to(DEV).contiguous() for k, v in dict(w_ih=gru.weight_ih, w_hh=gru.weight_hh, b_ih=gru.bias_ih,
+                                                             b_hh=gru.bias_hh, w_out=out.weight, b_out=out.bias).items()}
+    pred = torch.empty(B, steps, 2, device=DEV)
+    hs = torch.empty(B, steps + 1, 64, device=DEV)
+    gates = torch.empty(B, steps, 4, 64, device=DEV)
+    xin = torch.empty(B, steps, 2, device=DEV)
+    lt, loss = torch.empty(B, device=DEV), torch.empty(1, device=DEV)
+    ops.gru_head_fwd(z0.detach().to(DEV), target.to(DEV), P["w_ih"], P["w_hh"], P["b_ih"], P["b_hh"], P["w_out"], P["b_out"],
+                     gt.to(DEV), pred, hs, gates, xin, lt, loss, steps)
+    _close(pred, pred_ref, 1e-5, "gru pred")
+    assert abs(loss.item() - loss_ref.item()) < 1e-6
+    from mmfn_amd._lib import lib
+    npart = lib().mmfn_gru_head_part_floats()
+    part = torch.empty(B, npart, device=DEV)
+    dz0 = torch.empty(B, 64, device=DEV)
+    ops.gru_head_bwd(pred, gt.to(DEV), None, 1.0 / (B * steps * 2), P["w_ih"], P["w_hh"], P["w_out"], hs, gates, xin, dz0,
+                     part, steps)
+    _close(dz0, z0.grad, 2e-5, "dz0")
+    tot = part.sum(0).cpu()
+    offs = [("w_ih", 384, gru.weight_ih), ("w_hh", 12288, gru.weight_hh), ("b_ih", 192, gru.bias_ih),
+            ("b_hh", 192, gru.bias_hh), ("w_out", 128, out.weight), ("b_out", 2, out.bias)]
+    o = 0
+    for name, n, prm in offs:
+        _close(tot[o:o + n], prm.grad.flatten(), 5e-5, name)
+        o += n
+
+
+# ------------------------------------------------------------------ AdamW
+def test_adamw_matches_torch():
+    from mmfn_amd import ops
+    g = _g(31)
+    n = 10007
+    p0, grads = torch.randn(n, generator=g), [torch.randn(n, generator=g) for _ in range(3)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-4)
+    pd = torch.zeros(n + 5, device=DEV)[:n]
+    pd.copy_(p0)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for gr in grads:
+        ref.grad = gr.clone()
+        opt.step()
+        ops.step_advance(step)
+        ops.adamw(pd, gr.to(DEV), m, v, step)
+    assert (pd.cpu() - ref.detach()).abs().max().item() < 1e-6  # a few fp32 ulps at |p| ~ 3
+
+
+# ------------------------------------------------------------------ ingest
+def test_ingest_and_splat(golden_dir):
+    from mmfn_amd import ops
+    from oracle import fixtures, preprocess
+    from oracle.model import normalize_imagenet
+    batch = fixtures.synthetic_batch(2, seed=5)
+    rgb = batch["rgb_u8"]
+    ref = normalize_imagenet(torch.from_numpy(np.stack([preprocess.crop_chw(im) for im in rgb.numpy()]).copy()).float())
+    out = ops.ingest_rgb_u8(rgb.to(DEV), torch.empty(2, 256, 256, 3, device=DEV))
+    _close(out.permute(0, 3, 1, 2), ref, 1e-6, "rgb ingest")
+    # NCHW f32 module-boundary path with the same normalisation
+    raw = torch.from_numpy(np.stack([preprocess.crop_chw(im) for im in rgb.numpy()]).copy()).float()
+    mean = torch.tensor([0.485, 0.456, 0.406])
+    inv = torch.tensor([1 / 0.229, 1 / 0.224, 1 / 0.225])
+    out2 = ops.nchw_to_nhwc(raw.to(DEV), torch.empty(2, 256, 256, 3, device=DEV), mean.to(DEV), inv.to(DEV))
+    _close(out2.permute(0, 3, 1, 2), ref, 1e-6, "nchw ingest")
+    # LiDAR splat: bit-exact against the oracle histogram and the reference-generated edge cases
+    pts = batch["lidar_pts"]
+    bev_ref = np.stack([preprocess.lidar_histogram(p[:, :3].numpy().astype(np.float64)) for p in pts])
+    bev = ops.lidar_splat(pts.to(DEV), torch.empty(2, 256, 256, 2, device=DEV))
+    assert np.array_equal(bev.cpu().permute(0, 3, 1, 2).numpy(), bev_ref)
+    gold = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    for key_p, key_o in (("hist_pts", "hist_out"), ("hist_rand_pts", "hist_rand_out")):
+        p = torch.from_numpy(gold[key_p].astype(np.float32))[None].contiguous()
+        got = ops.lidar_splat(p.to(DEV), torch.empty(1, 256, 256, 2, device=DEV)).cpu().permute(0, 3, 1, 2).numpy()[0]
+        want = preprocess.lidar_histogram(gold[key_p].astype(np.float32).astype(np.float64))
+        assert np.array_equal(got, want)
+        if key_p == "hist_rand_pts":
+            assert np.array_equal(got, gold[key_o])
+
+
+def test_lane_to_vector_and_polyline_pool():
+    from mmfn_amd import ops
+    from oracle.model import _VectornetEncoder
+    g = _g(41)
+    lane = torch.randn(2, 7, 10, 5, generator=g)
+    vec = ops.lane_to_vector(lane.to(DEV), torch.empty(2 * 7 * 9, 7, device=DEV))
+    _close(vec.view(2, 7, 9, 7), _VectornetEncoder.lane_to_vector(lane), 0.0)
+    R, V, H = 37, 9, 64
+    y = torch.relu(torch.randn(R, V, H, generator=g))  # ReLU output: ties at 0
+    for last in (False, True):
+        yr = y.clone().requires_grad_(True)
+        pooled = yr.max(dim=-2, keepdim=True).values.expand_as(yr)
+        out_ref = torch.cat([yr, pooled], -1)
+        if last:
+            out_ref = out_ref.max(dim=-2).values
+        gout = torch.randn(out_ref.shape, generator=g)
+        out_ref.backward(gout)
+        out = torch.empty(out_ref.shape, device=DEV)
+        arg = torch.empty(R, H, dtype=torch.uint8, device=DEV)
+        ops.polyline_pool_fwd(y.to(DEV), out, arg, R, V, H, last)
+        assert torch.equal(out.cpu(), out_ref.detach())
+        gy = ops.polyline_pool_bwd(gout.to(DEV), arg, torch.empty(R, V, H, device=DEV), R, V, H, last)
+        _close(gy, yr.grad, 1e-6, "polyline bwd")
