@@ -33,8 +33,14 @@ int mmfn_device_selftest(void* stream);
 int mmfn_fill_f32(float* p, float v, int64_t n, void* stream);
 /* y = a*x + b*y (b == 0 ignores the old y) */
 int mmfn_axpby_f32(float* y, const float* x, float a, float b, int64_t n, void* stream);
+/* out = y > 0 ? g : 0  (ReLU backward) */
+int mmfn_relu_mask_f32(const float* g, const float* y, float* out, int64_t n, void* stream);
 /* dropout RNG state {seed, step}: step += 1 (launched once per training step, graph-safe) */
 int mmfn_rng_advance(uint64_t* state, void* stream);
+/* out[i] = in[i] * (keep_i ? 1/(1-p) : 0) with the mask of a contiguous [M,N] epilogue dropout
+ * (index i = row*N + col): backward of nn.Dropout fused into a GEMM epilogue */
+int mmfn_dropout_apply_f32(const float* in, float* out, int64_t n, float p, const uint64_t* rng_state,
+                           uint32_t rng_stream, void* stream);
 
 /* ---- GEMM / implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 ----------------------- */
 /* operand addressing modes */

@@ -20,7 +20,7 @@ struct AttnArgs {
   float* o;                                         // [B*T, ldo]
   float* lse;                                       // [B, NH, T]
   const float* dO;                                  // backward: grad of o (ldo)
-  float* delta;                                     // [B, NH, T]  rowsum(dO * O)
+  float* delta;                                     // [B, NH, T]  sum_j P_j dP_j
   float* dq; float* dk; float* dv;                  // row stride ldg
   const int* kv_len;                                // optional [B]: keys >= kv_len[b] are masked
   const uint64_t* rng_state;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnArgs a) {
   }
 }
 
-// query-owned backward pass: delta = rowsum(dO*O), dQ
+// query-owned backward pass: delta = sum_j P_j dP_j, dQ
 template <int HS, int NKT>
 __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const AttnArgs a) {
   constexpr int NC = HS / 8;
@@ -143,20 +143,13 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const AttnArgs a) {
   const size_t rowbase = (size_t)b * T;
   const float* Qp = a.q + (rowbase + qc) * a.ld + hd * HS + 4 * h;
   const float* dOp = a.dO + (rowbase + qc) * a.ldo + hd * HS + 4 * h;
-  const float* Op = a.o + (rowbase + qc) * a.ldo + hd * HS + 4 * h;
   f32x4 qf[NC], dof[NC];
-  float dl = 0.f;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     qf[c] = ld4g(Qp + 8 * c);
     dof[c] = ld4g(dOp + 8 * c);
-    const f32x4 of = ld4g(Op + 8 * c);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dl += dof[c][j] * of[j];
   }
-  const float delta = dl + __shfl_xor(dl, 32, 64);
   const size_t statoff = ((size_t)b * a.NH + hd) * T + qc;
-  if (qvalid && h == 0) a.delta[statoff] = delta;
   const float lse = a.lse[statoff];
   const bool drop = a.drop_p > 0.f;
   uint64_t key64 = 0;
@@ -164,7 +157,11 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const AttnArgs a) {
   if (drop) { key64 = mmfn_rng_key(a.rng_state, a.rng_stream); inv_keep = 1.0f / (1.0f - a.drop_p); }
   const uint64_t pbase = (((uint64_t)b * a.NH + hd) * T + q) * (uint64_t)T;
 
-  f32x16 ds[NKT];
+  // P^T and dP^T tiles stay in registers; delta = sum_j P_j dP_j is formed from them directly
+  // (the same cancellation structure as softmax_backward: more accurate than rowsum(dO*O) when
+  // attention is near-uniform and dS is a small difference of large terms)
+  f32x16 ds[NKT], dpt[NKT];
+  float dl = 0.f, psum = 0.f;
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) {
     f32x16 st, dp;
@@ -185,11 +182,25 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const AttnArgs a) {
     for (int r = 0; r < 16; ++r) {
       const int key = kt * 32 + rowmap(r) + 4 * h;
       const float p = key < kvlen ? expf(st[r] * a.scale - lse) : 0.f;
-      float dpt = dp[r];
-      if (drop) dpt *= mmfn_dropout_scale(key64, pbase + (uint64_t)key, a.drop_p, inv_keep);
-      ds[kt][r] = p * (dpt - delta) * a.scale;
+      float dpv = dp[r];
+      if (drop) dpv *= mmfn_dropout_scale(key64, pbase + (uint64_t)key, a.drop_p, inv_keep);
+      ds[kt][r] = p;
+      dpt[kt][r] = dpv;
+      dl += p * dpv;
+      psum += p;
     }
   }
+  // P is recomputed from the rounded log-sum-exp, so sum_j P_j = 1 + O(1e-6); dividing by it keeps
+  // sum_j dS_j = 0 to rounding (otherwise a common-mode term eps*delta*P leaks into dQ/dK, which
+  // dominates when attention is near-uniform and |dP - delta| << |delta|)
+  dl += __shfl_xor(dl, 32, 64);
+  psum += __shfl_xor(psum, 32, 64);
+  const float delta = dl / psum;
+  if (qvalid && h == 0) a.delta[statoff] = delta;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ds[kt][r] = ds[kt][r] * (dpt[kt][r] - delta) * a.scale;
   f32x16 dq[ND];
 #pragma unroll
   for (int dt = 0; dt < ND; ++dt)

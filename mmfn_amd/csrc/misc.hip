@@ -14,7 +14,20 @@ __global__ void axpby_kernel(float* y, const float* x, float a, float b, int64_t
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     y[i] = a * x[i] + (b == 0.0f ? 0.0f : b * y[i]);
 }
+// out = y > 0 ? g : 0
+__global__ void relu_mask_kernel(const float* __restrict__ g, const float* __restrict__ y, float* __restrict__ out, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = y[i] > 0.0f ? g[i] : 0.0f;
+}
 __global__ void rng_advance_kernel(uint64_t* state) { state[1] += 1; }
+// out[i] = in[i] * keepscale(i): the backward of an epilogue dropout (same index = row*N + col)
+__global__ void dropout_apply_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, float p,
+                                     const uint64_t* __restrict__ state, uint32_t stream_id) {
+  const uint64_t key = mmfn_rng_key(state, stream_id);
+  const float inv_keep = 1.0f / (1.0f - p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = in[i] * mmfn_dropout_scale(key, (uint64_t)i, p, inv_keep);
+}
 }  // namespace
 
 extern "C" int mmfn_abi_version(void) { return 1; }
@@ -44,6 +57,24 @@ extern "C" int mmfn_axpby_f32(float* y, const float* x, float a, float b, int64_
 
 extern "C" int mmfn_rng_advance(uint64_t* state, void* stream) {
   hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_dropout_apply_f32(const float* in, float* out, int64_t n, float p, const uint64_t* rng_state,
+                                      uint32_t rng_stream, void* stream) {
+  if (n <= 0) return 0;
+  if (!rng_state || p < 0.f || p >= 1.f) return MMFN_EINVAL;
+  int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(dropout_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, n, p, rng_state, rng_stream);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_relu_mask_f32(const float* g, const float* y, float* out, int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(relu_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, y, out, n);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

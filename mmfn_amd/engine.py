@@ -1,0 +1,675 @@
+"""Static execution plan of the MMFN training step on one MI355X.
+
+There is no autograd tape and no tracing compiler: forward and backward of every layer are
+written out explicitly as sequences of HIP launches (mmfn_amd.ops -> libmmfn_hip.so) over
+buffers that are allocated once per batch size.  Nothing allocates or synchronises during a
+step, so a whole step can be captured into a hipGraph and replayed (mmfn_amd.model).
+
+Data layout: feature maps are NHWC [B,H,W,C]; transformer tokens are rows of a [B*T, C] matrix,
+which is the same memory as an 8x8 NHWC map, so the reference's permute/contiguous copies
+around each GPT (model_vec.py:228,240-244) do not exist here.
+
+Backward conventions: `bwd` methods receive dL/d(output) buffers and write parameter gradients
+straight into the flat gradient buffer (each parameter has exactly one writer per step).
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import ACT_GELU, ACT_NONE, ACT_RELU
+
+
+class Buffers(object):
+    """Named, shape-keyed activation buffers: allocated on first use, reused on every later step."""
+
+    def __init__(self, device):
+        self.device = device
+        self._bufs = {}
+
+    def get(self, name, shape, dtype=torch.float32):
+        key = (name, tuple(shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("buffer %s%s first used during graph capture; run one eager step first" % (name, tuple(shape)))
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self._bufs.values())
+
+
+class Ctx(object):
+    """Per-call execution context."""
+
+    def __init__(self, bufs, training, drop_p, rng_state):
+        self.bufs = bufs
+        self.training = training
+        self.drop = drop_p if training else (0.0, 0.0, 0.0)  # (embd, attn, resid)
+        self.rng_state = rng_state
+
+
+# ----------------------------------------------------------------------------- conv + BN
+class ConvBN(object):
+    """conv (bias-free) -> BatchNorm2d -> [+ residual] -> [ReLU]."""
+
+    def __init__(self, name, layout, conv_name, bn_name, bn_mod, stride, pad):
+        self.name = name
+        self.w = layout.w(conv_name + ".weight")
+        self.gw = layout.g(conv_name + ".weight")
+        self.bn_w, self.bn_b = layout.w(bn_name + ".weight"), layout.w(bn_name + ".bias")
+        self.g_bn_w, self.g_bn_b = layout.g(bn_name + ".weight"), layout.g(bn_name + ".bias")
+        self.bn = bn_mod
+        self.stride, self.pad = stride, pad
+        self.cout = self.w.shape[0]
+
+    def fwd(self, ctx, x, relu=True, res=None):
+        B = x.shape[0]
+        _, oshape = ops.conv_geom(x.shape, self.w.shape, self.stride, self.pad)
+        co = ctx.bufs.get(self.name + ".conv", oshape)
+        ops.conv2d_fwd(x, self.w, self.stride, self.pad, out=co)
+        M = oshape[0] * oshape[1] * oshape[2]
+        co2 = co.view(M, self.cout)
+        mean = ctx.bufs.get(self.name + ".mean", (self.cout,))
+        rstd = ctx.bufs.get(self.name + ".rstd", (self.cout,))
+        if ctx.training:
+            ops.bn_train_stats(co2, mean, rstd, self.bn.running_mean, self.bn.running_var, self.bn.num_batches_tracked,
+                               self.bn.eps, self.bn.momentum)
+        else:
+            ops.bn_eval_prepare(self.bn.running_mean, self.bn.running_var, mean, rstd, self.bn.eps)
+        y = ctx.bufs.get(self.name + ".out", oshape)
+        ops.bn_apply(co2, y.view(M, self.cout), mean, rstd, self.bn_w, self.bn_b, relu,
+                     res=None if res is None else res.view(M, self.cout))
+        self.saved = (x, co, y, mean, rstd, relu)
+        return y
+
+    def bwd(self, ctx, g, need_dx=True, ge_out=None, dx_res=None, mask_y=None):
+        """g: dL/dy.  ge_out receives the ReLU-masked g (the residual branch's gradient).
+        dx_res is added to dx (gradient arriving at x from another branch).
+        mask_y overrides the tensor whose sign gates the ReLU (when y was further modified)."""
+        x, co, y, mean, rstd, relu = self.saved
+        M = co.numel() // self.cout
+        dco = ctx.bufs.get(self.name + ".dconv", co.shape)
+        ymask = None
+        if relu:
+            ymask = (y if mask_y is None else mask_y).view(M, self.cout)
+        ops.bn_bwd(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.bn_w, dco.view(M, self.cout),
+                   self.g_bn_w, self.g_bn_b, ge_out=None if ge_out is None else ge_out.view(M, self.cout))
+        ops.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, out=self.gw)
+        if not need_dx:
+            return None
+        dx = ctx.bufs.get(self.name + ".dx", x.shape)
+        if dx_res is None:
+            ops.conv2d_dgrad(dco, self.w, tuple(x.shape), self.stride, self.pad, out=dx)
+        else:
+            cin = x.shape[-1]
+            ops.conv2d_dgrad(dco, self.w, tuple(x.shape), self.stride, self.pad, out=dx, res=dx_res, ldr=cin)
+        return dx
+
+
+class BasicBlock(object):
+    def __init__(self, name, layout, prefix, mod):
+        self.name = name
+        s = mod.stride
+        self.c1 = ConvBN(name + ".c1", layout, prefix + ".conv1", prefix + ".bn1", mod.bn1, s, 1)
+        self.c2 = ConvBN(name + ".c2", layout, prefix + ".conv2", prefix + ".bn2", mod.bn2, 1, 1)
+        self.down = None
+        if mod.downsample is not None:
+            self.down = ConvBN(name + ".down", layout, prefix + ".downsample.0", prefix + ".downsample.1",
+                               mod.downsample[1], s, 0)
+
+    def fwd(self, ctx, x):
+        y1 = self.c1.fwd(ctx, x, relu=True)
+        skip = x if self.down is None else self.down.fwd(ctx, x, relu=False)
+        return self.c2.fwd(ctx, y1, relu=True, res=skip)
+
+    def bwd(self, ctx, g, mask_y=None):
+        ge = ctx.bufs.get(self.name + ".ge", g.shape)
+        g_y1 = self.c2.bwd(ctx, g, ge_out=ge, mask_y=mask_y)
+        if self.down is None:
+            return self.c1.bwd(ctx, g_y1, dx_res=ge)
+        dx_skip = self.down.bwd(ctx, ge)
+        return self.c1.bwd(ctx, g_y1, dx_res=dx_skip)
+
+
+class ResNetTrunk(object):
+    def __init__(self, name, layout, prefix, mod, with_stem=True, first_layer=1):
+        self.name = name
+        self.stem = ConvBN(name + ".stem", layout, prefix + ".conv1", prefix + ".bn1", mod.bn1, 2, 3) if with_stem else None
+        self.layers = {}
+        for li in range(first_layer, 5):
+            seq = getattr(mod, "layer%d" % li)
+            self.layers[li] = [BasicBlock("%s.l%d.%d" % (name, li, j), layout, "%s.layer%d.%d" % (prefix, li, j), blk)
+                               for j, blk in enumerate(seq)]
+
+    def stem_fwd(self, ctx, x):
+        y = self.stem.fwd(ctx, x, relu=True)
+        B, H, W, C = y.shape
+        p = ctx.bufs.get(self.name + ".pool", (B, (H + 1) // 2, (W + 1) // 2, C))
+        idx = ctx.bufs.get(self.name + ".poolidx", p.shape, torch.uint8)
+        ops.maxpool_fwd(y, p, idx)
+        self.pool_saved = (y, idx)
+        return p
+
+    def stem_bwd(self, ctx, g):
+        y, idx = self.pool_saved
+        gy = ctx.bufs.get(self.name + ".dpool", y.shape)
+        ops.maxpool_bwd(g, idx, gy)
+        self.stem.bwd(ctx, gy, need_dx=False)
+
+    def layer_fwd(self, ctx, li, x):
+        for blk in self.layers[li]:
+            x = blk.fwd(ctx, x)
+        return x
+
+    def layer_bwd(self, ctx, li, g, mask_y=None):
+        blocks = self.layers[li]
+        for i in range(len(blocks) - 1, -1, -1):
+            g = blocks[i].bwd(ctx, g, mask_y=mask_y if i == len(blocks) - 1 else None)
+        return g
+
+
+# ----------------------------------------------------------------------------- Linear helper
+class Linear(object):
+    def __init__(self, layout, prefix, bias=True):
+        self.w, self.gw = layout.w(prefix + ".weight"), layout.g(prefix + ".weight")
+        self.b = layout.w(prefix + ".bias") if bias else None
+        self.gb = layout.g(prefix + ".bias") if bias else None
+
+
+class LayerNorm(object):
+    def __init__(self, name, layout, prefix):
+        self.name = name
+        self.w, self.b = layout.w(prefix + ".weight"), layout.w(prefix + ".bias")
+        self.gw, self.gb = layout.g(prefix + ".weight"), layout.g(prefix + ".bias")
+
+    def fwd(self, ctx, x, act=ACT_NONE):
+        M, C = x.shape
+        y = ctx.bufs.get(self.name + ".y", (M, C))
+        mean, rstd = ctx.bufs.get(self.name + ".mu", (M,)), ctx.bufs.get(self.name + ".rs", (M,))
+        ops.layernorm_fwd(x, self.w, self.b, y, mean, rstd, act)
+        self.saved = (x, mean, rstd, act)
+        return y
+
+    def bwd(self, ctx, g, dres=None, out=None):
+        x, mean, rstd, act = self.saved
+        dx = ctx.bufs.get(self.name + ".dx", x.shape) if out is None else out
+        ops.layernorm_bwd(g, x, self.w, self.b, mean, rstd, dx, self.gw, self.gb, act, dres=dres)
+        return dx
+
+
+# ----------------------------------------------------------------------------- GPT fusion transformer
+class GPT(object):
+    """model_vec.py:136-246 (GPT), :112-133 (Block), :73-109 (SelfAttention)."""
+
+    def __init__(self, name, layout, prefix, mod, cfg, stream_base):
+        self.name, self.mod = name, mod
+        self.C = mod.n_embd
+        self.nh = cfg.n_head
+        self.hs = self.C // self.nh
+        self.T = mod.pos_emb.shape[1]
+        self.n_modal = mod.n_modal
+        self.pos, self.g_pos = layout.w(prefix + ".pos_emb"), layout.g(prefix + ".pos_emb")
+        self.vel = Linear(layout, prefix + ".vel_emb")
+        self.stream_base = stream_base
+        self.blocks = []
+        C = self.C
+        for i in range(len(mod.blocks)):
+            bp = "%s.blocks.%d" % (prefix, i)
+            blk = {
+                "ln1": LayerNorm("%s.b%d.ln1" % (name, i), layout, bp + ".ln1"),
+                "ln2": LayerNorm("%s.b%d.ln2" % (name, i), layout, bp + ".ln2"),
+                "proj": Linear(layout, bp + ".attn.proj"),
+                "fc1": Linear(layout, bp + ".mlp.0"),
+                "fc2": Linear(layout, bp + ".mlp.2"),
+            }
+            blk["wqkv"], blk["g_wqkv"] = layout.packed(bp + ".attn.key.weight", 3 * C, C)
+            blk["bqkv"], blk["g_bqkv"] = layout.packed(bp + ".attn.key.bias", 3 * C)
+            self.blocks.append(blk)
+        self.ln_f = LayerNorm(name + ".ln_f", layout, prefix + ".ln_f")
+
+    def fwd(self, ctx, feats, velocity):
+        B = feats[0].shape[0]
+        T, C, nh, hs = self.T, self.C, self.nh, self.hs
+        M = B * T
+        bufs, nm = ctx.bufs, self.name
+        p_embd, p_attn, p_resid = ctx.drop
+        x = bufs.get(nm + ".x0", (B, T, C))
+        ops.tokens_fwd(feats, self.pos.view(T, C), self.vel.w.view(C), self.vel.b, velocity, x, p_embd, ctx.rng_state,
+                       self.stream_base)
+        self.velocity = velocity
+        x = x.view(M, C)
+        self.acts = []
+        scale = 1.0 / math.sqrt(hs)
+        for i, blk in enumerate(self.blocks):
+            sb = self.stream_base + 1 + 3 * i
+            a = blk["ln1"].fwd(ctx, x)
+            qkv = bufs.get("%s.b%d.qkv" % (nm, i), (M, 3 * C))
+            ops.linear_fwd(a, blk["wqkv"], blk["bqkv"], out=qkv)
+            o = bufs.get("%s.b%d.att" % (nm, i), (M, C))
+            lse = bufs.get("%s.b%d.lse" % (nm, i), (B, nh, T))
+            # packed columns: [key | query | value]  (reference registration order, model_vec.py:82-84)
+            ops.attention_fwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, C, lse, B, T, nh, hs, scale, drop_p=p_attn,
+                              rng_state=ctx.rng_state, rng_stream=sb)
+            x1 = bufs.get("%s.b%d.x1" % (nm, i), (M, C))
+            ops.linear_fwd(o, blk["proj"].w, blk["proj"].b, out=x1, res=x, ldr=C, drop_p=p_resid, rng_state=ctx.rng_state,
+                           rng_stream=sb + 1)
+            a2 = blk["ln2"].fwd(ctx, x1)
+            h = bufs.get("%s.b%d.h" % (nm, i), (M, 4 * C))
+            ops.linear_fwd(a2, blk["fc1"].w, blk["fc1"].b, out=h, relu=True)
+            x2 = bufs.get("%s.b%d.x2" % (nm, i), (M, C))
+            ops.linear_fwd(h, blk["fc2"].w, blk["fc2"].b, out=x2, res=x1, ldr=C, drop_p=p_resid, rng_state=ctx.rng_state,
+                           rng_stream=sb + 2)
+            self.acts.append((x, a, qkv, o, lse, x1, a2, h))
+            x = x2
+        y = self.ln_f.fwd(ctx, x)
+        return y.view(B, T, C)
+
+    def bwd(self, ctx, g_y):
+        """g_y: [B,T,C] gradient of the GPT output.  Returns the token gradient (masked by the
+        embedding dropout) to be spread back over the feature maps; writes all parameter grads."""
+        B = g_y.shape[0]
+        T, C, nh, hs = self.T, self.C, self.nh, self.hs
+        M = B * T
+        bufs, nm = ctx.bufs, self.name
+        p_embd, p_attn, p_resid = ctx.drop
+        scale = 1.0 / math.sqrt(hs)
+        g = self.ln_f.bwd(ctx, g_y.view(M, C))
+        for i in range(len(self.blocks) - 1, -1, -1):
+            blk = self.blocks[i]
+            sb = self.stream_base + 1 + 3 * i
+            x, a, qkv, o, lse, x1, a2, h = self.acts[i]
+            # ---- MLP branch: x2 = x1 + drop(fc2(relu(fc1(ln2(x1)))))
+            gp = g
+            if p_resid > 0.0:
+                gp = ops.dropout_apply(g, bufs.get(nm + ".gdrop", (M, C)), p_resid, ctx.rng_state, sb + 2)
+            ops.colsum(gp, blk["fc2"].gb)
+            ops.linear_dw(gp, h, out=blk["fc2"].gw)
+            gh = bufs.get(nm + ".gh", (M, 4 * C))
+            ops.linear_dx(gp, blk["fc2"].w, out=gh, aux=h, ldaux=4 * C)
+            ops.colsum(gh, blk["fc1"].gb)
+            ops.linear_dw(gh, a2, out=blk["fc1"].gw)
+            ga2 = bufs.get(nm + ".ga", (M, C))
+            ops.linear_dx(gh, blk["fc1"].w, out=ga2)
+            g1 = blk["ln2"].bwd(ctx, ga2, dres=g, out=bufs.get(nm + ".g1", (M, C)))
+            # ---- attention branch: x1 = x + drop(proj(att(ln1(x))))
+            gp = g1
+            if p_resid > 0.0:
+                gp = ops.dropout_apply(g1, bufs.get(nm + ".gdrop", (M, C)), p_resid, ctx.rng_state, sb + 1)
+            ops.colsum(gp, blk["proj"].gb)
+            ops.linear_dw(gp, o, out=blk["proj"].gw)
+            go = bufs.get(nm + ".go", (M, C))
+            ops.linear_dx(gp, blk["proj"].w, out=go)
+            dqkv = bufs.get(nm + ".dqkv", (M, 3 * C))
+            delta = bufs.get(nm + ".delta", (B, nh, T))
+            ops.attention_bwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, go, C, lse, delta, dqkv[:, C:], dqkv, dqkv[:, 2 * C:],
+                              3 * C, B, T, nh, hs, scale, drop_p=p_attn, rng_state=ctx.rng_state, rng_stream=sb)
+            ops.colsum(dqkv, blk["g_bqkv"])
+            ops.linear_dw(dqkv, a, out=blk["g_wqkv"])
+            ga = bufs.get(nm + ".ga", (M, C))
+            ops.linear_dx(dqkv, blk["wqkv"], out=ga)
+            g = blk["ln1"].bwd(ctx, ga, dres=g1, out=bufs.get(nm + ".g0_%d" % (i & 1), (M, C)))
+        gtok = g.view(B, T, C)
+        ops.tokens_bwd(gtok, self.velocity, self.g_pos.view(T, C), self.vel.gw.view(C), self.vel.gb, p_embd, ctx.rng_state,
+                       self.stream_base)
+        return gtok
+
+
+# ----------------------------------------------------------------------------- VectorNet
+class VectorNet(object):
+    """model_vec.py:326-416.  Only lane 0's fused token feeds the generator (:412), so everything
+    after the lane attention runs on B rows; the constant pos_emb branch (fed zeros, :408) runs on
+    a single row."""
+
+    def __init__(self, name, layout, prefix, mod):
+        self.name = name
+        self.sub = []
+        for i in range(3):
+            p = "%s.lane_subgraph.layers.mlp_%d.mlp" % (prefix, i)
+            self.sub.append((Linear(layout, p + ".0"), LayerNorm("%s.sub%d.ln" % (name, i), layout, p + ".1")))
+        self.pe0, self.pe_ln, self.pe3 = (Linear(layout, prefix + ".pos_emb.0"), LayerNorm(name + ".pe.ln", layout, prefix + ".pos_emb.1"),
+                                          Linear(layout, prefix + ".pos_emb.3"))
+        self.qkv = Linear(layout, prefix + ".L2L.to_qkv", bias=False)
+        self.to_out = Linear(layout, prefix + ".L2L.to_out.0")
+        self.af0, self.af_ln, self.af3 = (Linear(layout, prefix + ".agent_fusion.0"), LayerNorm(name + ".af.ln", layout, prefix + ".agent_fusion.1"),
+                                          Linear(layout, prefix + ".agent_fusion.3"))
+        self.gen0, self.gen_ln, self.gen3 = (Linear(layout, prefix + ".generator.0"), LayerNorm(name + ".gen.ln", layout, prefix + ".generator.1"),
+                                             Linear(layout, prefix + ".generator.3"))
+        self.heads = mod.L2L.heads
+
+    def fwd(self, ctx, lane, lane_num):
+        """lane [B,L,n,5] f32, lane_num int32 [B]  ->  map features NHWC [B,64,64,64]."""
+        bufs, nm = ctx.bufs, self.name
+        B, L, n, _ = lane.shape
+        V = n - 1
+        R = B * L
+        vec = ops.lane_to_vector(lane, bufs.get(nm + ".vec", (R * V, 7)))
+        x = vec
+        self.sub_saved = []
+        for i, (lin, ln) in enumerate(self.sub):
+            pre = bufs.get("%s.sub%d.pre" % (nm, i), (R * V, 64))
+            ops.linear_fwd(x, lin.w, lin.b, out=pre)
+            y = ln.fwd(ctx, pre, ACT_RELU)
+            last = i == len(self.sub) - 1
+            out = bufs.get("%s.sub%d.cat" % (nm, i), (R, 128) if last else (R * V, 128))
+            arg = bufs.get("%s.sub%d.arg" % (nm, i), (R, 64), torch.uint8)
+            ops.polyline_pool_fwd(y, out, arg, R, V, 64, last)
+            self.sub_saved.append((x, arg))
+            x = out
+        tok = x  # [R,128] lane tokens
+        qkv = bufs.get(nm + ".qkv", (R, 384))
+        ops.linear_fwd(tok, self.qkv.w, None, out=qkv)
+        att = bufs.get(nm + ".att", (R, 128))
+        lse = bufs.get(nm + ".lse", (B, self.heads, L))
+        hd = 128 // self.heads
+        ops.attention_fwd(qkv, qkv[:, 128:], qkv[:, 256:], 384, att, 128, lse, B, L, self.heads, hd, hd ** -0.5, kv_len=lane_num)
+        # lane 0 of every sample: strided rows of `att`
+        att0 = att.view(B, L * 128)[:, :128]
+        t0 = bufs.get(nm + ".t0", (B, 128))
+        ops.gemm(att0, self.to_out.w, t0, B, 128, 128, L * 128, 128, 128, bias=self.to_out.b)
+        # constant positional branch: pos_emb(zeros) = Linear(GELU(LN(bias0)))
+        pe_pre = bufs.get(nm + ".pe.pre", (1, 64))
+        zero2 = bufs.get(nm + ".zero2", (1, 2))
+        ops.fill(zero2, 0.0)
+        ops.linear_fwd(zero2, self.pe0.w, self.pe0.b, out=pe_pre)
+        pe_act = self.pe_ln.fwd(ctx, pe_pre, ACT_GELU)
+        pe = bufs.get(nm + ".pe", (1, 64))
+        ops.linear_fwd(pe_act, self.pe3.w, self.pe3.b, out=pe)
+        # agent_fusion.0 over cat([t0, pe]): split the [128,192] weight into its two column blocks
+        cbias = bufs.get(nm + ".af.cbias", (1, 128))
+        ops.gemm(pe, self.af0.w[:, 128:], cbias, 1, 128, 64, 64, 192, 128, bias=self.af0.b)
+        af_pre = bufs.get(nm + ".af.pre", (B, 128))
+        ops.gemm(t0, self.af0.w, af_pre, B, 128, 128, 128, 192, 128, bias=cbias.view(128))
+        af_act = self.af_ln.fwd(ctx, af_pre, ACT_GELU)
+        fused = bufs.get(nm + ".fused", (B, 128))
+        ops.linear_fwd(af_act, self.af3.w, self.af3.b, out=fused)
+        gen_pre = bufs.get(nm + ".gen.pre", (B, 64))
+        ops.linear_fwd(fused, self.gen0.w, self.gen0.b, out=gen_pre)
+        gen_act = self.gen_ln.fwd(ctx, gen_pre, ACT_GELU)
+        nchw = bufs.get(nm + ".nchw", (B, 64 * 64 * 64))
+        ops.linear_fwd(gen_act, self.gen3.w, self.gen3.b, out=nchw)
+        out = bufs.get(nm + ".out", (B, 64, 64, 64))
+        ops.transpose(nchw, out, B, 64, 4096)  # "b (n d a)" -> NHWC [b, d, a, n]
+        self.saved = (B, L, V, tok, qkv, att, lse, lane_num, t0, pe, pe_act, af_act, fused, gen_act)
+        return out
+
+    def bwd(self, ctx, g_out):
+        bufs, nm = ctx.bufs, self.name
+        B, L, V, tok, qkv, att, lse, lane_num, t0, pe, pe_act, af_act, fused, gen_act = self.saved
+        R = B * L
+        g_nchw = bufs.get(nm + ".g.nchw", (B, 64 * 64 * 64))
+        ops.transpose(g_out.view(B, 4096, 64), g_nchw, B, 4096, 64)
+        ops.colsum(g_nchw, self.gen3.gb)
+        ops.linear_dw(g_nchw, gen_act, out=self.gen3.gw)
+        g_gen_act = ops.linear_dx(g_nchw, self.gen3.w, out=bufs.get(nm + ".g.gen_act", (B, 64)))
+        g_gen_pre = self.gen_ln.bwd(ctx, g_gen_act)
+        ops.colsum(g_gen_pre, self.gen0.gb)
+        ops.linear_dw(g_gen_pre, fused, out=self.gen0.gw)
+        g_fused = ops.linear_dx(g_gen_pre, self.gen0.w, out=bufs.get(nm + ".g.fused", (B, 128)))
+        ops.colsum(g_fused, self.af3.gb)
+        ops.linear_dw(g_fused, af_act, out=self.af3.gw)
+        g_af_act = ops.linear_dx(g_fused, self.af3.w, out=bufs.get(nm + ".g.af_act", (B, 128)))
+        g_af_pre = self.af_ln.bwd(ctx, g_af_act)
+        # agent_fusion.0: columns 0:128 act on t0, columns 128:192 on the constant pe row
+        gsum = ops.colsum(g_af_pre, bufs.get(nm + ".g.afsum", (1, 128)).view(128)).view(1, 128)
+        ops.axpby(self.af0.gb, gsum.view(128), 1.0, 0.0)
+        ops.gemm(g_af_pre, t0, self.af0.gw, 128, 128, B, 128, 128, 192, a_mode=ops.A_COLMAJOR, b_mode=ops.B_KN)
+        ops.gemm(gsum, pe, self.af0.gw[:, 128:], 128, 64, 1, 128, 64, 192, a_mode=ops.A_COLMAJOR, b_mode=ops.B_KN)
+        g_t0 = bufs.get(nm + ".g.t0", (B, 128))
+        ops.gemm(g_af_pre, self.af0.w, g_t0, B, 128, 128, 128, 192, 128, b_mode=ops.B_KN)
+        g_pe = bufs.get(nm + ".g.pe", (1, 64))
+        ops.gemm(gsum, self.af0.w[:, 128:], g_pe, 1, 64, 128, 128, 192, 64, b_mode=ops.B_KN)
+        # pos_emb branch (single row; its first Linear sees a zero input -> exactly-zero weight grad)
+        ops.axpby(self.pe3.gb, g_pe.view(64), 1.0, 0.0)
+        ops.linear_dw(g_pe, pe_act, out=self.pe3.gw)
+        g_pe_act = ops.linear_dx(g_pe, self.pe3.w, out=bufs.get(nm + ".g.pe_act", (1, 64)))
+        g_pe_pre = self.pe_ln.bwd(ctx, g_pe_act)
+        ops.axpby(self.pe0.gb, g_pe_pre.view(64), 1.0, 0.0)
+        ops.fill(self.pe0.gw, 0.0)
+        # to_out on lane 0 only
+        ops.colsum(g_t0, self.to_out.gb)
+        att0 = att.view(B, L * 128)[:, :128]
+        ops.gemm(g_t0, att0, self.to_out.gw, 128, 128, B, 128, L * 128, 128, a_mode=ops.A_COLMAJOR, b_mode=ops.B_KN)
+        g_att = bufs.get(nm + ".g.att", (R, 128))
+        ops.fill(g_att, 0.0)
+        ops.gemm(g_t0, self.to_out.w, g_att.view(B, L * 128)[:, :128], B, 128, 128, 128, 128, L * 128, b_mode=ops.B_KN)
+        dqkv = bufs.get(nm + ".g.qkv", (R, 384))
+        delta = bufs.get(nm + ".delta", (B, self.heads, L))
+        hd = 128 // self.heads
+        ops.attention_bwd(qkv, qkv[:, 128:], qkv[:, 256:], 384, att, g_att, 128, lse, delta, dqkv, dqkv[:, 128:], dqkv[:, 256:],
+                          384, B, L, self.heads, hd, hd ** -0.5, kv_len=lane_num)
+        ops.linear_dw(dqkv, tok, out=self.qkv.gw)
+        g = ops.linear_dx(dqkv, self.qkv.w, out=bufs.get(nm + ".g.tok", (R, 128)))
+        for i in range(len(self.sub) - 1, -1, -1):
+            lin, ln = self.sub[i]
+            x_in, arg = self.sub_saved[i]
+            last = i == len(self.sub) - 1
+            gy = ops.polyline_pool_bwd(g, arg, bufs.get("%s.g.sub%d.y" % (nm, i), (R * V, 64)), R, V, 64, last)
+            g_pre = ln.bwd(ctx, gy)
+            ops.colsum(g_pre, lin.gb)
+            ops.linear_dw(g_pre, x_in, out=lin.gw)
+            if i > 0:
+                g = ops.linear_dx(g_pre, lin.w, out=bufs.get("%s.g.sub%d.x" % (nm, i), (R * V, 128)))
+
+
+# ----------------------------------------------------------------------------- waypoint head
+class Head(object):
+    """model_vec.py:642-651,664-680: join MLP 512-256-128-64 (ReLU), GRUCell x pred_len, Linear(64,2)."""
+
+    def __init__(self, layout, pred_len):
+        self.join = [Linear(layout, "join.0"), Linear(layout, "join.2"), Linear(layout, "join.4")]
+        self.w_ih, self.w_hh = layout.w("decoder.weight_ih"), layout.w("decoder.weight_hh")
+        self.b_ih, self.b_hh = layout.w("decoder.bias_ih"), layout.w("decoder.bias_hh")
+        self.out = Linear(layout, "output")
+        self.grads = [layout.g("decoder.weight_ih"), layout.g("decoder.weight_hh"), layout.g("decoder.bias_ih"),
+                      layout.g("decoder.bias_hh"), self.out.gw, self.out.gb]
+        self.steps = pred_len
+
+    def fwd(self, ctx, fused, target, gt=None):
+        bufs = ctx.bufs
+        B = fused.shape[0]
+        self.xs = [fused]
+        x = fused
+        for i, lin in enumerate(self.join):
+            y = bufs.get("head.j%d" % i, (B, lin.w.shape[0]))
+            ops.linear_fwd(x, lin.w, lin.b, out=y, relu=True)
+            self.xs.append(y)
+            x = y
+        S = self.steps
+        pred = bufs.get("head.pred", (B, S, 2))
+        train = ctx.training
+        hs = bufs.get("head.hs", (B, S + 1, 64)) if train else None
+        gates = bufs.get("head.gates", (B, S, 4, 64)) if train else None
+        xin = bufs.get("head.xin", (B, S, 2)) if train else None
+        lt = bufs.get("head.lt", (B,)) if gt is not None else None
+        loss = bufs.get("head.loss", (1,)) if gt is not None else None
+        ops.gru_head_fwd(x, target, self.w_ih, self.w_hh, self.b_ih, self.b_hh, self.out.w, self.out.b, gt, pred, hs, gates, xin,
+                         lt, loss, S)
+        self.saved = (pred, gt, hs, gates, xin)
+        return pred, loss
+
+    def bwd(self, ctx, dpred=None, gscale=None):
+        bufs = ctx.bufs
+        pred, gt, hs, gates, xin = self.saved
+        B, S = pred.shape[0], self.steps
+        if gscale is None:
+            gscale = 1.0 / (B * S * 2)
+        npart = ops.lib().mmfn_gru_head_part_floats()
+        part = bufs.get("head.part", (B, npart))
+        dz = bufs.get("head.dz", (B, 64))
+        ops.gru_head_bwd(pred, gt, dpred, gscale, self.w_ih, self.w_hh, self.out.w, hs, gates, xin, dz, part, S)
+        tot = ops.colsum(part, bufs.get("head.partsum", (npart,)))
+        o = 0
+        for gbuf in self.grads:
+            n = gbuf.numel()
+            ops.axpby(gbuf, tot[o:o + n], 1.0, 0.0)
+            o += n
+        # z0 = relu(join.4(.)): mask the GRU's gradient, then walk the MLP back; each dX GEMM applies
+        # the ReLU mask of the layer below in its epilogue
+        g = ops.relu_mask(dz, self.xs[-1], out=bufs.get("head.gz", dz.shape))
+        for i in range(len(self.join) - 1, -1, -1):
+            lin, x = self.join[i], self.xs[i]
+            ops.colsum(g, lin.gb)
+            ops.linear_dw(g, x, out=lin.gw)
+            gx = bufs.get("head.gx%d" % i, x.shape)
+            if i > 0:
+                g = ops.linear_dx(g, lin.w, out=gx, aux=x, ldaux=x.shape[1])
+            else:
+                g = ops.linear_dx(g, lin.w, out=gx)
+        return g
+
+
+# ----------------------------------------------------------------------------- whole network
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+class Engine(object):
+    """Forward / backward / optimizer step of one MMFN replica on one GPU.
+
+    Orchestration restates Encoder.forward (model_vec.py:488-598; model_img.py:310-423) and
+    MMFN.forward (model_vec.py:653-682) for seq_len = 1, n_views = 1 (the reference's only
+    configuration, config.py:6,11)."""
+
+    def __init__(self, module, layout, variant):
+        cfg = module.config
+        if cfg.seq_len != 1 or cfg.n_views != 1:
+            raise NotImplementedError("only seq_len=1, n_views=1 (the reference configuration) is built")
+        self.module, self.layout, self.variant, self.cfg = module, layout, variant, cfg
+        self.device = layout.device
+        if self.device.type != "cuda":
+            raise ops._lib.MMFNLibraryError("the MMFN HIP path needs a GPU device (got %s); there is no CPU fallback" % self.device)
+        enc = module.encoder
+        self.img = ResNetTrunk("img", layout, "encoder.image_encoder.features", enc.image_encoder.features)
+        self.lid = ResNetTrunk("lid", layout, "encoder.lidar_encoder._model", enc.lidar_encoder._model)
+        if variant == "img":
+            self.map = ResNetTrunk("map", layout, "encoder.img_map_encoder.features", enc.img_map_encoder.features)
+            self.vec = None
+        else:
+            self.map = ResNetTrunk("map", layout, "encoder.img_map_encoder.features", enc.img_map_encoder.features,
+                                   with_stem=False, first_layer=2)
+            self.vec = VectorNet("vec", layout, "encoder.vectornet_encoder", enc.vectornet_encoder)
+        if variant == "rad":
+            raise NotImplementedError("radar (GAT) branch: SURVEY.md section 8 row a14 is not built yet")
+        self.gpts = [GPT("gpt%d" % (i + 1), layout, "encoder.transformer%d" % (i + 1), getattr(enc, "transformer%d" % (i + 1)),
+                         cfg, 100 * (i + 1)) for i in range(4)]
+        self.head = Head(layout, cfg.pred_len)
+        self.bufs = {}
+        dev = self.device
+        self.rng_state = torch.tensor([0x5EED, 0], dtype=torch.int64, device=dev)
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.norm_mean = torch.tensor(IMAGENET_MEAN, dtype=torch.float32, device=dev)
+        self.norm_inv_std = torch.tensor([1.0 / s for s in IMAGENET_STD], dtype=torch.float32, device=dev)
+        ops.norm_workspace(dev)
+        ops.workspace(64 << 20, dev)
+
+    # ------------------------------------------------------------------ inputs
+    def _bufs_for(self, B):
+        b = self.bufs.get(B)
+        if b is None:
+            b = Buffers(self.device)
+            self.bufs[B] = b
+        return b
+
+    def _ctx(self, B, training):
+        cfg = self.cfg
+        return Ctx(self._bufs_for(B), training, (cfg.embd_pdrop, cfg.attn_pdrop, cfg.resid_pdrop), self.rng_state)
+
+    def _ingest(self, ctx, inp):
+        """inp: dict of device tensors -> NHWC network inputs."""
+        bufs = ctx.bufs
+        if "rgb_u8" in inp:
+            rgb = inp["rgb_u8"]
+            B = rgb.shape[0]
+            img = ops.ingest_rgb_u8(rgb, bufs.get("in.img", (B, 256, 256, 3)))
+        else:
+            x = inp["image"]
+            B = x.shape[0]
+            img = ops.nchw_to_nhwc(x, bufs.get("in.img", (B, x.shape[2], x.shape[3], 3)), self.norm_mean, self.norm_inv_std)
+        if "lidar_pts" in inp:
+            lid = ops.lidar_splat(inp["lidar_pts"], bufs.get("in.lid", (B, 256, 256, 2)))
+        else:
+            x = inp["lidar"]
+            lid = ops.nchw_to_nhwc(x, bufs.get("in.lid", (B, x.shape[2], x.shape[3], x.shape[1])))
+        mp = None
+        if self.variant == "img":
+            x = inp["map"]
+            mp = ops.nchw_to_nhwc(x, bufs.get("in.map", (B, x.shape[2], x.shape[3], 3)))  # NOT normalised (model_img.py:337)
+        return img, lid, mp
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, inp, training, gt=None):
+        B = inp["target_point"].shape[0]
+        ctx = self._ctx(B, training)
+        self._last = (ctx, B)
+        img, lid, mp = self._ingest(ctx, inp)
+        vel = inp["velocity"]
+        f_img = self.img.layer_fwd(ctx, 1, self.img.stem_fwd(ctx, img))
+        f_lid = self.lid.layer_fwd(ctx, 1, self.lid.stem_fwd(ctx, lid))
+        if self.variant == "img":
+            f_map = self.map.layer_fwd(ctx, 1, self.map.stem_fwd(ctx, mp))
+        else:
+            f_map = self.vec.fwd(ctx, inp["lane"], inp["lane_num"])
+        self.taps = {"stage1": (f_img, f_lid, f_map)}
+        feats = [f_img, f_lid, f_map]
+        trunks = [self.img, self.lid, self.map]
+        self.pre_add = []
+        for s in range(4):
+            if s > 0:
+                feats = [t.layer_fwd(ctx, s + 1, f) for t, f in zip(trunks, feats)]
+            tok = self.gpts[s].fwd(ctx, feats, vel)
+            self.taps["gpt%d" % (s + 1)] = tok
+            self.pre_add.append(feats)
+            Bq, S, _, C = feats[0].shape
+            feats = [ops.upsample_add_fwd(f, tok, ctx.bufs.get("fuse%d.%d" % (s, m), f.shape), m) for m, f in enumerate(feats)]
+        fused = ops.gap_sum_fwd(feats, ctx.bufs.get("fused", (B, 512)))
+        self.taps["fused"] = fused
+        pred, loss = self.head.fwd(ctx, fused, inp["target_point"], gt)
+        return pred, loss
+
+    def backward(self, dpred=None, gscale=None):
+        """Backward of the last training forward.  dpred None => gradient of the fused L1 loss."""
+        ctx, B = self._last
+        bufs = ctx.bufs
+        g_fused = self.head.bwd(ctx, dpred, gscale)
+        trunks = [self.img, self.lid, self.map]
+        shapes = [f.shape for f in self.pre_add[3]]
+        G = [bufs.get("G3.%d" % m, shp) for m, shp in enumerate(shapes)]
+        ops.gap_sum_bwd(g_fused, G)
+        for s in range(3, -1, -1):
+            gpt = self.gpts[s]
+            gtok = bufs.get("gtok%d" % s, (B, gpt.T, gpt.C))
+            for m, g in enumerate(G):
+                ops.upsample_adj(g, gtok, m)
+            gin = gpt.bwd(ctx, gtok)
+            dF = [ops.pool_bcast_add(g, gin, bufs.get("dF%d.%d" % (s, m), g.shape), m) for m, g in enumerate(G)]
+            if s > 0:
+                G = [t.layer_bwd(ctx, s + 1, d) for t, d in zip(trunks, dF)]
+        g_img = self.img.layer_bwd(ctx, 1, dF[0])
+        self.img.stem_bwd(ctx, g_img)
+        g_lid = self.lid.layer_bwd(ctx, 1, dF[1])
+        self.lid.stem_bwd(ctx, g_lid)
+        if self.variant == "img":
+            g_map = self.map.layer_bwd(ctx, 1, dF[2])
+            self.map.stem_bwd(ctx, g_map)
+        else:
+            self.vec.bwd(ctx, dF[2])
+
+    def optimizer_step(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+        L = self.layout
+        ops.step_advance(self.step_count)
+        ops.adamw(L.params, L.grads, L.exp_avg, L.exp_avg_sq, self.step_count, lr, betas[0], betas[1], eps, weight_decay,
+                  grad_scale, n=L.tail)
+
+    def train_step(self, inp, gt, lr=1e-4, grad_hook=None):
+        """zero-grad (implicit: every gradient is overwritten) + forward + L1 + backward + AdamW
+        (phase2_train_net.py:60-110).  Returns the device-resident loss scalar."""
+        ops.rng_advance(self.rng_state)
+        _, loss = self.forward(inp, True, gt)
+        self.backward()
+        if grad_hook is not None:
+            grad_hook(self.layout.grads[:self.layout.tail])
+        self.optimizer_step(lr=lr)
+        return loss

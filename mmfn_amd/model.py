@@ -1,0 +1,173 @@
+"""MMFN model class with the reference's constructor / forward / control_pid / checkpoint contract
+(mmfn_utils/models/model_vec.py:626-726, model_img.py:451-550, model_rad.py:656-745), executing on
+hand-written gfx950 kernels through mmfn_amd.engine.
+
+Drop-in surface:
+  MMFN(config, device)                                   same ctor
+  forward(image_list, lidar_list, maps_list, vectormaps_list, radar_list, radar_adj,
+          target_point, velocity) -> pred_wp [B, pred_len, 2]
+  control_pid(waypoints, velocity)                       CPU numpy PID, as the agents call it
+  state_dict()/load_state_dict()                         identical keys / shapes / order
+  parameters()                                           reference order (optimizer state files map 1:1)
+Training through autograd works (`loss.backward()` fills p.grad from the flat gradient buffer);
+`train_step()` is the fused fast path (forward + L1 + backward + AdamW, hipGraph-capturable).
+"""
+from collections import deque
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import params as P
+from ._lib import MMFNLibraryError
+
+
+class PIDController(object):
+    """model_vec.py:601-623."""
+
+    def __init__(self, K_P=1.0, K_I=0.0, K_D=0.0, n=20):
+        self._K_P, self._K_I, self._K_D = K_P, K_I, K_D
+        self._window = deque([0 for _ in range(n)], maxlen=n)
+        self._max = 0.0
+        self._min = 0.0
+
+    def step(self, error):
+        self._window.append(error)
+        self._max = max(self._max, abs(error))
+        self._min = -abs(self._max)
+        if len(self._window) >= 2:
+            integral = np.mean(self._window)
+            derivative = self._window[-1] - self._window[-2]
+        else:
+            integral, derivative = 0.0, 0.0
+        return self._K_P * error + self._K_I * integral + self._K_D * derivative
+
+
+class _AutogradBridge(torch.autograd.Function):
+    """Lets a reference-style loop (`loss = f(model(...)); loss.backward()`) drive the explicit
+    HIP backward: the whole network is one autograd node."""
+
+    @staticmethod
+    def forward(ctx, anchor, module, inp):
+        pred, _ = module._engine_for().forward(inp, True, None)
+        ctx.module = module
+        return pred.clone()
+
+    @staticmethod
+    def backward(ctx, dpred):
+        m = ctx.module
+        m._engine_for().backward(dpred.contiguous(), 1.0)
+        m._layout.attach_grads()
+        return None, None, None
+
+
+class MMFN(nn.Module):
+    """Transformer-based multi-modal fusion + GRU waypoint head (vec variant by default)."""
+
+    variant = "vec"
+
+    def __init__(self, config, device, variant=None):
+        super().__init__()
+        if variant is not None:
+            self.variant = variant
+        self.device = device
+        self.config = config
+        self.pred_len = config.pred_len
+        self.turn_controller = PIDController(config.turn_KP, config.turn_KI, config.turn_KD, config.turn_n)
+        self.speed_controller = PIDController(config.speed_KP, config.speed_KI, config.speed_KD, config.speed_n)
+        self.encoder = P.encoder_params(config, self.variant)
+        self.join = nn.Sequential(nn.Linear(512, 256), nn.ReLU(inplace=True), nn.Linear(256, 128), nn.ReLU(inplace=True),
+                                  nn.Linear(128, 64), nn.ReLU(inplace=True))
+        self.decoder = nn.GRUCell(input_size=2, hidden_size=64)
+        self.output = nn.Linear(64, 2)
+        object.__setattr__(self, "_layout", P.FlatLayout(self, P.default_unused(self.variant)))
+        object.__setattr__(self, "_engine", None)
+        object.__setattr__(self, "_anchor", None)
+        self._layout.materialize(device)
+
+    # ------------------------------------------------------------------ device moves keep the flat layout
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        dev = next(self.parameters()).device
+        self._layout.materialize(dev)
+        object.__setattr__(self, "_engine", None)
+        self.device = dev
+        return self
+
+    def _engine_for(self):
+        if self._engine is None:
+            from .engine import Engine
+            if self._layout.device.type != "cuda":
+                raise MMFNLibraryError("MMFN runs on hand-written HIP kernels only: construct it on a GPU device "
+                                       "(got %s); there is no CPU fallback" % self._layout.device)
+            object.__setattr__(self, "_engine", Engine(self, self._layout, self.variant))
+            object.__setattr__(self, "_anchor", torch.zeros(1, device=self._layout.device, requires_grad=True))
+        return self._engine
+
+    # ------------------------------------------------------------------ reference forward signature
+    def _pack(self, image_list, lidar_list, maps_list, vectormaps_list, radar_list, radar_adj, target_point, velocity):
+        dev = self._layout.device
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        cfg = self.config
+        if len(image_list) != cfg.seq_len or len(lidar_list) != cfg.seq_len:
+            raise NotImplementedError("only seq_len=1, n_views=1 inputs are supported")
+        cfg.n_views = len(image_list) // cfg.seq_len  # the reference mutates config here (model_vec.py:504)
+        inp = {"image": f32(image_list[0]), "lidar": f32(lidar_list[0]), "target_point": f32(target_point),
+               "velocity": f32(velocity).view(-1)}
+        assert inp["image"].shape[2:] == inp["lidar"].shape[2:], "image and LiDAR BEV must share H x W (model_vec.py:500,506)"
+        if self.variant == "img":
+            inp["map"] = f32(maps_list[0])
+        else:
+            lane = vectormaps_list[0][0]
+            lane_num = vectormaps_list[1][0]
+            if lane.dim() == 5:  # agent packing [1,1,L,10,5] (e2e_agent/mmfn_vectornet.py:287-293)
+                lane = lane[0]
+            B = lane.shape[0]
+            inp["lane"] = f32(lane)
+            inp["lane_num"] = lane_num.reshape(B).to(device=dev, dtype=torch.int32).contiguous()
+        return inp
+
+    def forward(self, image_list, lidar_list, maps_list, vectormaps_list, radar_list, radar_adj, target_point, velocity):
+        inp = self._pack(image_list, lidar_list, maps_list, vectormaps_list, radar_list, radar_adj, target_point, velocity)
+        eng = self._engine_for()
+        if self.training and torch.is_grad_enabled():
+            return _AutogradBridge.apply(self._anchor, self, inp)
+        pred, _ = eng.forward(inp, self.training, None)
+        return pred.clone()
+
+    # ------------------------------------------------------------------ fused fast path
+    def train_step(self, inp, gt_wp, lr=1e-4, grad_hook=None):
+        """One full training step on device-resident inputs (see engine.Engine.train_step)."""
+        return self._engine_for().train_step(inp, gt_wp, lr=lr, grad_hook=grad_hook)
+
+    # ------------------------------------------------------------------ PID (model_vec.py:684-726)
+    def control_pid(self, waypoints, velocity):
+        assert waypoints.size(0) == 1
+        wp = waypoints[0].data.cpu().numpy()
+        wp[:, 1] *= -1
+        speed = velocity[0].data.cpu().numpy()
+        desired_speed = np.linalg.norm(wp[0] - wp[1]) * 2.0
+        brake = desired_speed < self.config.brake_speed or (speed / desired_speed) > self.config.brake_ratio
+        aim = (wp[1] + wp[0]) / 2.0
+        angle = np.degrees(np.pi / 2 - np.arctan2(aim[1], aim[0])) / 90
+        if speed < 0.01:
+            angle = np.array(0.0)
+        steer = np.clip(self.turn_controller.step(angle), -1.0, 1.0)
+        delta = np.clip(desired_speed - speed, 0.0, self.config.clip_delta)
+        throttle = np.clip(self.speed_controller.step(delta), 0.0, self.config.max_throttle)
+        throttle = throttle if not brake else 0.0
+        metadata = {
+            "speed": float(speed.astype(np.float64)), "steer": float(steer), "throttle": float(throttle),
+            "brake": float(brake), "wp_2": tuple(wp[1].astype(np.float64)), "wp_1": tuple(wp[0].astype(np.float64)),
+            "desired_speed": float(desired_speed.astype(np.float64)), "angle": float(angle.astype(np.float64)),
+            "aim": tuple(aim.astype(np.float64)), "delta": float(delta.astype(np.float64)),
+        }
+        return steer, throttle, brake, metadata
+
+
+class MMFNImg(MMFN):
+    variant = "img"
+
+
+class MMFNRad(MMFN):
+    variant = "rad"

@@ -367,3 +367,14 @@ def polyline_pool_fwd(y, out, arg, R, V, H, last):
 def polyline_pool_bwd(gout, arg, gy, R, V, H, last):
     _call("mmfn_polyline_pool_bwd_f32", ptr(gout), ptr(arg), ptr(gy), R, V, H, 1 if last else 0, stream())
     return gy
+
+
+def dropout_apply(inp, out, p, rng_state, rng_stream):
+    _call("mmfn_dropout_apply_f32", ptr(inp), ptr(out), inp.numel(), float(p), ptr(rng_state), rng_stream, stream())
+    return out
+
+
+def relu_mask(g, y, out=None):
+    out = g if out is None else out
+    _call("mmfn_relu_mask_f32", ptr(g), ptr(y), ptr(out), g.numel(), stream())
+    return out

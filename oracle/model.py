@@ -236,11 +236,13 @@ class _VectornetEncoder(nn.Module):
         lane, lane_num, max_lane = data[0][0], data[1][0], data[2]
         max_lane = int(max_lane.reshape(-1)[0]) if torch.is_tensor(max_lane) else int(max_lane)
         b = lane.shape[0]
-        tok = self.lane_subgraph(self.lane_to_vector(lane))
+        # the reference casts to float32; following the weights' dtype keeps that for fp32 models and
+        # lets the same code run as an fp64 ground truth in the gradient-conditioning tests
+        tok = self.lane_subgraph(self.lane_to_vector(lane).to(self.L2L.to_qkv.weight.dtype))
         counts = lane_num.reshape(b).to(torch.int64)
         mask = (torch.arange(max_lane, device=lane.device)[None, :] < counts[:, None]).float()[:, None, :]
         tok = self.L2L(tok, mask)
-        pos = self.pos_emb(torch.zeros(b, tok.shape[1], 2, device=lane.device))
+        pos = self.pos_emb(torch.zeros(b, tok.shape[1], 2, device=lane.device, dtype=tok.dtype))
         fused = self.agent_fusion(torch.cat([tok, pos], dim=-1))
         return self.generator(fused[:, 0, :]).view(b, 64, 64, 64)
 

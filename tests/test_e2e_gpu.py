@@ -1,0 +1,169 @@
+"""End-to-end parity of the HIP MMFN against the CPU oracle on identical weights and batches."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(variant="vec", B=2, lanes=None, dropout=0.0):
+    lanes = (9 if variant != "img" else 4) if lanes is None else lanes  # as oracle/make_golden.py
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd import model as M
+    from oracle import fixtures, harness
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    oracle = harness.build_oracle(variant, dropout=dropout)
+    cfg = GlobalConfig(embd_pdrop=dropout, attn_pdrop=dropout, resid_pdrop=dropout)
+    cls = {"vec": M.MMFN, "img": M.MMFNImg}[variant]
+    net = cls(cfg, DEV)
+    net.load_state_dict(oracle.state_dict(), strict=True)
+    batch = fixtures.synthetic_batch(B, variant, seed=42, lanes=lanes)
+    args = harness.forward_args(batch, variant)
+    return oracle, net, batch, args
+
+
+def _dev_args(args):
+    to = lambda t: t.to(DEV)
+    img, lid, maps, vm, radar, adj, tp, vel = args
+    vmd = [[to(vm[0][0])], [to(vm[1][0])], vm[2]]
+    return ([to(img[0])], [to(lid[0])], [to(maps[0])], vmd, None, None, to(tp), to(vel))
+
+
+@pytest.mark.parametrize("variant", ["vec", "img"])
+def test_eval_forward_matches_oracle(variant):
+    from oracle import harness
+    oracle, net, batch, args = _setup(variant)
+    harness.calibrate_bn(oracle, args)
+    net.load_state_dict(oracle.state_dict(), strict=True)  # calibrated running stats
+    net.eval()
+    with torch.no_grad():
+        ref = oracle(*args)
+        got = net(*_dev_args(args)).cpu()
+    err = (got - ref).abs().max().item()
+    assert err <= 1e-4, "waypoint max abs err %g" % err
+
+
+def test_golden_eval_waypoints(golden_dir):
+    """Same check against the committed vectors produced by the reference itself."""
+    from oracle import harness
+    oracle, net, batch, args = _setup("vec")
+    g = np.load(os.path.join(golden_dir, "mmfn_vec_b2.npz"))
+    harness.calibrate_bn(oracle, args)
+    net.load_state_dict(oracle.state_dict(), strict=True)
+    net.eval()
+    with torch.no_grad():
+        got = net(*_dev_args(args)).cpu().numpy()
+    assert np.abs(got - g["eval_pred_wp"]).max() <= 1e-4
+    # agent-style call: batch 1, vectormap lane count passed as tensors (mmfn_vectornet.py:287-297)
+    one = [[batch["lane"][:1][None].to(DEV)], [batch["lane_num"][:1].int().view(1, 1).to(DEV)],
+           batch["lane_num"][:1].int().view(1, 1).to(DEV)]
+    with torch.no_grad():
+        got1 = net([args[0][0][:1].to(DEV)], [args[1][0][:1].to(DEV)], None, one, None, None,
+                   batch["target_point"][:1].to(DEV), batch["velocity"][:1].to(DEV)).cpu().numpy()
+    assert np.abs(got1 - g["eval_pred_wp_b1_agent"]).max() <= 1e-4
+
+
+def _to64(a):
+    if torch.is_tensor(a):
+        return a.double() if a.is_floating_point() else a
+    if isinstance(a, (list, tuple)):
+        return type(a)(_to64(x) for x in a)
+    return a
+
+
+@pytest.mark.parametrize("variant", ["vec", "img"])
+def test_train_step_matches_oracle(variant, golden_dir):
+    """loss, every parameter gradient, BN running stats and the AdamW update of one step.
+
+    Gradients: with batch 2 the backward through 85 train-mode BatchNorms is ill-conditioned — the
+    fp32 CPU oracle itself deviates from an fp64 evaluation of the same graph by up to ~30 % on
+    some tensors.  So the HIP gradients are judged against the fp64 oracle, with the fp32 oracle's
+    own error on the same tensor as the yardstick."""
+    import copy
+    from oracle import harness
+    oracle, net, batch, args = _setup(variant)
+    o64 = copy.deepcopy(oracle).double()
+    _, loss64, g64 = harness.train_step(o64, _to64(args), batch["gt_wp"].double())
+    pred_ref, loss_ref, grads_ref = harness.train_step(oracle, args, batch["gt_wp"])
+    net.train()
+    for p in net.parameters():
+        p.grad = None
+    pred = net(*_dev_args(args))
+    loss = torch.nn.functional.l1_loss(pred, batch["gt_wp"].to(DEV), reduction="none").mean()
+    loss.backward()
+    assert (pred.detach().cpu() - pred_ref).abs().max().item() <= 1e-4
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4, (loss.item(), loss_ref.item())
+    assert abs(loss.item() - loss64.item()) <= 2e-5, (loss.item(), loss64.item())
+    g = np.load(os.path.join(golden_dir, "mmfn_%s_b2.npz" % variant))
+    assert abs(loss.item() - float(g["train_loss"])) <= 1e-4
+    gmax = max(t.norm().item() for t in g64.values() if t is not None)
+    bad, ratios = [], []
+    for name, p in net.named_parameters():
+        t = g64[name]
+        if t is None:
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None, name
+        n = t.norm().item()
+        e_gpu = (p.grad.detach().cpu().double() - t).norm().item()
+        e_cpu = (grads_ref[name].double() - t).norm().item()
+        if n > 1e-6 * gmax:
+            ratios.append(e_gpu / max(e_cpu, 1e-12 * gmax))
+        if e_gpu > 12.0 * e_cpu + 2e-4 * n + 1e-8 * gmax:
+            bad.append((name, e_gpu, e_cpu, n))
+    assert not bad, "gradient error (name, |gpu-f64|, |cpu32-f64|, |f64|): %s" % bad[:8]
+    ratios.sort()
+    assert ratios[len(ratios) // 2] <= 2.5, "median HIP/CPU-fp32 gradient error ratio %g" % ratios[len(ratios) // 2]
+    assert ratios[int(len(ratios) * 0.95)] <= 6.0, "95th percentile gradient error ratio %g" % ratios[int(len(ratios) * 0.95)]
+    # optimizer: torch AdamW on the views == what the reference loop does
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4)
+    opt.step()
+    ref_sd = oracle.state_dict()
+    got_sd = net.state_dict()
+    for k, v in ref_sd.items():
+        if v.dtype != torch.float32:
+            assert int(got_sd[k].item()) == int(v.item()), k
+            continue
+        d = (got_sd[k].cpu() - v).abs().max().item()
+        # one Adam step moves every weight by <= lr (sign-like update): noise-level gradients may flip
+        tol = 1e-4 * max(1.0, v.abs().max().item()) if "running" in k else 2.1e-4
+        assert d <= tol, (k, d)
+
+
+def test_fused_train_step_equals_autograd_path():
+    """engine.train_step (fused loss + flat AdamW) == autograd bridge + torch AdamW."""
+    oracle, net_a, batch, args = _setup("vec")
+    _, net_b, _, _ = _setup("vec")
+    dargs = _dev_args(args)
+    net_a.train()
+    pred = net_a(*dargs)
+    loss_a = torch.nn.functional.l1_loss(pred, batch["gt_wp"].to(DEV), reduction="none").mean()
+    loss_a.backward()
+    torch.optim.AdamW(net_a.parameters(), lr=1e-4).step()
+    net_b.train()
+    inp = net_b._pack(*dargs)
+    loss_b = net_b.train_step(inp, batch["gt_wp"].to(DEV))
+    assert abs(loss_a.item() - loss_b.item()) <= 1e-6
+    sa, sb = net_a.state_dict(), net_b.state_dict()
+    for k in sa:
+        if sa[k].dtype == torch.float32:
+            assert (sa[k] - sb[k]).abs().max().item() <= 1e-6, k
+
+
+def test_raw_sensor_ingest_path_equals_tensor_path():
+    """u8 camera frames + XYZI points through the GPU ingest/splat kernels == preprocessed tensors."""
+    oracle, net, batch, args = _setup("vec")
+    net.eval()
+    dargs = _dev_args(args)
+    with torch.no_grad():
+        ref = net(*dargs)
+        inp = net._pack(*dargs)
+        raw = dict(inp)
+        del raw["image"], raw["lidar"]
+        raw["rgb_u8"] = batch["rgb_u8"].to(DEV)
+        raw["lidar_pts"] = batch["lidar_pts"].to(DEV)
+        pred, _ = net._engine_for().forward(raw, False, None)
+    assert torch.equal(pred, ref)

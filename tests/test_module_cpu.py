@@ -1,0 +1,114 @@
+"""Host-side contract of the product module (no GPU): checkpoint layout, flat HBM layout, ABI."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from mmfn_amd.config import GlobalConfig
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def vec_model():
+    from mmfn_amd.model import MMFN
+    torch.manual_seed(0)
+    return MMFN(GlobalConfig(), "cpu")
+
+
+def test_state_dict_matches_reference_layout(golden_dir, vec_model):
+    g = np.load(os.path.join(golden_dir, "mmfn_vec_b2.npz"))
+    sd = vec_model.state_dict()
+    assert list(sd.keys()) == list(g["keys"])
+    assert [",".join(map(str, v.shape)) for v in sd.values()] == list(g["shapes"])
+    assert [k for k, _ in vec_model.named_parameters()] == list(g["param_names"])
+
+
+@pytest.mark.parametrize("variant,cls", [("img", "MMFNImg"), ("rad", "MMFNRad")])
+def test_other_variants_layout(golden_dir, variant, cls):
+    import mmfn_amd.model as M
+    m = getattr(M, cls)(GlobalConfig(), "cpu")
+    g = np.load(os.path.join(golden_dir, "mmfn_%s_b2.npz" % variant))
+    assert list(m.state_dict().keys()) == list(g["keys"])
+    assert [",".join(map(str, v.shape)) for v in m.state_dict().values()] == list(g["shapes"])
+
+
+def test_checkpoint_roundtrip_with_oracle(vec_model):
+    """A reference-layout checkpoint loads strictly; conv weights land in [Cout,KH,KW,Cin] storage."""
+    from oracle import harness
+    oracle = harness.build_oracle("vec")
+    missing = vec_model.load_state_dict(oracle.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    sd, ref = vec_model.state_dict(), oracle.state_dict()
+    for k in ref:
+        assert torch.equal(sd[k], ref[k]), k
+    L = vec_model._layout
+    name = "encoder.image_encoder.features.layer2.0.conv1.weight"
+    w = ref[name]
+    assert torch.equal(L.w(name), w.permute(0, 2, 3, 1))
+    assert L.w(name).is_contiguous() and tuple(sd[name].shape) == tuple(w.shape)
+    # k/q/v of one block are adjacent: one [3C, C] GEMM operand
+    base = "encoder.transformer3.blocks.5.attn."
+    packed, _ = L.packed(base + "key.weight", 3 * 256, 256)
+    assert torch.equal(packed, torch.cat([ref[base + "key.weight"], ref[base + "query.weight"], ref[base + "value.weight"]]))
+    pb, _ = L.packed(base + "key.bias", 3 * 256)
+    assert torch.equal(pb, torch.cat([ref[base + "key.bias"], ref[base + "query.bias"], ref[base + "value.bias"]]))
+    # the 21 never-trained tensors sit behind the optimizer range
+    unused = [n for n in L.names if n in L.unused]
+    assert len(unused) == 21 and all(L.offsets[n][0] >= L.tail for n in unused)
+    assert all(L.offsets[n][0] + L.offsets[n][1] <= L.tail for n in L.names if n not in L.unused)
+    # torch.save / torch.load round trip of the state_dict (what Engine.save does, phase2:207-211)
+    import io
+    buf = io.BytesIO()
+    torch.save(vec_model.state_dict(), buf)
+    buf.seek(0)
+    back = torch.load(buf)
+    for k in ref:
+        assert torch.equal(back[k], ref[k]), k
+
+
+def test_entry_points_resolve():
+    """load_entry_point("mmfn_utils.models.model_vec:MMFN") (run_steps/utils.py:68-72)."""
+    from importlib import import_module
+    for mod, variant in (("model_vec", "vec"), ("model_img", "img"), ("model_rad", "rad")):
+        cls = getattr(import_module("mmfn_utils.models." + mod), "MMFN")
+        assert cls.variant == variant
+    from mmfn_utils.datasets.config import GlobalConfig as G2
+    assert G2 is GlobalConfig
+
+
+def test_forward_on_cpu_fails_loudly(vec_model):
+    from mmfn_amd._lib import MMFNLibraryError
+    x = torch.zeros(1, 3, 256, 256)
+    vm = [[torch.zeros(1, 2, 10, 5)], [torch.tensor([2.0])], 2]
+    with pytest.raises(MMFNLibraryError):
+        vec_model([x], [torch.zeros(1, 2, 256, 256)], None, vm, None, None, torch.zeros(1, 2), torch.zeros(1))
+
+
+def test_control_pid_matches_reference(golden_dir, vec_model):
+    from mmfn_amd.model import PIDController
+    g = np.load(os.path.join(golden_dir, "pid.npz"))
+    cfg = vec_model.config
+    vec_model.turn_controller = PIDController(cfg.turn_KP, cfg.turn_KI, cfg.turn_KD, cfg.turn_n)
+    vec_model.speed_controller = PIDController(cfg.speed_KP, cfg.speed_KI, cfg.speed_KD, cfg.speed_n)
+    for wp, v, ref in zip(g["wps"], g["vels"], g["outs"]):
+        s, t, b, meta = vec_model.control_pid(torch.from_numpy(wp.copy()), torch.from_numpy(v.copy()))
+        got = [float(s), float(t), float(b), meta["angle"], meta["desired_speed"], meta["delta"]]
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from mmfn_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "mmfn_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(mmfn_\w+)\s*\(", hdr)))
+    assert len(declared) >= 40
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert [d for d in declared if d not in exported] == []
+    handle = _lib.lib()
+    assert handle.mmfn_abi_version() == 1
+    assert set(_lib._SIGNATURES) == set(declared)
