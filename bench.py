@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""MMFN training-step benchmark on MI355X (BASELINE.json metric: train samples/sec).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL gradient all-reduce)
+
+Workload (BASELINE.json configs[1]): full MMFN "vec" variant, fp32, batch
+32 per GPU, synthetic sensor data resident in HBM (u8 300x400x3 camera frames, 16384-point
+XYZI LiDAR sweeps, 64x10x5 lane polylines), random-init weights.  One step = on-GPU ingest
+(crop/normalise, BEV splat) + forward + L1 loss + backward + AdamW — nothing is skipped.
+
+Prints ONE JSON line with the contract fields plus
+  roofline      the fp32-MFMA GEMM/implicit-conv kernel family (99 % of the FLOPs): algorithmic
+                FLOPs of its launches / their summed duration, timed with HIP events on the
+                launch stream in extra instrumented steps after the timed region,
+  cpu_baseline  the CPU oracle (oracle/, a plain-PyTorch restatement pinned to the reference)
+                timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+ALGO_GFLOP_PER_SAMPLE = {"vec": 106.6, "img": 112.4}  # SURVEY.md section 8d (train step, matmul/conv)
+
+
+def synth_inputs(B, device, seed, lanes=64, n_lidar=16384):
+    g = torch.Generator().manual_seed(seed)
+    rgb = torch.randint(0, 256, (B, 300, 400, 3), generator=g, dtype=torch.uint8)
+    pts = torch.empty(B, n_lidar, 4)
+    pts[..., 0:2] = torch.rand(B, n_lidar, 2, generator=g) * 40.0 - 20.0
+    pts[..., 2] = torch.rand(B, n_lidar, generator=g) * 4.0 - 3.0
+    pts[..., 3] = torch.rand(B, n_lidar, generator=g)
+    pts[:, n_lidar - n_lidar // 16:, 0] = 1e6
+    lane = torch.zeros(B, lanes, 10, 5)
+    lane[..., 0:2] = torch.randn(B, lanes, 10, 2, generator=g) * 8.0
+    lane[..., 2:5] = torch.randint(0, 2, (B, lanes, 10, 3), generator=g).float()
+    lane_num = torch.randint(1, lanes + 1, (B,), generator=g)
+    lane_num[0] = lanes
+    for i in range(B):
+        lane[i, int(lane_num[i]):] = 0.0
+    inp = {
+        "rgb_u8": rgb, "lidar_pts": pts, "lane": lane, "lane_num": lane_num.to(torch.int32),
+        "target_point": torch.randn(B, 2, generator=g) * 10.0, "velocity": torch.rand(B, generator=g) * 8.0,
+    }
+    gt = torch.randn(B, 4, 2, generator=g) * 5.0
+    return {k: v.to(device).contiguous() for k, v in inp.items()}, gt.to(device)
+
+
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box
+    reports 256 logical CPUs but grants a 16-CPU quota; oversubscribing it stalls oneDNN for minutes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(batch=8, steps=3, warmup=1, budget_s=40.0):
+    """The oracle's train step (fwd + L1 + bwd + AdamW, fp32) on the host cores."""
+    from oracle import fixtures, harness
+    threads = usable_cores()
+    torch.set_num_threads(threads)
+    model = harness.build_oracle("vec", dropout=0.1)
+    b = fixtures.synthetic_batch(batch, "vec", seed=42, lanes=64)
+    args = harness.forward_args(b, "vec")
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    model.train()
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        loss = harness.l1_waypoint_loss(model(*args), b["gt_wp"])
+        loss.backward()
+        opt.step()
+
+    for _ in range(warmup):
+        step()
+    t0 = time.time()
+    done = 0
+    for _ in range(steps):
+        step()
+        done += 1
+        if time.time() - t0 > budget_s:
+            break
+    steps = done
+    dt = (time.time() - t0) / steps
+    return {"value": round(batch / dt, 3), "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": "%d train steps of the CPU oracle at batch %d (vec, fp32, %d torch threads)" % (steps, batch, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--variant", default="vec")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps for the roofline block")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mmfn_amd import ops
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd.model import MMFN, MMFNImg
+    from mmfn_amd.parallel import DataParallel
+
+    torch.manual_seed(42)  # init_torch(): run_steps/utils.py:77-84
+    net = {"vec": MMFN, "img": MMFNImg}[args.variant](GlobalConfig(), dev)
+    net.train()
+    B = args.batch
+    inp, gt = synth_inputs(B, dev, seed=42 + rank)
+    dp = DataParallel(net, dist) if world > 1 else None
+    if dp is not None:
+        dp.broadcast_parameters()
+    eng = net._engine_for()
+
+    def step():
+        return eng.train_step(inp, gt, lr=1e-4, dp=dp)
+
+    # two eager steps size every buffer, then (optionally) capture one step into a hipGraph
+    step(); step()
+    torch.cuda.synchronize()
+    runner = step
+    graph = None
+    if not args.no_graph and world == 1:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss_buf = step()
+        runner = graph.replay
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+    loss_val = float(eng._bufs_for(B).get("head.loss", (1,)).item())
+
+    result = {
+        "metric": "train samples/sec (RGB+LiDAR+vec-map fusion)", "value": round(value, 2), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "full MMFN %s (ResNet34 img + ResNet18 LiDAR-BEV + VectorNet -> 4 GPT fusion -> GRU), "
+                               "train step fwd+L1+bwd+AdamW, batch %d/GPU, 400x300x3 u8 RGB + 16384-pt LiDAR + 64x10x5 lanes"
+                               % (args.variant, B),
+                   "global_batch": B * world, "parallelism": "dp%d" % world, "hipgraph": graph is not None},
+        "loss": round(loss_val, 6),
+    }
+    if rank == 0:
+        # ---- roofline of the dominant kernel family (fp32 MFMA GEMM / implicit conv)
+        prof = ops.GemmProfiler()
+        ops.set_gemm_profiler(prof)
+        for _ in range(max(1, args.profile_steps)):
+            eng.train_step(inp, gt, lr=1e-4, dp=None)
+        torch.cuda.synchronize()
+        ops.set_gemm_profiler(None)
+        n_launch, flops, ms = prof.summary()
+        if os.environ.get("MMFN_BENCH_BREAKDOWN"):
+            rows = sorted(prof.by_tag().items(), key=lambda kv: -kv[1][2])
+            for tag, (n, fl, t) in rows[:60]:
+                sys.stderr.write("%-46s n=%3d  %8.3f ms  %7.2f TF/s\n" % (tag, n, t, fl / (t * 1e-3) / 1e12 if t > 0 else 0))
+        steps_p = max(1, args.profile_steps)
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        result["roofline"] = {
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32 GEMM / implicit-GEMM conv fwd+dgrad+wgrad)",
+            "launches_per_step": n_launch // steps_p,
+            "algorithmic_gflop_per_step": round(flops / steps_p / 1e9, 1),
+            "kernel_ms_per_step": round(ms / steps_p, 3),
+            "whole_step_algorithmic_tflops": round(ALGO_GFLOP_PER_SAMPLE.get(args.variant, 0) * B / ms_per_step, 2),
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -629,8 +629,10 @@ class Engine(object):
         pred, loss = self.head.fwd(ctx, fused, inp["target_point"], gt)
         return pred, loss
 
-    def backward(self, dpred=None, gscale=None):
-        """Backward of the last training forward.  dpred None => gradient of the fused L1 loss."""
+    def backward(self, dpred=None, gscale=None, on_stage=None):
+        """Backward of the last training forward.  dpred None => gradient of the fused L1 loss.
+        on_stage(i) is called as soon as every gradient of backward stage i (params.FlatLayout.stage_of)
+        has been written, so a data-parallel wrapper can start reducing that bucket."""
         ctx, B = self._last
         bufs = ctx.bufs
         g_fused = self.head.bwd(ctx, dpred, gscale)
@@ -647,6 +649,8 @@ class Engine(object):
             dF = [ops.pool_bcast_add(g, gin, bufs.get("dF%d.%d" % (s, m), g.shape), m) for m, g in enumerate(G)]
             if s > 0:
                 G = [t.layer_bwd(ctx, s + 1, d) for t, d in zip(trunks, dF)]
+                if on_stage is not None:
+                    on_stage(3 - s)
         g_img = self.img.layer_bwd(ctx, 1, dF[0])
         self.img.stem_bwd(ctx, g_img)
         g_lid = self.lid.layer_bwd(ctx, 1, dF[1])
@@ -656,6 +660,8 @@ class Engine(object):
             self.map.stem_bwd(ctx, g_map)
         else:
             self.vec.bwd(ctx, dF[2])
+        if on_stage is not None:
+            on_stage(3)
 
     def optimizer_step(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
         L = self.layout
@@ -663,13 +669,17 @@ class Engine(object):
         ops.adamw(L.params, L.grads, L.exp_avg, L.exp_avg_sq, self.step_count, lr, betas[0], betas[1], eps, weight_decay,
                   grad_scale, n=L.tail)
 
-    def train_step(self, inp, gt, lr=1e-4, grad_hook=None):
+    def train_step(self, inp, gt, lr=1e-4, dp=None):
         """zero-grad (implicit: every gradient is overwritten) + forward + L1 + backward + AdamW
-        (phase2_train_net.py:60-110).  Returns the device-resident loss scalar."""
+        (phase2_train_net.py:60-110).  `dp` (mmfn_amd.parallel.DataParallel) reduces the gradient
+        buckets across ranks while the backward is still running.  Returns the device loss scalar."""
         ops.rng_advance(self.rng_state)
         _, loss = self.forward(inp, True, gt)
-        self.backward()
-        if grad_hook is not None:
-            grad_hook(self.layout.grads[:self.layout.tail])
-        self.optimizer_step(lr=lr)
+        if dp is None:
+            self.backward()
+            self.optimizer_step(lr=lr)
+        else:
+            self.backward(on_stage=dp.on_stage)
+            dp.finish()
+            self.optimizer_step(lr=lr, grad_scale=1.0 / dp.world)
         return loss

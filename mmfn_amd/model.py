@@ -136,9 +136,9 @@ class MMFN(nn.Module):
         return pred.clone()
 
     # ------------------------------------------------------------------ fused fast path
-    def train_step(self, inp, gt_wp, lr=1e-4, grad_hook=None):
+    def train_step(self, inp, gt_wp, lr=1e-4, dp=None):
         """One full training step on device-resident inputs (see engine.Engine.train_step)."""
-        return self._engine_for().train_step(inp, gt_wp, lr=lr, grad_hook=grad_hook)
+        return self._engine_for().train_step(inp, gt_wp, lr=lr, dp=dp)
 
     # ------------------------------------------------------------------ PID (model_vec.py:684-726)
     def control_pid(self, waypoints, velocity):

@@ -16,6 +16,35 @@ from ._lib import (A_COLMAJOR, A_DGRAD, A_IM2COL, A_ROWMAJOR, B_DGRADW, B_IM2COL
 _workspace = {}
 
 
+class GemmProfiler(object):
+    """Brackets every GEMM/conv launch with HIP events on the launch stream and tallies its
+    ALGORITHMIC FLOPs (true conv/matmul FLOPs, not the zero-inflated implicit-GEMM count)."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
+        return len(self.records), float(sum(f for _, _, f, _ in self.records)), ms
+
+    def by_tag(self):
+        torch.cuda.synchronize()
+        out = {}
+        for s, e, f, tag in self.records:
+            n, fl, ms = out.get(tag, (0, 0.0, 0.0))
+            out[tag] = (n + 1, fl + f, ms + s.elapsed_time(e))
+        return out
+
+
+_profiler = None
+
+
+def set_gemm_profiler(p):
+    global _profiler
+    _profiler = p
+
+
 def workspace(nbytes, device):
     """Grow-only scratch buffer (split-K slabs); never freed so captured graphs stay valid."""
     key = str(device)
@@ -69,7 +98,25 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=N
     need = L.mmfn_gemm_workspace_bytes(ctypes.byref(d))
     if need > 0:
         d.workspace = ptr(workspace(need, C.device))
+    if _profiler is None:
+        check(L.mmfn_gemm_f32(ctypes.byref(d), stream()), "mmfn_gemm_f32")
+        return C
+    if a_mode == A_DGRAD:  # true transposed-conv FLOPs: output pixels x Cin x taps x Cout
+        H, W, Cin, OH, OW, Cout, KH, KW, st, pd = conv
+        flops = 2.0 * (M // (H * W)) * OH * OW * Cin * KH * KW * Cout
+        tag = "dgrad %dx%d c%d->%d k%d s%d" % (H, W, Cin, Cout, KH, st)
+    else:
+        flops = 2.0 * M * N * K
+        if conv is not None:
+            H, W, Cin, OH, OW, Cout, KH, KW, st, pd = conv
+            tag = "%s %dx%d c%d->%d k%d s%d" % ("conv" if a_mode == A_IM2COL else "wgrad", H, W, Cin, Cout, KH, st)
+        else:
+            tag = "gemm a%d b%d %dx%dx%d" % (a_mode, b_mode, M, N, K)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(L.mmfn_gemm_f32(ctypes.byref(d), stream()), "mmfn_gemm_f32")
+    e1.record()
+    _profiler.records.append((e0, e1, flops, tag))
     return C
 
 

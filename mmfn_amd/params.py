@@ -190,16 +190,37 @@ class FlatLayout(object):
         if "tail" not in self.__dict__:
             self.tail = off
         self.total = off
+        # [begin, end) of each backward stage inside the trained range
+        self.stage_ranges = []
+        for st in range(4):
+            offs = [self.offsets[n] for n, _ in order if n not in unused and self.stage_of(n) == st]
+            if offs:
+                self.stage_ranges.append((min(o for o, _ in offs), max((o + (k + 3) // 4 * 4) for o, k in offs)))
+            else:
+                self.stage_ranges.append((0, 0))
         self.unused = unused
         self.device = None
         self.params = self.grads = self.exp_avg = self.exp_avg_sq = None
         self.buffers_flat = None
 
     @staticmethod
-    def _storage_order(named, unused):
-        """Storage order != registration order: pack k/q/v of each attention block adjacently
-        (weights, then biases) and push never-trained tensors to the tail."""
-        used = [(n, p) for n, p in named if n not in unused]
+    def stage_of(name):
+        """Backward completion stage of a parameter's gradient (0 finishes first): the fusion scale
+        it belongs to, deepest first.  Gradient buckets for the data-parallel all-reduce are the
+        contiguous stage ranges of the flat buffer, so each bucket can be reduced while the
+        shallower stages are still back-propagating."""
+        for s, (gpt, layer) in enumerate((("transformer4", "layer4"), ("transformer3", "layer3"),
+                                           ("transformer2", "layer2"))):
+            if gpt in name or layer in name:
+                return s
+        if name.startswith(("join.", "decoder.", "output.")) or "radar_encoder" in name:
+            return 0
+        return 3
+
+    def _storage_order(self, named, unused):
+        """Storage order != registration order: sort by backward stage, pack k/q/v of each attention
+        block adjacently (weights, then biases) and push never-trained tensors to the tail."""
+        used = sorted([(n, p) for n, p in named if n not in unused], key=lambda np_: self.stage_of(np_[0]))
         tail = [(n, p) for n, p in named if n in unused]
         by_name = dict(used)
         taken = set()
