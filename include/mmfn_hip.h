@@ -83,7 +83,7 @@ typedef struct mmfn_gemm_desc {
   int32_t H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
   int32_t flags;
   int32_t splitk;       /* 0 auto, 1 none, >1 forced number of k slices                   */
-  int32_t tile;         /* 0 auto, 1 = 128x128, 2 = 64x64                                 */
+  int32_t tile;         /* 0 auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128          */
   uint32_t rng_stream;  /* distinguishes dropout sites                                    */
   float drop_p;
 } mmfn_gemm_desc;

@@ -359,6 +359,11 @@ __global__ void splitk_reduce_kernel(const mmfn_gemm_desc d) {
   }
 }
 
+struct TileCand { int id, bm, bn; float eff; int target; };
+// id: 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128.  eff = measured relative MFMA efficiency of the
+// tile shape; target = resident blocks that saturate the chip (256 CUs x blocks/CU that fit).
+const TileCand kTiles[4] = {{1, 128, 128, 1.00f, 512}, {3, 128, 64, 0.93f, 768}, {4, 64, 128, 0.93f, 768}, {2, 64, 64, 0.85f, 1024}};
+
 template <int AM, int BMODE>
 int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
   const int nkt = ceil_div(d.K, BK);
@@ -366,15 +371,17 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
   const int zdim = ceil_div(nkt, kps);
   mmfn_gemm_desc dd = d;
   dd.splitk = zdim;
-  if (tile == 1) {
-    const int tn = ceil_div(d.N, 128);
-    dim3 grid(ceil_div(d.M, 128) * tn, zdim);
-    hipLaunchKernelGGL((gemm_f32_kernel<AM, BMODE, 128, 128>), grid, dim3(NT), 0, s, dd, kps, tn);
-  } else {
-    const int tn = ceil_div(d.N, 64);
-    dim3 grid(ceil_div(d.M, 64) * tn, zdim);
-    hipLaunchKernelGGL((gemm_f32_kernel<AM, BMODE, 64, 64>), grid, dim3(NT), 0, s, dd, kps, tn);
+#define MMFN_LAUNCH_TILE(BM_, BN_)                                                                              \
+  {                                                                                                             \
+    const int tn = ceil_div(d.N, BN_);                                                                          \
+    dim3 grid(ceil_div(d.M, BM_) * tn, zdim);                                                                   \
+    hipLaunchKernelGGL((gemm_f32_kernel<AM, BMODE, BM_, BN_>), grid, dim3(NT), 0, s, dd, kps, tn);              \
   }
+  if (tile == 1) MMFN_LAUNCH_TILE(128, 128)
+  else if (tile == 3) MMFN_LAUNCH_TILE(128, 64)
+  else if (tile == 4) MMFN_LAUNCH_TILE(64, 128)
+  else MMFN_LAUNCH_TILE(64, 64)
+#undef MMFN_LAUNCH_TILE
   MMFN_LAUNCH_CHECK();
   if (zdim > 1) {
     const size_t total = (size_t)d.M * d.N;
@@ -386,25 +393,34 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
 }
 
 void pick_config(const mmfn_gemm_desc& d, int* tile, int* splitk) {
-  int t = d.tile;
-  if (t != 1 && t != 2) {
-    const int64_t b128 = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128);
-    t = (b128 >= 384) ? 1 : 2;
+  const int nkt = ceil_div(d.K, BK);
+  const bool can_split = d.workspace != nullptr && d.splitk != 1;
+  const int sk_max = can_split ? std::max(1, nkt / 8) : 1;
+  int best = -1;
+  float best_cost = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const TileCand& c = kTiles[i];
+    if (d.tile >= 1 && d.tile <= 4 && d.tile != c.id) continue;
+    const int64_t tm = ceil_div(d.M, c.bm), tn = ceil_div(d.N, c.bn);
+    const float waste = (float)(tm * c.bm * tn * c.bn) / ((float)d.M * (float)d.N);
+    const int64_t par = tm * tn * sk_max;
+    const float under = par >= c.target ? 1.0f : (float)c.target / (float)par;
+    // split-K is not free (slab round trip + reduce launch): prefer shapes that fill the chip unsplit
+    const float split_pen = (tm * tn >= c.target / 2) ? 1.0f : 1.05f;
+    const float cost = waste / c.eff * under * split_pen;
+    if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
   }
+  const TileCand& c = kTiles[best];
+  const int64_t blocks = (int64_t)ceil_div(d.M, c.bm) * ceil_div(d.N, c.bn);
   int sk = d.splitk;
-  if (sk < 1) {  // auto: fill the 256 CUs (x2) when the output grid alone cannot
-    const int bs = (t == 1) ? 128 : 64;
-    const int64_t blocks = (int64_t)ceil_div(d.M, bs) * ceil_div(d.N, bs);
-    const int nkt = ceil_div(d.K, BK);
+  if (sk < 1) {
     sk = 1;
-    if (blocks < 256 && nkt >= 16) {
-      sk = (int)std::min<int64_t>((512 + blocks - 1) / blocks, nkt / 8);
-      if (sk < 1) sk = 1;
-      if (sk > 64) sk = 64;
-    }
+    if (blocks < c.target / 2) sk = (int)std::min<int64_t>((c.target + blocks - 1) / blocks, sk_max);
+    if (sk > 256) sk = 256;
   }
-  if (d.workspace == nullptr) sk = 1;
-  *tile = t;
+  if (!can_split) sk = 1;
+  if (sk > nkt) sk = std::max(1, nkt);
+  *tile = c.id;
   *splitk = sk;
 }
 
