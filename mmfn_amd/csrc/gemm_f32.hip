@@ -26,7 +26,11 @@
 
 namespace {
 
-constexpr int BK = 16;
+#ifndef MMFN_GEMM_BK
+#define MMFN_GEMM_BK 16
+#endif
+constexpr int BK = MMFN_GEMM_BK;
+constexpr int KQ = BK / 4;  // float4 slots per staged row
 constexpr int NT = 256;
 
 struct ConvPos {  // decoded position of a GEMM row in conv space
@@ -35,6 +39,11 @@ struct ConvPos {  // decoded position of a GEMM row in conv space
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// LDS image of a k-contiguous operand tile: row r holds BK floats = KQ 16-byte slots, slot q stored at
+// q ^ ((r / (64/BK)) & (KQ-1)).  ds_write_b128 (8-lane groups = 2 rows x 4 slots... ) and the MFMA
+// fragment ds_read_b128 (16-lane groups) are both bank-conflict free with no padding.
+__device__ __forceinline__ int kc_slot(int row, int q) { return q ^ ((row / (64 / BK)) & (KQ - 1)); }
 
 __device__ __forceinline__ void epilogue_store(const mmfn_gemm_desc& d, uint64_t key, int row, int col, float v) {
   const int f = d.flags;
@@ -57,7 +66,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d, co
   constexpr bool B_KC = (BMODE == MMFN_B_NK);
   constexpr int WAVES_M = 2, WAVES_N = 2;
   constexpr int TM = BM / (WAVES_M * 32), TN = BN / (WAVES_N * 32);
-  constexpr int LDK = BK + 4;
+  constexpr int LDK = BK;  // unpadded rows; 16-byte slots are XOR-swizzled by row (see kc_slot)
   constexpr int A_ELEMS = A_KC ? BM * LDK : BK * BM;
   constexpr int B_ELEMS = B_KC ? BN * LDK : BK * BN;
   constexpr int UA = BM * BK / 4 / NT, UB = BN * BK / 4 / NT;
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d, co
   for (int i = 0; i < UA; ++i) {
     apos[i].ok = false; apos[i].b = 0; apos[i].y0 = 0; apos[i].x0 = 0;
     if (AM == MMFN_A_IM2COL || AM == MMFN_A_DGRAD) {
-      const int m = m0 + ((tid + i * NT) >> 2);
+      const int m = m0 + ((tid + i * NT) / KQ);
       if (m < d.M) {
         if (AM == MMFN_A_IM2COL) {
           const int ohw = d.OH * d.OW;
@@ -123,8 +132,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d, co
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const int u = tid + i * NT;
     if (A_KC) {
-      const int m = m0 + (u >> 2);
-      const int k = kt * BK + (u & 3) * 4;
+      const int m = m0 + (u / KQ);
+      const int k = kt * BK + (u % KQ) * 4;
       if (m >= d.M || k >= d.K) return v;
       if (AM == MMFN_A_ROWMAJOR) {
         const float* p = d.A + (size_t)m * d.lda + k;
@@ -191,8 +200,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d, co
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const int u = tid + i * NT;
     if (B_KC) {
-      const int n = n0 + (u >> 2);
-      const int k = kt * BK + (u & 3) * 4;
+      const int n = n0 + (u / KQ);
+      const int k = kt * BK + (u % KQ) * 4;
       if (n >= d.N || k >= d.K) return v;
       const float* p = d.B + (size_t)n * d.ldb + k;
       if (b_vec && k + 3 < d.K) return ld4(p);
@@ -241,12 +250,12 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d, co
 
   auto store_a = [&](float* As, int i, f32x4 v) {
     const int u = tid + i * NT;
-    if (A_KC) *reinterpret_cast<f32x4*>(&As[(u >> 2) * LDK + (u & 3) * 4]) = v;
+    if (A_KC) *reinterpret_cast<f32x4*>(&As[(u / KQ) * LDK + kc_slot(u / KQ, u % KQ) * 4]) = v;
     else *reinterpret_cast<f32x4*>(&As[(u / (BM / 4)) * BM + (u % (BM / 4)) * 4]) = v;
   };
   auto store_b = [&](float* Bs, int i, f32x4 v) {
     const int u = tid + i * NT;
-    if (B_KC) *reinterpret_cast<f32x4*>(&Bs[(u >> 2) * LDK + (u & 3) * 4]) = v;
+    if (B_KC) *reinterpret_cast<f32x4*>(&Bs[(u / KQ) * LDK + kc_slot(u / KQ, u % KQ) * 4]) = v;
     else *reinterpret_cast<f32x4*>(&Bs[(u / (BN / 4)) * BN + (u % (BN / 4)) * 4]) = v;
   };
 
@@ -273,7 +282,11 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d, co
 
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
+#ifdef MMFN_GEMM_ABLATE_LOADS
+    const bool more = false;  // ablation: measure the MFMA + ds_read + barrier skeleton alone
+#else
     const bool more = (kt + 1 < kt_end);
+#endif
     if (more) {
 #pragma unroll
       for (int i = 0; i < UA; ++i) ra[i] = load_a(i, kt + 1);
@@ -289,7 +302,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d, co
       for (int i = 0; i < TM; ++i) {
         const int row = wm * TM * 32 + i * 32 + l31;
         if (A_KC) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(&As[row * LDK + c * 8 + h * 4]);
+          const f32x4 t = *reinterpret_cast<const f32x4*>(&As[row * LDK + kc_slot(row, c * 2 + h) * 4]);
           a[i][0] = t[0]; a[i][1] = t[1]; a[i][2] = t[2]; a[i][3] = t[3];
         } else {
 #pragma unroll
@@ -300,7 +313,252 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d, co
       for (int i = 0; i < TN; ++i) {
         const int col = wn * TN * 32 + i * 32 + l31;
         if (B_KC) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(&Bs[col * LDK + c * 8 + h * 4]);
+          const f32x4 t = *reinterpret_cast<const f32x4*>(&Bs[col * LDK + kc_slot(col, c * 2 + h) * 4]);
+          b[i][0] = t[0]; b[i][1] = t[1]; b[i][2] = t[2]; b[i][3] = t[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) b[i][j] = Bs[(c * 8 + h * 4 + j) * BN + col];
+        }
+      }
+#ifdef MMFN_GEMM_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int q = 0; q < TN; ++q)
+            acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[q][j], acc[i][q], 0, 0, 0);
+#ifdef MMFN_GEMM_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    }
+    if (more) {
+      float* An = smem + (cur ^ 1) * (A_ELEMS + B_ELEMS);
+#pragma unroll
+      for (int i = 0; i < UA; ++i) store_a(An, i, ra[i]);
+#pragma unroll
+      for (int i = 0; i < UB; ++i) store_b(An + A_ELEMS, i, rb[i]);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---------------- epilogue ----------------
+  uint64_t key = 0;
+  if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
+  const bool to_slab = d.splitk > 1;
+  float* slab = to_slab ? d.workspace + (size_t)blockIdx.y * d.M * d.N : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int q = 0; q < TN; ++q) {
+      const int col = n0 + wn * TN * 32 + q * 32 + l31;
+      if (col >= d.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= d.M) continue;
+        if (to_slab) slab[(size_t)row * d.N + col] = acc[i][q][r];
+        else epilogue_store(d, key, row, col, acc[i][q][r]);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Fast path: same tiling and LDS image, but every global access is an unconditional 16-byte load.
+//   * rows/columns beyond M/N are clamped to the last valid row (their products are never stored),
+//   * convolution padding and invalid transposed-conv taps read a 16-byte zero page instead of
+//     branching,
+//   * Cin % BK == 0 (Cout for dgrad) so a k-tile never straddles a filter tap: the (kh, kw, c0) of
+//     the tile is wave-uniform scalar state advanced once per tile — no per-thread division,
+//   * wgrad decodes its pixel rows with shifts (OH*OW and OW are powers of two).
+// Eligibility is checked on the host (fast_ok); everything else runs the generic kernel above.
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int AM, int BMODE, int BM, int BN>
+__global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc d, const int kt_per_split, const int tiles_n,
+                                                           const int log2_ow, const int log2_ohw) {
+  constexpr bool A_KC = (AM != MMFN_A_COLMAJOR);
+  constexpr bool B_KC = (BMODE == MMFN_B_NK);
+  constexpr int WAVES_N = 2;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int LDK = BK;
+  constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;
+  constexpr int UA = BM * BK / 4 / NT, UB = BN * BK / 4 / NT;
+  __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int bid = blockIdx.x;
+  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
+  const int nkt = d.K / BK;
+  const int kt_begin = blockIdx.y * kt_per_split;
+  const int kt_end = min(nkt, kt_begin + kt_per_split);
+  const int KHW = d.KH * d.KW;
+  const float* zero = g_zero_page;
+
+  // ---- A loader state
+  const float* pa[UA];
+  int ay0[UA], ax0[UA];
+#pragma unroll
+  for (int i = 0; i < UA; ++i) {
+    const int u = tid + i * NT;
+    ay0[i] = ax0[i] = 0;
+    if (AM == MMFN_A_ROWMAJOR) {
+      pa[i] = d.A + (size_t)min(m0 + u / KQ, d.M - 1) * d.lda + (u % KQ) * 4;
+    } else if (AM == MMFN_A_COLMAJOR) {
+      pa[i] = d.A + (size_t)(u / (BM / 4)) * d.lda + min(m0 + (u % (BM / 4)) * 4, d.M - 4);
+    } else if (AM == MMFN_A_IM2COL) {
+      const int m = min(m0 + u / KQ, d.M - 1);
+      const int ohw = d.OH * d.OW;
+      const int b = m / ohw, rem = m - b * ohw;
+      const int oh = rem / d.OW, ow = rem - oh * d.OW;
+      ay0[i] = oh * d.stride - d.pad;
+      ax0[i] = ow * d.stride - d.pad;
+      pa[i] = d.A + (size_t)b * d.H * d.W * d.Cin + (u % KQ) * 4;
+    } else {
+      const int m = min(m0 + u / KQ, d.M - 1);
+      const int hw = d.H * d.W;
+      const int b = m / hw, rem = m - b * hw;
+      const int ih = rem / d.W, iw = rem - ih * d.W;
+      ay0[i] = ih + d.pad;
+      ax0[i] = iw + d.pad;
+      pa[i] = d.A + (size_t)b * d.OH * d.OW * d.Cout + (u % KQ) * 4;
+    }
+  }
+  // ---- B loader state
+  const float* pb[UB];
+  int bkh[UB], bkw[UB];
+#pragma unroll
+  for (int i = 0; i < UB; ++i) {
+    const int u = tid + i * NT;
+    bkh[i] = bkw[i] = 0;
+    if (BMODE == MMFN_B_NK) {
+      pb[i] = d.B + (size_t)min(n0 + u / KQ, d.N - 1) * d.ldb + (u % KQ) * 4;
+    } else if (BMODE == MMFN_B_KN) {
+      pb[i] = d.B + (size_t)(u / (BN / 4)) * d.ldb + min(n0 + (u % (BN / 4)) * 4, d.N - 4);
+    } else if (BMODE == MMFN_B_DGRADW) {
+      pb[i] = d.B + (size_t)(u / (BN / 4)) * KHW * d.Cin + min(n0 + (u % (BN / 4)) * 4, d.N - 4);
+    } else {  // B_IM2COL: column (kh,kw,ci) fixed per unit
+      const int n = min(n0 + (u % (BN / 4)) * 4, d.N - 4);
+      const int khw = n / d.Cin;
+      bkh[i] = khw / d.KW;
+      bkw[i] = khw - bkh[i] * d.KW;
+      pb[i] = d.B + (n - khw * d.Cin);
+    }
+  }
+  // ---- wave-uniform tap state of the NEXT tile to load (conv modes)
+  int t_kh = 0, t_kw = 0, t_c0 = 0;
+  {
+    const int chan = (AM == MMFN_A_IM2COL) ? d.Cin : d.Cout;
+    if (AM == MMFN_A_IM2COL || AM == MMFN_A_DGRAD) {
+      const int k0 = kt_begin * BK;
+      const int tap = k0 / chan;
+      t_c0 = k0 - tap * chan;
+      t_kh = tap / d.KW;
+      t_kw = tap - t_kh * d.KW;
+    }
+  }
+  auto advance_tap = [&]() {
+    const int chan = (AM == MMFN_A_IM2COL) ? d.Cin : d.Cout;
+    t_c0 += BK;
+    if (t_c0 == chan) { t_c0 = 0; if (++t_kw == d.KW) { t_kw = 0; ++t_kh; } }
+  };
+
+  auto load_a = [&](int i, int kt) -> f32x4 {
+    if (AM == MMFN_A_ROWMAJOR) return ld4(pa[i] + (size_t)kt * BK);
+    if (AM == MMFN_A_COLMAJOR) return ld4(pa[i] + (size_t)kt * BK * d.lda);
+    if (AM == MMFN_A_IM2COL) {
+      const int ih = ay0[i] + t_kh, iw = ax0[i] + t_kw;
+      const bool ok = (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+      return ld4(ok ? pa[i] + ((size_t)ih * d.W + iw) * d.Cin + t_c0 : zero);
+    }
+    int oh = ay0[i] - t_kh, ow = ax0[i] - t_kw;
+    bool ok = oh >= 0 && ow >= 0;
+    if (d.stride == 2) { ok = ok && !((oh | ow) & 1); oh >>= 1; ow >>= 1; }
+    else if (d.stride != 1) { ok = ok && (oh % d.stride == 0) && (ow % d.stride == 0); oh /= d.stride; ow /= d.stride; }
+    ok = ok && oh < d.OH && ow < d.OW;
+    return ld4(ok ? pa[i] + ((size_t)oh * d.OW + ow) * d.Cout + t_c0 : zero);
+  };
+  auto load_b = [&](int i, int kt) -> f32x4 {
+    if (BMODE == MMFN_B_NK) return ld4(pb[i] + (size_t)kt * BK);
+    if (BMODE == MMFN_B_KN) return ld4(pb[i] + (size_t)kt * BK * d.ldb);
+    if (BMODE == MMFN_B_DGRADW) return ld4(pb[i] + ((size_t)t_c0 * KHW + (t_kh * d.KW + t_kw)) * d.Cin);
+    const int kk = kt * BK + (tid + i * NT) / (BN / 4);
+    const int b = kk >> log2_ohw, rem = kk & ((1 << log2_ohw) - 1);
+    const int oh = rem >> log2_ow, ow = rem & ((1 << log2_ow) - 1);
+    const int ih = oh * d.stride - d.pad + bkh[i], iw = ow * d.stride - d.pad + bkw[i];
+    const bool ok = (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+    return ld4(ok ? pb[i] + ((size_t)(b * d.H + ih) * d.W + iw) * d.Cin : zero);
+  };
+  auto store_a = [&](float* As, int i, f32x4 v) {
+    const int u = tid + i * NT;
+    if (A_KC) *reinterpret_cast<f32x4*>(&As[(u / KQ) * LDK + kc_slot(u / KQ, u % KQ) * 4]) = v;
+    else *reinterpret_cast<f32x4*>(&As[(u / (BM / 4)) * BM + (u % (BM / 4)) * 4]) = v;
+  };
+  auto store_b = [&](float* Bs, int i, f32x4 v) {
+    const int u = tid + i * NT;
+    if (B_KC) *reinterpret_cast<f32x4*>(&Bs[(u / KQ) * LDK + kc_slot(u / KQ, u % KQ) * 4]) = v;
+    else *reinterpret_cast<f32x4*>(&Bs[(u / (BN / 4)) * BN + (u % (BN / 4)) * 4]) = v;
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  f32x4 ra[UA], rb[UB];
+  if (kt_begin < kt_end) {
+#pragma unroll
+    for (int i = 0; i < UA; ++i) ra[i] = load_a(i, kt_begin);
+#pragma unroll
+    for (int i = 0; i < UB; ++i) rb[i] = load_b(i, kt_begin);
+    advance_tap();
+#pragma unroll
+    for (int i = 0; i < UA; ++i) store_a(smem, i, ra[i]);
+#pragma unroll
+    for (int i = 0; i < UB; ++i) store_b(smem + A_ELEMS, i, rb[i]);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = (kt + 1 < kt_end);
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < UA; ++i) ra[i] = load_a(i, kt + 1);
+#pragma unroll
+      for (int i = 0; i < UB; ++i) rb[i] = load_b(i, kt + 1);
+      advance_tap();
+    }
+    const float* As = smem + cur * (A_ELEMS + B_ELEMS);
+    const float* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int c = 0; c < BK / 8; ++c) {
+      float a[TM][4], b[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * TM * 32 + i * 32 + l31;
+        if (A_KC) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(&As[row * LDK + kc_slot(row, c * 2 + h) * 4]);
+          a[i][0] = t[0]; a[i][1] = t[1]; a[i][2] = t[2]; a[i][3] = t[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[i][j] = As[(c * 8 + h * 4 + j) * BM + row];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int col = wn * TN * 32 + i * 32 + l31;
+        if (B_KC) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(&Bs[col * LDK + kc_slot(col, c * 2 + h) * 4]);
           b[i][0] = t[0]; b[i][1] = t[1]; b[i][2] = t[2]; b[i][3] = t[3];
         } else {
 #pragma unroll
@@ -326,7 +584,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d, co
     cur ^= 1;
   }
 
-  // ---------------- epilogue ----------------
   uint64_t key = 0;
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
   const bool to_slab = d.splitk > 1;
@@ -364,6 +621,33 @@ struct TileCand { int id, bm, bn; float eff; int target; };
 // tile shape; target = resident blocks that saturate the chip (256 CUs x blocks/CU that fit).
 const TileCand kTiles[4] = {{1, 128, 128, 1.00f, 512}, {3, 128, 64, 0.93f, 768}, {4, 64, 128, 0.93f, 768}, {2, 64, 64, 0.85f, 1024}};
 
+int ilog2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+bool fast_ok(const mmfn_gemm_desc& d) {
+  if (d.K % BK) return false;
+  if ((((uintptr_t)d.A) | ((uintptr_t)d.B)) & 15) return false;
+  switch (d.a_mode) {
+    case MMFN_A_ROWMAJOR: if (d.lda & 3) return false; break;
+    case MMFN_A_COLMAJOR: if ((d.lda & 3) || (d.M & 3) || d.M < 4) return false; break;
+    case MMFN_A_IM2COL: if (d.Cin % BK) return false; break;
+    case MMFN_A_DGRAD: if (d.Cout % BK) return false; break;
+  }
+  switch (d.b_mode) {
+    case MMFN_B_NK: if (d.ldb & 3) return false; break;
+    case MMFN_B_KN: if ((d.ldb & 3) || (d.N & 3) || d.N < 4) return false; break;
+    case MMFN_B_DGRADW: if ((d.Cin & 3) || (d.N & 3) || d.N < 4 || d.Cout % BK) return false; break;
+    case MMFN_B_IM2COL:
+      if ((d.Cin & 3) || (d.N & 3) || d.N < 4 || ilog2_exact(d.OW) < 0 || ilog2_exact(d.OH * d.OW) < 0) return false;
+      break;
+  }
+  return true;
+}
+
 template <int AM, int BMODE>
 int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
   const int nkt = ceil_div(d.K, BK);
@@ -371,6 +655,31 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
   const int zdim = ceil_div(nkt, kps);
   mmfn_gemm_desc dd = d;
   dd.splitk = zdim;
+#ifndef MMFN_GEMM_NO_FAST
+  if (fast_ok(d)) {
+    const int l_ow = (BMODE == MMFN_B_IM2COL) ? ilog2_exact(d.OW) : 0;
+    const int l_ohw = (BMODE == MMFN_B_IM2COL) ? ilog2_exact(d.OH * d.OW) : 0;
+#define MMFN_LAUNCH_FAST(BM_, BN_)                                                                                   \
+  {                                                                                                                  \
+    const int tn = ceil_div(d.N, BN_);                                                                               \
+    dim3 grid(ceil_div(d.M, BM_) * tn, zdim);                                                                        \
+    hipLaunchKernelGGL((gemm_f32_fast_kernel<AM, BMODE, BM_, BN_>), grid, dim3(NT), 0, s, dd, kps, tn, l_ow, l_ohw); \
+  }
+    if (tile == 1) MMFN_LAUNCH_FAST(128, 128)
+    else if (tile == 3) MMFN_LAUNCH_FAST(128, 64)
+    else if (tile == 4) MMFN_LAUNCH_FAST(64, 128)
+    else MMFN_LAUNCH_FAST(64, 64)
+#undef MMFN_LAUNCH_FAST
+    MMFN_LAUNCH_CHECK();
+    if (zdim > 1) {
+      const size_t total = (size_t)d.M * d.N;
+      const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, dd);
+      MMFN_LAUNCH_CHECK();
+    }
+    return 0;
+  }
+#endif
 #define MMFN_LAUNCH_TILE(BM_, BN_)                                                                              \
   {                                                                                                             \
     const int tn = ceil_div(d.N, BN_);                                                                          \

@@ -1,6 +1,6 @@
 """Dev tool: time representative GEMM / conv shapes of the MMFN step (B=32) in isolation."""
 import os, sys, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mmfn_amd import ops
 dev = "cuda:0"
