@@ -604,22 +604,49 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
     }
 }
 
-__global__ void splitk_reduce_kernel(const mmfn_gemm_desc d) {
+// Deterministic split-K combine: slabs [splitk][M][N] -> epilogue(C).  One thread per 4 consecutive
+// columns (16-byte loads), 4 independent partial sums so the slab loads pipeline.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const mmfn_gemm_desc d) {
   const size_t total = (size_t)d.M * d.N;
+  const size_t total4 = total >> 2;
   uint64_t key = 0;
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    float v = 0.0f;
-    for (int z = 0; z < d.splitk; ++z) v += d.workspace[(size_t)z * total + idx];
-    const int row = (int)(idx / d.N), col = (int)(idx - (size_t)row * d.N);
-    epilogue_store(d, key, row, col, v);
+  const bool vec = (d.N & 3) == 0;
+  if (vec) {
+    for (size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (size_t)gridDim.x * blockDim.x) {
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+      const float* p = d.workspace + i4 * 4;
+      int z = 0;
+      for (; z + 3 < d.splitk; z += 4) {
+        const f32x4 a = ld4(p + (size_t)z * total), b = ld4(p + (size_t)(z + 1) * total);
+        const f32x4 c = ld4(p + (size_t)(z + 2) * total), e = ld4(p + (size_t)(z + 3) * total);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s0[q] += a[q]; s1[q] += b[q]; s2[q] += c[q]; s3[q] += e[q]; }
+      }
+      for (; z < d.splitk; ++z) {
+        const f32x4 a = ld4(p + (size_t)z * total);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s0[q] += a[q];
+      }
+      const size_t idx = i4 * 4;
+      const int row = (int)(idx / d.N), col = (int)(idx - (size_t)row * d.N);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) epilogue_store(d, key, row, col + q, (s0[q] + s1[q]) + (s2[q] + s3[q]));
+    }
+  } else {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+      float v = 0.0f;
+      for (int z = 0; z < d.splitk; ++z) v += d.workspace[(size_t)z * total + idx];
+      const int row = (int)(idx / d.N), col = (int)(idx - (size_t)row * d.N);
+      epilogue_store(d, key, row, col, v);
+    }
   }
 }
 
 struct TileCand { int id, bm, bn; float eff; int target; };
 // id: 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128.  eff = measured relative MFMA efficiency of the
 // tile shape; target = resident blocks that saturate the chip (256 CUs x blocks/CU that fit).
-const TileCand kTiles[4] = {{1, 128, 128, 1.00f, 512}, {3, 128, 64, 0.93f, 768}, {4, 64, 128, 0.93f, 768}, {2, 64, 64, 0.85f, 1024}};
+const TileCand kTiles[4] = {{1, 128, 128, 1.00f, 512}, {3, 128, 64, 1.00f, 512}, {4, 64, 128, 1.00f, 512}, {2, 64, 64, 0.98f, 768}};
 
 int ilog2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;
@@ -673,7 +700,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
     MMFN_LAUNCH_CHECK();
     if (zdim > 1) {
       const size_t total = (size_t)d.M * d.N;
-      const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+      const int blocks = (int)std::min<size_t>((total / 4 + 255) / 256 + 1, 4096);
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, dd);
       MMFN_LAUNCH_CHECK();
     }
@@ -694,7 +721,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
   MMFN_LAUNCH_CHECK();
   if (zdim > 1) {
     const size_t total = (size_t)d.M * d.N;
-    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    const int blocks = (int)std::min<size_t>((total / 4 + 255) / 256 + 1, 4096);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, dd);
     MMFN_LAUNCH_CHECK();
   }
@@ -704,7 +731,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
 void pick_config(const mmfn_gemm_desc& d, int* tile, int* splitk) {
   const int nkt = ceil_div(d.K, BK);
   const bool can_split = d.workspace != nullptr && d.splitk != 1;
-  const int sk_max = can_split ? std::max(1, nkt / 8) : 1;
+  const int sk_max = can_split ? std::min(48, std::max(1, nkt / 8)) : 1;
   int best = -1;
   float best_cost = 0.f;
   for (int i = 0; i < 4; ++i) {
@@ -713,10 +740,11 @@ void pick_config(const mmfn_gemm_desc& d, int* tile, int* splitk) {
     const int64_t tm = ceil_div(d.M, c.bm), tn = ceil_div(d.N, c.bn);
     const float waste = (float)(tm * c.bm * tn * c.bn) / ((float)d.M * (float)d.N);
     const int64_t par = tm * tn * sk_max;
-    const float under = par >= c.target ? 1.0f : (float)c.target / (float)par;
-    // split-K is not free (slab round trip + reduce launch): prefer shapes that fill the chip unsplit
-    const float split_pen = (tm * tn >= c.target / 2) ? 1.0f : 1.05f;
-    const float cost = waste / c.eff * under * split_pen;
+    // enough tiles to saturate the chip -> no penalty; reachable only through split-K -> pay for the
+    // slab round trip + reduce launch; not reachable at all -> proportional under-fill
+    float fill = 1.0f;
+    if (tm * tn < c.target) fill = par >= c.target ? 1.3f : 1.3f * (float)c.target / (float)par;
+    const float cost = waste / c.eff * fill;
     if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
   }
   const TileCand& c = kTiles[best];
@@ -724,8 +752,8 @@ void pick_config(const mmfn_gemm_desc& d, int* tile, int* splitk) {
   int sk = d.splitk;
   if (sk < 1) {
     sk = 1;
-    if (blocks < c.target / 2) sk = (int)std::min<int64_t>((c.target + blocks - 1) / blocks, sk_max);
-    if (sk > 256) sk = 256;
+    if (blocks < c.target) sk = (int)std::min<int64_t>((c.target + blocks - 1) / blocks, sk_max);
+    if (sk > 48) sk = 48;  // slab traffic grows with sk; beyond this the reduce costs more than the fill gains
   }
   if (!can_split) sk = 1;
   if (sk > nkt) sk = std::max(1, nkt);

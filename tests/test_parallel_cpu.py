@@ -1,0 +1,105 @@
+"""Data-parallel wrapper on CPU: 2 processes, gloo backend (the GPU build uses RCCL through the same API)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from mmfn_amd.parallel import DataParallel
+from mmfn_amd.params import FlatLayout
+
+
+class _Tiny(nn.Module):
+    """Parameter names that hit every backward stage + a never-trained tail tensor."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = nn.Module()
+        self.encoder.transformer4 = nn.Linear(8, 8)
+        self.encoder.layer3 = nn.Conv2d(4, 4, 3, bias=False)
+        self.encoder.transformer2 = nn.Linear(6, 3)
+        self.encoder.stem = nn.Linear(5, 7)
+        self.encoder.unused = nn.Linear(3, 3)
+        self.join = nn.Linear(4, 2)
+        self.bn = nn.BatchNorm2d(4)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)  # different init per rank: broadcast must fix it
+    m = _Tiny()
+    object.__setattr__(m, "_layout", FlatLayout(m, ("encoder.unused.weight", "encoder.unused.bias")).materialize("cpu"))
+    L = m._layout
+    dp = DataParallel(m, dist, max_bucket_bytes=64)  # tiny buckets: several chunks per stage
+    dp.broadcast_parameters()
+    ref = [torch.empty_like(L.params) for _ in range(world)]
+    dist.all_gather(ref, L.params)
+    same_params = all(torch.equal(ref[0], r) for r in ref)
+    # buckets tile [0, tail) exactly
+    spans = sorted(c for chunks in dp.buckets for c in chunks)
+    covered = spans[0][0] == 0 and spans[-1][1] == L.tail and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    L.grads.copy_(torch.arange(L.total, dtype=torch.float32) * (rank + 1))
+    tail_before = L.grads[L.tail:].clone()
+    for stage in range(4):
+        dp.on_stage(stage)
+    dp.finish()
+    expect = torch.arange(L.total, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    ok_sum = torch.equal(L.grads[:L.tail], expect[:L.tail])
+    ok_tail = torch.equal(L.grads[L.tail:], tail_before)
+    # p.grad views see the reduced values (reference-style optimizers read p.grad)
+    L.attach_grads()
+    g = m.encoder.layer3.weight.grad
+    off, n = L.offsets["encoder.layer3.weight"]
+    ok_view = torch.equal(g.permute(0, 2, 3, 1).reshape(-1), expect[off:off + n]) and m.encoder.unused.weight.grad is None
+    if rank == 0:
+        out.put((same_params, covered, ok_sum, ok_tail, ok_view, dp.world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    same_params, covered, ok_sum, ok_tail, ok_view, world = res
+    assert world == 2
+    assert same_params, "rank-0 broadcast did not equalise the parameters"
+    assert covered, "gradient buckets must tile the trained range exactly"
+    assert ok_sum, "all-reduce (sum) over the trained range"
+    assert ok_tail, "never-trained tail must be excluded from the reduction"
+    assert ok_view, "p.grad views alias the reduced flat buffer"
+
+
+def test_stage_order_of_real_model():
+    """Flat storage is ordered by backward stage: deepest fusion scale first, stem/VectorNet last."""
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd.model import MMFN
+    m = MMFN(GlobalConfig(), "cpu")
+    L = m._layout
+    r = L.stage_ranges
+    assert r[0][0] == 0 and all(r[i][1] == r[i + 1][0] for i in range(3)) and r[3][1] == L.tail
+    assert L.offsets["encoder.transformer4.blocks.0.mlp.0.weight"][0] < r[0][1]
+    assert r[1][0] <= L.offsets["encoder.image_encoder.features.layer3.0.conv1.weight"][0] < r[1][1]
+    assert r[3][0] <= L.offsets["encoder.vectornet_encoder.generator.3.weight"][0] < r[3][1]
+    sizes = [(e - b) * 4 / 2 ** 20 for b, e in r]
+    assert sizes[0] > sum(sizes[1:])  # the first bucket (scale 4) is the largest -> most overlap

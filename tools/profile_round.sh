@@ -1,0 +1,18 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence for a round (run on the GPU box through gpurun):
+#   1. --kernel-trace --stats of the default bench command,
+#   2. PMC passes (separate runs, no tracing domains besides kernel-trace): MFMA busy / wave cycles,
+#      FETCH_SIZE, WRITE_SIZE for the dominant GEMM kernels.
+# Usage: bash tools/profile_round.sh r01
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python $R/bench.py --no-graph --no-cpu-baseline --steps 5 --warmup 2 --profile-steps 1"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- $BENCH > $OUT/trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT -o pmc_mfma -- $BENCH > $OUT/pmc_mfma.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1
+ls -la $OUT
+python $R/tools/summarize_profile.py $OUT $TAG
