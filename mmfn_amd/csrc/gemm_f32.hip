@@ -377,6 +377,19 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d, co
 // Eligibility is checked on the host (fast_ok); everything else runs the generic kernel above.
 __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
+#ifdef MMFN_GEMM_NO_GLDS
+constexpr bool USE_GLDS = false;  // register-staged fallback (A/B experiment switch)
+#else
+constexpr bool USE_GLDS = true;   // +5-10 % over register staging on every shape measured (tools/gemm_bench.py)
+#endif
+// source-side slot of unit u (k-contiguous operands): the physical LDS slot u % KQ holds logical slot
+// (u % KQ) ^ swizzle(row) when the tile is written lane-linearly by global_load_lds
+#define SRCQ(u) (USE_GLDS ? kc_slot((u) / KQ, (u) % KQ) : (u) % KQ)
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
 template <int AM, int BMODE, int BM, int BN>
 __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc d, const int kt_per_split, const int tiles_n,
                                                            const int log2_ow, const int log2_ohw) {
@@ -409,7 +422,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
     const int u = tid + i * NT;
     ay0[i] = ax0[i] = 0;
     if (AM == MMFN_A_ROWMAJOR) {
-      pa[i] = d.A + (size_t)min(m0 + u / KQ, d.M - 1) * d.lda + (u % KQ) * 4;
+      pa[i] = d.A + (size_t)min(m0 + u / KQ, d.M - 1) * d.lda + SRCQ(u) * 4;
     } else if (AM == MMFN_A_COLMAJOR) {
       pa[i] = d.A + (size_t)(u / (BM / 4)) * d.lda + min(m0 + (u % (BM / 4)) * 4, d.M - 4);
     } else if (AM == MMFN_A_IM2COL) {
@@ -419,7 +432,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
       const int oh = rem / d.OW, ow = rem - oh * d.OW;
       ay0[i] = oh * d.stride - d.pad;
       ax0[i] = ow * d.stride - d.pad;
-      pa[i] = d.A + (size_t)b * d.H * d.W * d.Cin + (u % KQ) * 4;
+      pa[i] = d.A + (size_t)b * d.H * d.W * d.Cin + SRCQ(u) * 4;
     } else {
       const int m = min(m0 + u / KQ, d.M - 1);
       const int hw = d.H * d.W;
@@ -427,7 +440,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
       const int ih = rem / d.W, iw = rem - ih * d.W;
       ay0[i] = ih + d.pad;
       ax0[i] = iw + d.pad;
-      pa[i] = d.A + (size_t)b * d.OH * d.OW * d.Cout + (u % KQ) * 4;
+      pa[i] = d.A + (size_t)b * d.OH * d.OW * d.Cout + SRCQ(u) * 4;
     }
   }
   // ---- B loader state
@@ -438,7 +451,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
     const int u = tid + i * NT;
     bkh[i] = bkw[i] = 0;
     if (BMODE == MMFN_B_NK) {
-      pb[i] = d.B + (size_t)min(n0 + u / KQ, d.N - 1) * d.ldb + (u % KQ) * 4;
+      pb[i] = d.B + (size_t)min(n0 + u / KQ, d.N - 1) * d.ldb + SRCQ(u) * 4;
     } else if (BMODE == MMFN_B_KN) {
       pb[i] = d.B + (size_t)(u / (BN / 4)) * d.ldb + min(n0 + (u % (BN / 4)) * 4, d.N - 4);
     } else if (BMODE == MMFN_B_DGRADW) {
@@ -469,40 +482,42 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
     if (t_c0 == chan) { t_c0 = 0; if (++t_kw == d.KW) { t_kw = 0; ++t_kh; } }
   };
 
-  auto load_a = [&](int i, int kt) -> f32x4 {
-    if (AM == MMFN_A_ROWMAJOR) return ld4(pa[i] + (size_t)kt * BK);
-    if (AM == MMFN_A_COLMAJOR) return ld4(pa[i] + (size_t)kt * BK * d.lda);
+  auto src_a = [&](int i, int kt) -> const float* {
+    if (AM == MMFN_A_ROWMAJOR) return pa[i] + (size_t)kt * BK;
+    if (AM == MMFN_A_COLMAJOR) return pa[i] + (size_t)kt * BK * d.lda;
     if (AM == MMFN_A_IM2COL) {
       const int ih = ay0[i] + t_kh, iw = ax0[i] + t_kw;
       const bool ok = (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
-      return ld4(ok ? pa[i] + ((size_t)ih * d.W + iw) * d.Cin + t_c0 : zero);
+      return ok ? pa[i] + ((size_t)ih * d.W + iw) * d.Cin + t_c0 : zero;
     }
     int oh = ay0[i] - t_kh, ow = ax0[i] - t_kw;
     bool ok = oh >= 0 && ow >= 0;
     if (d.stride == 2) { ok = ok && !((oh | ow) & 1); oh >>= 1; ow >>= 1; }
     else if (d.stride != 1) { ok = ok && (oh % d.stride == 0) && (ow % d.stride == 0); oh /= d.stride; ow /= d.stride; }
     ok = ok && oh < d.OH && ow < d.OW;
-    return ld4(ok ? pa[i] + ((size_t)oh * d.OW + ow) * d.Cout + t_c0 : zero);
+    return ok ? pa[i] + ((size_t)oh * d.OW + ow) * d.Cout + t_c0 : zero;
   };
-  auto load_b = [&](int i, int kt) -> f32x4 {
-    if (BMODE == MMFN_B_NK) return ld4(pb[i] + (size_t)kt * BK);
-    if (BMODE == MMFN_B_KN) return ld4(pb[i] + (size_t)kt * BK * d.ldb);
-    if (BMODE == MMFN_B_DGRADW) return ld4(pb[i] + ((size_t)t_c0 * KHW + (t_kh * d.KW + t_kw)) * d.Cin);
+  auto src_b = [&](int i, int kt) -> const float* {
+    if (BMODE == MMFN_B_NK) return pb[i] + (size_t)kt * BK;
+    if (BMODE == MMFN_B_KN) return pb[i] + (size_t)kt * BK * d.ldb;
+    if (BMODE == MMFN_B_DGRADW) return pb[i] + ((size_t)t_c0 * KHW + (t_kh * d.KW + t_kw)) * d.Cin;
     const int kk = kt * BK + (tid + i * NT) / (BN / 4);
     const int b = kk >> log2_ohw, rem = kk & ((1 << log2_ohw) - 1);
     const int oh = rem >> log2_ow, ow = rem & ((1 << log2_ow) - 1);
     const int ih = oh * d.stride - d.pad + bkh[i], iw = ow * d.stride - d.pad + bkw[i];
     const bool ok = (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
-    return ld4(ok ? pb[i] + ((size_t)(b * d.H + ih) * d.W + iw) * d.Cin : zero);
+    return ok ? pb[i] + ((size_t)(b * d.H + ih) * d.W + iw) * d.Cin : zero;
   };
   auto store_a = [&](float* As, int i, f32x4 v) {
     const int u = tid + i * NT;
-    if (A_KC) *reinterpret_cast<f32x4*>(&As[(u / KQ) * LDK + kc_slot(u / KQ, u % KQ) * 4]) = v;
+    if (USE_GLDS) *reinterpret_cast<f32x4*>(&As[u * 4]) = v;
+    else if (A_KC) *reinterpret_cast<f32x4*>(&As[(u / KQ) * LDK + kc_slot(u / KQ, u % KQ) * 4]) = v;
     else *reinterpret_cast<f32x4*>(&As[(u / (BM / 4)) * BM + (u % (BM / 4)) * 4]) = v;
   };
   auto store_b = [&](float* Bs, int i, f32x4 v) {
     const int u = tid + i * NT;
-    if (B_KC) *reinterpret_cast<f32x4*>(&Bs[(u / KQ) * LDK + kc_slot(u / KQ, u % KQ) * 4]) = v;
+    if (USE_GLDS) *reinterpret_cast<f32x4*>(&Bs[u * 4]) = v;
+    else if (B_KC) *reinterpret_cast<f32x4*>(&Bs[(u / KQ) * LDK + kc_slot(u / KQ, u % KQ) * 4]) = v;
     else *reinterpret_cast<f32x4*>(&Bs[(u / (BN / 4)) * BN + (u % (BN / 4)) * 4]) = v;
   };
 
@@ -515,29 +530,41 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   f32x4 ra[UA], rb[UB];
-  if (kt_begin < kt_end) {
+  // stage(kt, dst): global -> LDS for one k-tile.  With USE_GLDS the 16-byte pieces go straight to LDS
+  // (global_load_lds: wave-uniform LDS base + lane*16, so the image is lane-linear and the slot swizzle
+  // is applied to the SOURCE address); otherwise through registers (issue now, ds_write after the MFMAs).
+  auto stage_issue = [&](int kt, float* dst) {
+    if (USE_GLDS) {
 #pragma unroll
-    for (int i = 0; i < UA; ++i) ra[i] = load_a(i, kt_begin);
+      for (int i = 0; i < UA; ++i) glds16(src_a(i, kt), dst + (i * NT + wave * 64) * 4);
 #pragma unroll
-    for (int i = 0; i < UB; ++i) rb[i] = load_b(i, kt_begin);
+      for (int i = 0; i < UB; ++i) glds16(src_b(i, kt), dst + A_ELEMS + (i * NT + wave * 64) * 4);
+    } else {
+#pragma unroll
+      for (int i = 0; i < UA; ++i) ra[i] = ld4(src_a(i, kt));
+#pragma unroll
+      for (int i = 0; i < UB; ++i) rb[i] = ld4(src_b(i, kt));
+    }
     advance_tap();
+  };
+  auto stage_commit = [&](float* dst) {
+    if (!USE_GLDS) {
 #pragma unroll
-    for (int i = 0; i < UA; ++i) store_a(smem, i, ra[i]);
+      for (int i = 0; i < UA; ++i) store_a(dst, i, ra[i]);
 #pragma unroll
-    for (int i = 0; i < UB; ++i) store_b(smem + A_ELEMS, i, rb[i]);
+      for (int i = 0; i < UB; ++i) store_b(dst + A_ELEMS, i, rb[i]);
+    }
+  };
+  if (kt_begin < kt_end) {
+    stage_issue(kt_begin, smem);
+    stage_commit(smem);
   }
   __syncthreads();
 
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const bool more = (kt + 1 < kt_end);
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < UA; ++i) ra[i] = load_a(i, kt + 1);
-#pragma unroll
-      for (int i = 0; i < UB; ++i) rb[i] = load_b(i, kt + 1);
-      advance_tap();
-    }
+    if (more) stage_issue(kt + 1, smem + (cur ^ 1) * (A_ELEMS + B_ELEMS));
     const float* As = smem + cur * (A_ELEMS + B_ELEMS);
     const float* Bs = As + A_ELEMS;
 #pragma unroll
@@ -573,13 +600,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
           for (int q = 0; q < TN; ++q)
             acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[q][j], acc[i][q], 0, 0, 0);
     }
-    if (more) {
-      float* An = smem + (cur ^ 1) * (A_ELEMS + B_ELEMS);
-#pragma unroll
-      for (int i = 0; i < UA; ++i) store_a(An, i, ra[i]);
-#pragma unroll
-      for (int i = 0; i < UB; ++i) store_b(An + A_ELEMS, i, rb[i]);
-    }
+    if (more) stage_commit(smem + (cur ^ 1) * (A_ELEMS + B_ELEMS));
     __syncthreads();
     cur ^= 1;
   }

@@ -74,14 +74,24 @@ __global__ __launch_bounds__(NT) void col_partial_kernel(const float* __restrict
 
 // Sum `nblk` partial rows for column c: 8 row-lanes per column + LDS tree (the serial per-column
 // loop this replaces took 50-90 us per launch at nblk ~ 400 and dominated the non-GEMM time).
-constexpr int FIN_COLS = 32, FIN_LANES = 8;
+constexpr int FIN_COLS = 8, FIN_LANES = 32;
 template <typename T>
 __device__ __forceinline__ double reduce_partials(const T* __restrict__ partials, int nblk, size_t row_stride, int c, bool valid,
                                                   double (*sh)[FIN_COLS]) {
   const int cl = threadIdx.x % FIN_COLS, rl = threadIdx.x / FIN_COLS;
   double s = 0;
-  if (valid)
-    for (int b = rl; b < nblk; b += FIN_LANES) s += (double)partials[(size_t)b * row_stride + c];
+  if (valid) {
+    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;  // four independent loads in flight (latency-bound otherwise)
+    int b = rl;
+    for (; b + 3 * FIN_LANES < nblk; b += 4 * FIN_LANES) {
+      t0 += (double)partials[(size_t)b * row_stride + c];
+      t1 += (double)partials[(size_t)(b + FIN_LANES) * row_stride + c];
+      t2 += (double)partials[(size_t)(b + 2 * FIN_LANES) * row_stride + c];
+      t3 += (double)partials[(size_t)(b + 3 * FIN_LANES) * row_stride + c];
+    }
+    for (; b < nblk; b += FIN_LANES) t0 += (double)partials[(size_t)b * row_stride + c];
+    s = (t0 + t1) + (t2 + t3);
+  }
   sh[rl][cl] = s;
   __syncthreads();
   double tot = 0;
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
 
 int bn_grid(int64_t M, int C, int64_t* rows_per_block) {
   // aim for ~2 blocks per CU, at least 64 rows each
-  int64_t rpb = std::max<int64_t>(64, ceil_div64(M, 512));
+  int64_t rpb = std::max<int64_t>(64, ceil_div64(M, 256));
   *rows_per_block = rpb;
   return (int)ceil_div64(M, rpb);
 }
@@ -313,9 +323,16 @@ __global__ __launch_bounds__(NT) void colsum_partial_kernel(const float* __restr
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
   for (int c = blockIdx.y * NT + threadIdx.x; c < C; c += gridDim.y * NT) {
-    float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += in[(size_t)r * ld + c];
-    partials[(size_t)blockIdx.x * C + c] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int64_t r = r0;
+    for (; r + 3 < r1; r += 4) {
+      s0 += in[(size_t)r * ld + c];
+      s1 += in[(size_t)(r + 1) * ld + c];
+      s2 += in[(size_t)(r + 2) * ld + c];
+      s3 += in[(size_t)(r + 3) * ld + c];
+    }
+    for (; r < r1; ++r) s0 += in[(size_t)r * ld + c];
+    partials[(size_t)blockIdx.x * C + c] = (s0 + s1) + (s2 + s3);
   }
 }
 
@@ -403,7 +420,7 @@ extern "C" int mmfn_layernorm_bwd_f32(const float* g, const float* x, const floa
                                       float* dbias, int M, int C, int act, void* workspace, void* stream) {
   if (C % 64 || C > 512 || M <= 0 || !workspace) return MMFN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const int rpb = std::max(16, ceil_div(M, 512));
+  const int rpb = std::max(32, ceil_div(M, 256));
   const int nblk = ceil_div(M, rpb);
   float* partials = (float*)workspace;
   hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(nblk), dim3(NT), 0, s, g, x, weight, bias, mean, rstd, dres, dx, partials,
