@@ -752,13 +752,18 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
 void pick_config(const mmfn_gemm_desc& d, int* tile, int* splitk) {
   const int nkt = ceil_div(d.K, BK);
   const bool can_split = d.workspace != nullptr && d.splitk != 1;
-  const int sk_max = can_split ? std::min(48, std::max(1, nkt / 8)) : 1;
+  const int sk_cap_base = 48;  // slab traffic grows with the split factor ...
   int best = -1;
   float best_cost = 0.f;
+  int best_skmax = 1;
   for (int i = 0; i < 4; ++i) {
     const TileCand& c = kTiles[i];
     if (d.tile >= 1 && d.tile <= 4 && d.tile != c.id) continue;
     const int64_t tm = ceil_div(d.M, c.bm), tn = ceil_div(d.N, c.bn);
+    // ... except when the output is only a handful of tiles (weight gradients of the first layers:
+    // K = B*H*W is in the 1e5..1e6 range): then slabs are tiny and a deep split is the only parallelism
+    const int sk_cap = (int)std::max<int64_t>(sk_cap_base, std::min<int64_t>(512, 1024 / (tm * tn)));
+    const int sk_max = can_split ? std::min(sk_cap, std::max(1, nkt / 8)) : 1;
     const float waste = (float)(tm * c.bm * tn * c.bn) / ((float)d.M * (float)d.N);
     const int64_t par = tm * tn * sk_max;
     // enough tiles to saturate the chip -> no penalty; reachable only through split-K -> pay for the
@@ -766,15 +771,14 @@ void pick_config(const mmfn_gemm_desc& d, int* tile, int* splitk) {
     float fill = 1.0f;
     if (tm * tn < c.target) fill = par >= c.target ? 1.3f : 1.3f * (float)c.target / (float)par;
     const float cost = waste / c.eff * fill;
-    if (best < 0 || cost < best_cost) { best = i; best_cost = cost; }
+    if (best < 0 || cost < best_cost) { best = i; best_cost = cost; best_skmax = sk_max; }
   }
   const TileCand& c = kTiles[best];
   const int64_t blocks = (int64_t)ceil_div(d.M, c.bm) * ceil_div(d.N, c.bn);
   int sk = d.splitk;
   if (sk < 1) {
     sk = 1;
-    if (blocks < c.target) sk = (int)std::min<int64_t>((c.target + blocks - 1) / blocks, sk_max);
-    if (sk > 48) sk = 48;  // slab traffic grows with sk; beyond this the reduce costs more than the fill gains
+    if (blocks < c.target) sk = (int)std::min<int64_t>((c.target + blocks - 1) / blocks, best_skmax);
   }
   if (!can_split) sk = 1;
   if (sk > nkt) sk = std::max(1, nkt);
