@@ -86,6 +86,11 @@ typedef struct mmfn_gemm_desc {
   int32_t tile;         /* 0 auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128          */
   uint32_t rng_stream;  /* distinguishes dropout sites                                    */
   float drop_p;
+  /* batched GEMM (radar GAT, model_rad.py:816-824): problem z uses A + z*strideA, ... (floats);
+   * batch <= 1 means a single problem.  Split-K is disabled for batch > 1. */
+  int32_t batch;
+  int32_t reserved;
+  int64_t strideA, strideB, strideC;
 } mmfn_gemm_desc;
 
 /* C = epilogue(A*B).  Replaces aten addmm / cudnn convolution fwd, dgrad, wgrad dispatched by
@@ -193,6 +198,20 @@ int mmfn_lane_to_vector_f32(const float* lane, float* vec, int64_t R, int n, voi
 int mmfn_polyline_pool_fwd_f32(const float* y, float* out, uint8_t* arg, int R, int V, int H, int last, void* stream);
 int mmfn_polyline_pool_bwd_f32(const float* gout, const uint8_t* arg, float* gy, int R, int V, int H, int last,
                                void* stream);
+
+/* ---- radar GAT pieces (model_rad.py:800-884); the matrix products use the batched mmfn_gemm_f32 ---- */
+int mmfn_elu_fwd_f32(const float* x, float* y, int64_t n, void* stream);
+int mmfn_elu_bwd_f32(const float* g, const float* y, float* dx, int64_t n, void* stream);
+/* p = softmax(adj > 0 ? LeakyReLU_alpha(e_pre) : -9e15) over rows of N; att = dropout(p) */
+int mmfn_gat_softmax_fwd_f32(const float* e_pre, const float* adj, float alpha, float* p, float* att, int R, int N,
+                             float drop_p, const uint64_t* rng_state, uint32_t rng_stream, void* stream);
+int mmfn_gat_softmax_bwd_f32(const float* g_att, const float* p, const float* e_pre, const float* adj, float alpha,
+                             float* g_epre, int R, int N, float drop_p, const uint64_t* rng_state, uint32_t rng_stream,
+                             void* stream);
+/* y[orow] = log_softmax(x[row]) over C channels; swap: row (b, i*8+j) -> orow (b, j*8+i), i.e. the
+ * view(B,8,8,512).transpose(1,3) of model_rad.py:883 expressed on NHWC rows */
+int mmfn_log_softmax_fwd_f32(const float* x, float* y, int R, int C, int swap, void* stream);
+int mmfn_log_softmax_bwd_f32(const float* g, const float* y, float* dx, int R, int C, int swap, void* stream);
 
 #ifdef __cplusplus
 }

@@ -59,9 +59,23 @@ __device__ __forceinline__ void epilogue_store(const mmfn_gemm_desc& d, uint64_t
   *c = v;
 }
 
+__device__ __forceinline__ mmfn_gemm_desc batch_view(const mmfn_gemm_desc& in) {
+  mmfn_gemm_desc d = in;
+  if (in.batch > 1) {
+    const size_t z = blockIdx.z;
+    d.A += z * in.strideA;
+    d.B += z * in.strideB;
+    d.C += z * in.strideC;
+    if (d.res) d.res += z * in.strideC;
+    if (d.aux) d.aux += z * in.strideC;
+  }
+  return d;
+}
+
 template <int AM, int BMODE, int BM, int BN>
-__global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d, const int kt_per_split,
+__global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d_in, const int kt_per_split,
                                                       const int tiles_n) {
+  const mmfn_gemm_desc d = batch_view(d_in);
   constexpr bool A_KC = (AM != MMFN_A_COLMAJOR);
   constexpr bool B_KC = (BMODE == MMFN_B_NK);
   constexpr int WAVES_M = 2, WAVES_N = 2;
@@ -391,8 +405,9 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 }
 
 template <int AM, int BMODE, int BM, int BN>
-__global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc d, const int kt_per_split, const int tiles_n,
+__global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, const int tiles_n,
                                                            const int log2_ow, const int log2_ohw) {
+  const mmfn_gemm_desc d = batch_view(d_in);
   constexpr bool A_KC = (AM != MMFN_A_COLMAJOR);
   constexpr bool B_KC = (BMODE == MMFN_B_NK);
   constexpr int WAVES_N = 2;
@@ -710,7 +725,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
 #define MMFN_LAUNCH_FAST(BM_, BN_)                                                                                   \
   {                                                                                                                  \
     const int tn = ceil_div(d.N, BN_);                                                                               \
-    dim3 grid(ceil_div(d.M, BM_) * tn, zdim);                                                                        \
+    dim3 grid(ceil_div(d.M, BM_) * tn, zdim, d.batch > 1 ? d.batch : 1);                                             \
     hipLaunchKernelGGL((gemm_f32_fast_kernel<AM, BMODE, BM_, BN_>), grid, dim3(NT), 0, s, dd, kps, tn, l_ow, l_ohw); \
   }
     if (tile == 1) MMFN_LAUNCH_FAST(128, 128)
@@ -731,7 +746,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
 #define MMFN_LAUNCH_TILE(BM_, BN_)                                                                              \
   {                                                                                                             \
     const int tn = ceil_div(d.N, BN_);                                                                          \
-    dim3 grid(ceil_div(d.M, BM_) * tn, zdim);                                                                   \
+    dim3 grid(ceil_div(d.M, BM_) * tn, zdim, d.batch > 1 ? d.batch : 1);                                        \
     hipLaunchKernelGGL((gemm_f32_kernel<AM, BMODE, BM_, BN_>), grid, dim3(NT), 0, s, dd, kps, tn);              \
   }
   if (tile == 1) MMFN_LAUNCH_TILE(128, 128)
@@ -751,7 +766,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
 
 void pick_config(const mmfn_gemm_desc& d, int* tile, int* splitk) {
   const int nkt = ceil_div(d.K, BK);
-  const bool can_split = d.workspace != nullptr && d.splitk != 1;
+  const bool can_split = d.workspace != nullptr && d.splitk != 1 && d.batch <= 1;
   const int sk_cap_base = 48;  // slab traffic grows with the split factor ...
   int best = -1;
   float best_cost = 0.f;

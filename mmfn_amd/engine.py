@@ -454,6 +454,114 @@ class VectorNet(object):
                 g = ops.linear_dx(g_pre, lin.w, out=bufs.get("%s.g.sub%d.x" % (nm, i), (R * V, 128)))
 
 
+
+# ----------------------------------------------------------------------------- radar GAT
+class RadarGAT(object):
+    """model_rad.py:853-884 (SpGAT) with its two SpGraphAttentionLayer heads (:778-847).
+
+    radar [B,81,5], adj [B,81,81] -> NHWC map [B,8,8,512] (log-softmax over channels).  Matrix products
+    run on the (batched) MFMA GEMM; the (nhid == N == 81) coincidence that makes `Wh @ a` an [81,81]
+    score matrix (config.py:53) is kept as is."""
+
+    def __init__(self, name, layout, prefix, mod):
+        self.name = name
+        self.nh = mod.nheads
+        self.alpha = mod.alpha
+        self.p = mod.dropout
+        self.W = [layout.w("%s.attention_%d.W" % (prefix, i)) for i in range(self.nh)]
+        self.gW = [layout.g("%s.attention_%d.W" % (prefix, i)) for i in range(self.nh)]
+        self.a = [layout.w("%s.attention_%d.a" % (prefix, i)) for i in range(self.nh)]
+        self.ga = [layout.g("%s.attention_%d.a" % (prefix, i)) for i in range(self.nh)]
+        self.m1 = Linear(layout, prefix + ".mlp_1.0")
+        self.m2 = Linear(layout, prefix + ".mlp_2.0")
+        self.stream_base = 900
+
+    def _drop(self, ctx, t, tag, sid):
+        p = self.p if ctx.training else 0.0
+        if p <= 0.0:
+            return t
+        return ops.dropout_apply(t, ctx.bufs.get("%s.%s" % (self.name, tag), t.shape), p, ctx.rng_state, self.stream_base + sid)
+
+    def fwd(self, ctx, radar, adj):
+        bufs, nm = ctx.bufs, self.name
+        B, N, Fin = radar.shape  # 81 nodes, 5 features
+        H2 = self.W[0].shape[1]  # 162
+        R = B * N
+        p = self.p if ctx.training else 0.0
+        x = self._drop(ctx, radar.view(R, Fin), "xd", 0)
+        cat = bufs.get(nm + ".cat", (B, self.nh * N, H2))
+        self.heads = []
+        adj2 = adj.view(R, N)
+        for h in range(self.nh):
+            wh = bufs.get("%s.wh%d" % (nm, h), (R, H2))
+            ops.gemm(x, self.W[h], wh, R, H2, Fin, Fin, H2, H2, b_mode=ops.B_KN)
+            epre = bufs.get("%s.epre%d" % (nm, h), (R, N))
+            ops.gemm(wh, self.a[h], epre, R, N, H2, H2, N, N, b_mode=ops.B_KN)
+            prob = bufs.get("%s.p%d" % (nm, h), (R, N))
+            att = bufs.get("%s.att%d" % (nm, h), (R, N))
+            ops.gat_softmax_fwd(epre, adj2, self.alpha, prob, att, p, ctx.rng_state, self.stream_base + 1 + h)
+            # h' = att @ Wh per sample, written into rows [h*81, (h+1)*81) of the concatenated tensor
+            ops.gemm(att, wh, cat[:, h * N:], N, H2, N, N, H2, H2, b_mode=ops.B_KN, batch=B, strideA=N * N,
+                     strideB=N * H2, strideC=self.nh * N * H2)
+            self.heads.append((wh, epre, prob, att))
+        n_cat = B * self.nh * N
+        y1 = ops.elu_fwd(cat, bufs.get(nm + ".y1", cat.shape))                 # F.elu inside each head
+        y1d = self._drop(ctx, y1, "y1d", 4)
+        y2 = ops.elu_fwd(y1d, bufs.get(nm + ".y2", cat.shape))                # F.elu before mlp_1
+        m1 = bufs.get(nm + ".m1", (n_cat, 256))
+        ops.linear_fwd(y2.view(n_cat, H2), self.m1.w, self.m1.b, out=m1)
+        m1d = self._drop(ctx, m1, "m1d", 5)
+        m1t = bufs.get(nm + ".m1t", (B * 256, self.nh * N))
+        ops.transpose(m1d, m1t, B, self.nh * N, 256)
+        m2 = bufs.get(nm + ".m2", (B * 256, 128))
+        ops.linear_fwd(m1t, self.m2.w, self.m2.b, out=m2)
+        m2d = self._drop(ctx, m2, "m2d", 6)
+        out = bufs.get(nm + ".out", (B, 8, 8, 512))
+        ops.log_softmax_fwd(m2d, out, B * 64, 512, True)
+        self.saved = (B, N, Fin, H2, x, adj2, y1, y2, m1t, out)
+        return out
+
+    def bwd(self, ctx, g_out):
+        bufs, nm = ctx.bufs, self.name
+        B, N, Fin, H2, x, adj2, y1, y2, m1t, out = self.saved
+        R = B * N
+        n_cat = B * self.nh * N
+        p = self.p if ctx.training else 0.0
+        g_m2 = ops.log_softmax_bwd(g_out, out, bufs.get(nm + ".g.m2", (B * 256, 128)), B * 64, 512, True)
+        if p > 0.0:
+            ops.dropout_apply(g_m2, g_m2, p, ctx.rng_state, self.stream_base + 6)
+        ops.colsum(g_m2, self.m2.gb)
+        ops.linear_dw(g_m2, m1t, out=self.m2.gw)
+        g_m1t = ops.linear_dx(g_m2, self.m2.w, out=bufs.get(nm + ".g.m1t", m1t.shape))
+        g_m1 = ops.transpose(g_m1t, bufs.get(nm + ".g.m1", (n_cat, 256)), B, 256, self.nh * N)
+        if p > 0.0:
+            ops.dropout_apply(g_m1, g_m1, p, ctx.rng_state, self.stream_base + 5)
+        ops.colsum(g_m1, self.m1.gb)
+        ops.linear_dw(g_m1, y2.view(n_cat, H2), out=self.m1.gw)
+        g_y2 = ops.linear_dx(g_m1, self.m1.w, out=bufs.get(nm + ".g.y2", (n_cat, H2)))
+        g_y1d = ops.elu_bwd(g_y2, y2, bufs.get(nm + ".g.y1d", (n_cat, H2)))
+        if p > 0.0:
+            ops.dropout_apply(g_y1d, g_y1d, p, ctx.rng_state, self.stream_base + 4)
+        g_cat = ops.elu_bwd(g_y1d, y1, bufs.get(nm + ".g.cat", (B, self.nh * N, H2)))
+        for h in range(self.nh):
+            wh, epre, prob, att = self.heads[h]
+            gh = g_cat[:, h * N:]  # [B, 81, 162] view, batch stride nh*N*H2
+            # h' = att @ Wh:  d_att = g h'  Wh^T   ;   d_Wh = att^T g h'
+            g_att = bufs.get("%s.g.att%d" % (nm, h), (R, N))
+            ops.gemm(gh, wh, g_att, N, N, H2, H2, H2, N, b_mode=ops.B_NK, batch=B, strideA=self.nh * N * H2, strideB=N * H2,
+                     strideC=N * N)
+            g_wh = bufs.get("%s.g.wh%d" % (nm, h), (R, H2))
+            ops.gemm(att, gh, g_wh, N, H2, N, N, H2, H2, a_mode=ops.A_COLMAJOR, b_mode=ops.B_KN, batch=B, strideA=N * N,
+                     strideB=self.nh * N * H2, strideC=N * H2)
+            g_epre = bufs.get("%s.g.epre%d" % (nm, h), (R, N))
+            ops.gat_softmax_bwd(g_att, prob, epre, adj2, self.alpha, g_epre, p, ctx.rng_state, self.stream_base + 1 + h)
+            # e_pre = Wh @ a
+            ops.gemm(wh, g_epre, self.ga[h], H2, N, R, H2, N, N, a_mode=ops.A_COLMAJOR, b_mode=ops.B_KN)
+            ops.gemm(g_epre, self.a[h], g_wh, R, H2, N, N, N, H2, b_mode=ops.B_NK, accum=True)
+            # Wh = x @ W
+            ops.gemm(x, g_wh, self.gW[h], Fin, H2, R, Fin, H2, H2, a_mode=ops.A_COLMAJOR, b_mode=ops.B_KN)
+
+
 # ----------------------------------------------------------------------------- waypoint head
 class Head(object):
     """model_vec.py:642-651,664-680: join MLP 512-256-128-64 (ReLU), GRUCell x pred_len, Linear(64,2)."""
@@ -551,8 +659,7 @@ class Engine(object):
             self.map = ResNetTrunk("map", layout, "encoder.img_map_encoder.features", enc.img_map_encoder.features,
                                    with_stem=False, first_layer=2)
             self.vec = VectorNet("vec", layout, "encoder.vectornet_encoder", enc.vectornet_encoder)
-        if variant == "rad":
-            raise NotImplementedError("radar (GAT) branch: SURVEY.md section 8 row a14 is not built yet")
+        self.rad = RadarGAT("rad", layout, "encoder.radar_encoder", enc.radar_encoder) if variant == "rad" else None
         self.gpts = [GPT("gpt%d" % (i + 1), layout, "encoder.transformer%d" % (i + 1), getattr(enc, "transformer%d" % (i + 1)),
                          cfg, 100 * (i + 1)) for i in range(4)]
         self.head = Head(layout, cfg.pred_len)
@@ -619,6 +726,8 @@ class Engine(object):
         for s in range(4):
             if s > 0:
                 feats = [t.layer_fwd(ctx, s + 1, f) for t, f in zip(trunks, feats)]
+            if s == 3 and self.rad is not None:  # radar joins only the deepest fusion (model_rad.py:585-593)
+                feats = feats + [self.rad.fwd(ctx, inp["radar"], inp["radar_adj"])]
             tok = self.gpts[s].fwd(ctx, feats, vel)
             self.taps["gpt%d" % (s + 1)] = tok
             self.pre_add.append(feats)
@@ -647,8 +756,10 @@ class Engine(object):
                 ops.upsample_adj(g, gtok, m)
             gin = gpt.bwd(ctx, gtok)
             dF = [ops.pool_bcast_add(g, gin, bufs.get("dF%d.%d" % (s, m), g.shape), m) for m, g in enumerate(G)]
+            if s == 3 and self.rad is not None:
+                self.rad.bwd(ctx, dF[3])
             if s > 0:
-                G = [t.layer_bwd(ctx, s + 1, d) for t, d in zip(trunks, dF)]
+                G = [t.layer_bwd(ctx, s + 1, d) for t, d in zip(trunks, dF[:3])]
                 if on_stage is not None:
                     on_stage(3 - s)
         g_img = self.img.layer_bwd(ctx, 1, dF[0])

@@ -125,6 +125,9 @@ class MMFN(nn.Module):
             B = lane.shape[0]
             inp["lane"] = f32(lane)
             inp["lane_num"] = lane_num.reshape(B).to(device=dev, dtype=torch.int32).contiguous()
+        if self.variant == "rad":
+            inp["radar"] = f32(radar_list[0]).view(-1, 81, 5)
+            inp["radar_adj"] = f32(radar_adj[0]).view(-1, 81, 81)
         return inp
 
     def forward(self, image_list, lidar_list, maps_list, vectormaps_list, radar_list, radar_adj, target_point, velocity):

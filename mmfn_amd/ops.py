@@ -64,8 +64,9 @@ def _f32c(t, name):
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=None, res=None, ldr=0,
          aux=None, ldaux=0, relu=False, gelu=False, accum=False, drop_p=0.0, rng_state=None, rng_stream=0,
-         conv=None, splitk=0, tile=0):
+         conv=None, splitk=0, tile=0, batch=1, strideA=0, strideB=0, strideC=0):
     d = GemmDesc()
+    d.batch, d.strideA, d.strideB, d.strideC = batch, strideA, strideB, strideC
     d.A, d.B, d.C = ptr(A), ptr(B), ptr(C)
     d.bias, d.res, d.aux = ptr(bias), ptr(res), ptr(aux)
     d.rng_state = ptr(rng_state)
@@ -106,7 +107,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=N
         flops = 2.0 * (M // (H * W)) * OH * OW * Cin * KH * KW * Cout
         tag = "dgrad %dx%d c%d->%d k%d s%d" % (H, W, Cin, Cout, KH, st)
     else:
-        flops = 2.0 * M * N * K
+        flops = 2.0 * M * N * K * max(1, batch)
         if conv is not None:
             H, W, Cin, OH, OW, Cout, KH, KW, st, pd = conv
             tag = "%s %dx%d c%d->%d k%d s%d" % ("conv" if a_mode == A_IM2COL else "wgrad", H, W, Cin, Cout, KH, st)
@@ -425,3 +426,36 @@ def relu_mask(g, y, out=None):
     out = g if out is None else out
     _call("mmfn_relu_mask_f32", ptr(g), ptr(y), ptr(out), g.numel(), stream())
     return out
+
+
+# ---------------------------------------------------------------- radar GAT pieces
+def elu_fwd(x, y):
+    _call("mmfn_elu_fwd_f32", ptr(x), ptr(y), x.numel(), stream())
+    return y
+
+
+def elu_bwd(g, y, dx):
+    _call("mmfn_elu_bwd_f32", ptr(g), ptr(y), ptr(dx), g.numel(), stream())
+    return dx
+
+
+def gat_softmax_fwd(e_pre, adj, alpha, p, att, drop_p=0.0, rng_state=None, rng_stream=0):
+    R, N = e_pre.shape
+    _call("mmfn_gat_softmax_fwd_f32", ptr(e_pre), ptr(adj), float(alpha), ptr(p), ptr(att), R, N, float(drop_p), ptr(rng_state),
+          rng_stream, stream())
+
+
+def gat_softmax_bwd(g_att, p, e_pre, adj, alpha, g_epre, drop_p=0.0, rng_state=None, rng_stream=0):
+    R, N = e_pre.shape
+    _call("mmfn_gat_softmax_bwd_f32", ptr(g_att), ptr(p), ptr(e_pre), ptr(adj), float(alpha), ptr(g_epre), R, N, float(drop_p),
+          ptr(rng_state), rng_stream, stream())
+
+
+def log_softmax_fwd(x, y, R, C, swap):
+    _call("mmfn_log_softmax_fwd_f32", ptr(x), ptr(y), R, C, 1 if swap else 0, stream())
+    return y
+
+
+def log_softmax_bwd(g, y, dx, R, C, swap):
+    _call("mmfn_log_softmax_bwd_f32", ptr(g), ptr(y), ptr(dx), R, C, 1 if swap else 0, stream())
+    return dx

@@ -17,7 +17,7 @@ def _setup(variant="vec", B=2, lanes=None, dropout=0.0):
     torch.set_num_threads(min(16, os.cpu_count() or 8))
     oracle = harness.build_oracle(variant, dropout=dropout)
     cfg = GlobalConfig(embd_pdrop=dropout, attn_pdrop=dropout, resid_pdrop=dropout)
-    cls = {"vec": M.MMFN, "img": M.MMFNImg}[variant]
+    cls = {"vec": M.MMFN, "img": M.MMFNImg, "rad": M.MMFNRad}[variant]
     net = cls(cfg, DEV)
     net.load_state_dict(oracle.state_dict(), strict=True)
     batch = fixtures.synthetic_batch(B, variant, seed=42, lanes=lanes)
@@ -29,10 +29,10 @@ def _dev_args(args):
     to = lambda t: t.to(DEV)
     img, lid, maps, vm, radar, adj, tp, vel = args
     vmd = [[to(vm[0][0])], [to(vm[1][0])], vm[2]]
-    return ([to(img[0])], [to(lid[0])], [to(maps[0])], vmd, None, None, to(tp), to(vel))
+    return ([to(img[0])], [to(lid[0])], [to(maps[0])], vmd, [to(radar[0])], [to(adj[0])], to(tp), to(vel))
 
 
-@pytest.mark.parametrize("variant", ["vec", "img"])
+@pytest.mark.parametrize("variant", ["vec", "img", "rad"])
 def test_eval_forward_matches_oracle(variant):
     from oracle import harness
     oracle, net, batch, args = _setup(variant)
@@ -46,11 +46,12 @@ def test_eval_forward_matches_oracle(variant):
     assert err <= 1e-4, "waypoint max abs err %g" % err
 
 
-def test_golden_eval_waypoints(golden_dir):
+@pytest.mark.parametrize("variant", ["vec", "rad"])
+def test_golden_eval_waypoints(golden_dir, variant):
     """Same check against the committed vectors produced by the reference itself."""
     from oracle import harness
-    oracle, net, batch, args = _setup("vec")
-    g = np.load(os.path.join(golden_dir, "mmfn_vec_b2.npz"))
+    oracle, net, batch, args = _setup(variant)
+    g = np.load(os.path.join(golden_dir, "mmfn_%s_b2.npz" % variant))
     harness.calibrate_bn(oracle, args)
     net.load_state_dict(oracle.state_dict(), strict=True)
     net.eval()
@@ -61,8 +62,9 @@ def test_golden_eval_waypoints(golden_dir):
     one = [[batch["lane"][:1][None].to(DEV)], [batch["lane_num"][:1].int().view(1, 1).to(DEV)],
            batch["lane_num"][:1].int().view(1, 1).to(DEV)]
     with torch.no_grad():
-        got1 = net([args[0][0][:1].to(DEV)], [args[1][0][:1].to(DEV)], None, one, None, None,
-                   batch["target_point"][:1].to(DEV), batch["velocity"][:1].to(DEV)).cpu().numpy()
+        got1 = net([args[0][0][:1].to(DEV)], [args[1][0][:1].to(DEV)], None, one, [batch["radar"][:1].to(DEV)],
+                   [batch["radar_adj"][:1].to(DEV)], batch["target_point"][:1].to(DEV),
+                   batch["velocity"][:1].to(DEV)).cpu().numpy()
     assert np.abs(got1 - g["eval_pred_wp_b1_agent"]).max() <= 1e-4
 
 
@@ -74,7 +76,7 @@ def _to64(a):
     return a
 
 
-@pytest.mark.parametrize("variant", ["vec", "img"])
+@pytest.mark.parametrize("variant", ["vec", "img", "rad"])
 def test_train_step_matches_oracle(variant, golden_dir):
     """loss, every parameter gradient, BN running stats and the AdamW update of one step.
 
