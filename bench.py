@@ -194,6 +194,12 @@ def main():
         torch.cuda.synchronize()
         ops.set_gemm_profiler(None)
         n_launch, flops, ms = prof.summary()
+        traffic, traffic_src = None, None
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+        if tfiles:  # PMC-derived HBM bytes per launch of this kernel family (tools/profile_round.sh)
+            rec = json.load(open(tfiles[-1]))
+            traffic, traffic_src = round(rec["hbm_bytes_per_launch"]), os.path.basename(tfiles[-1])
         if os.environ.get("MMFN_BENCH_BREAKDOWN"):
             rows = sorted(prof.by_tag().items(), key=lambda kv: -kv[1][2])
             for tag, (n, fl, t) in rows[:60]:
@@ -202,7 +208,8 @@ def main():
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         result["roofline"] = {
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch",
+            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(prof.algo_bytes() / max(n_launch, 1)),
             "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32 GEMM / implicit-GEMM conv fwd+dgrad+wgrad)",
             "launches_per_step": n_launch // steps_p,
             "algorithmic_gflop_per_step": round(flops / steps_p / 1e9, 1),

@@ -421,7 +421,17 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+#ifdef MMFN_GEMM_NO_XCD_SWIZZLE
   const int bid = blockIdx.x;
+#else
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch policy; speed only).  Give each
+  // XCD a contiguous run of tiles so the blocks that share an A row-panel / B column-panel hit the same L2.
+  int bid;
+  {
+    const int nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, r = nb & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  }
+#endif
   const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
   const int nkt = d.K / BK;
   const int kt_begin = blockIdx.y * kt_per_split;

@@ -25,13 +25,16 @@ class GemmProfiler(object):
 
     def summary(self):
         torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for s, e, _, _ in self.records)
-        return len(self.records), float(sum(f for _, _, f, _ in self.records)), ms
+        ms = sum(r[0].elapsed_time(r[1]) for r in self.records)
+        return len(self.records), float(sum(r[2] for r in self.records)), ms
+
+    def algo_bytes(self):
+        return float(sum(r[4] for r in self.records))
 
     def by_tag(self):
         torch.cuda.synchronize()
         out = {}
-        for s, e, f, tag in self.records:
+        for s, e, f, tag, _ in self.records:
             n, fl, ms = out.get(tag, (0, 0.0, 0.0))
             out[tag] = (n + 1, fl + f, ms + s.elapsed_time(e))
         return out
@@ -113,11 +116,18 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=N
             tag = "%s %dx%d c%d->%d k%d s%d" % ("conv" if a_mode == A_IM2COL else "wgrad", H, W, Cin, Cout, KH, st)
         else:
             tag = "gemm a%d b%d %dx%dx%d" % (a_mode, b_mode, M, N, K)
+    # algorithmic (compulsory) bytes: every operand element read once, every output written once
+    if conv is not None:
+        H, W, Cin, OH, OW, Cout, KH, KW, st, pd = conv
+        nb = (M // (H * W)) if a_mode == A_DGRAD else ((M // (OH * OW)) if a_mode == A_IM2COL else (K // (OH * OW)))
+        abytes = 4.0 * (nb * H * W * Cin + nb * OH * OW * Cout + Cout * KH * KW * Cin)
+    else:
+        abytes = 4.0 * (M * K + N * K + M * N) * max(1, batch)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     check(L.mmfn_gemm_f32(ctypes.byref(d), stream()), "mmfn_gemm_f32")
     e1.record()
-    _profiler.records.append((e0, e1, flops, tag))
+    _profiler.records.append((e0, e1, flops, tag, abytes))
     return C
 
 

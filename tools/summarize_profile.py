@@ -64,3 +64,32 @@ for name, cname in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
             lines.append("%-70s calls %6d  total %14.0f  per_launch %12.1f" % (k, calls[k], v[cname], v[cname] / max(calls[k], 1)))
 open(os.path.join(dst, "%s_pmc.txt" % tag), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
+
+
+# 3. HBM traffic of the dominant (GEMM) kernel family, per launch, for bench.py's roofline.traffic
+import json
+fetch = glob.glob(os.path.join(out, "pmc_fetch*counter_collection.csv"))
+write = glob.glob(os.path.join(out, "pmc_write*counter_collection.csv"))
+if fetch and write:
+    def fam(fname, cname):
+        tot, ids = 0.0, set()
+        for r in csv.DictReader(open(fname)):
+            if "gemm_f32" in r["Kernel_Name"] and r["Counter_Name"] == cname:
+                tot += float(r["Counter_Value"])
+                ids.add(r["Dispatch_Id"])
+        return tot, len(ids)
+    f, nf = fam(fetch[0], "FETCH_SIZE")
+    w, nw = fam(write[0], "WRITE_SIZE")
+    rec = {
+        "kernel_family": "gemm_f32_kernel / gemm_f32_fast_kernel", "launches_profiled": nf,
+        "fetch_bytes_per_launch_raw": f * 1024.0 / max(nf, 1),
+        "fetch_bytes_per_launch_corrected": 2.0 * f * 1024.0 / max(nf, 1),
+        "write_bytes_per_launch": w * 1024.0 / max(nw, 1),
+        "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0 / max(nf, 1),
+        "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
+                  "`bench.py --no-graph --steps 1 --warmup 0 --profile-steps 1`; counters are KiB; FETCH_SIZE doubled per "
+                  "MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B/lane streaming reads); WRITE_SIZE matches "
+                  "M*N*4 exactly on the isolated GEMM (tools/pmc_traffic.sh)",
+    }
+    json.dump(rec, open(os.path.join(dst, "%s_traffic.json" % tag), "w"), indent=1)
+    print(rec)
