@@ -50,15 +50,30 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnArgs a) {
 
   f32x16 s[NKT];
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
+  for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-    const float* Kp = a.k + (rowbase + min(kt * 32 + l31, T - 1)) * a.ld + hd * HS + 4 * h;
+  // One wave per SIMD runs alone, so L2 latency must be hidden inside the wave: the K fragments are
+  // software-pipelined PF chunks (8 d-columns each) ahead of the MFMAs that consume them.  hipcc does not
+  // pipeline this on its own (it emits load; s_waitcnt vmcnt(0); 4 MFMAs), hence the explicit ring and
+  // the sched_barrier pins.
+  {
+    constexpr int PF = (NC < 8 ? NC : 8), TOT = NKT * NC;
+    f32x4 ring[PF];
+    auto kptr = [&](int i) {
+      const int kt = i / NC, c = i % NC;
+      return a.k + (rowbase + min(kt * 32 + l31, T - 1)) * a.ld + hd * HS + 4 * h + 8 * c;
+    };
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const f32x4 kf = ld4g(Kp + 8 * c);
+    for (int i = 0; i < PF; ++i) ring[i] = ld4g(kptr(i));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[c][j], s[kt], 0, 0, 0);
+    for (int i = 0; i < TOT; ++i) {
+      const f32x4 kf = ring[i % PF];
+      if (i + PF < TOT) ring[i % PF] = ld4g(kptr(i + PF));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        s[i / NC] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[i % NC][j], s[i / NC], 0, 0, 0);
     }
   }
   // ---- softmax over keys (rows of S^T): register-local + one cross-half exchange
@@ -103,19 +118,35 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnArgs a) {
   for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  {
+    // V rows are consumed one accumulator row (r) at a time; prefetch them in groups of 4 rows, one group ahead
+    constexpr int G = NKT * 4;
+    float vv[2][4][ND];
+    auto vload = [&](int g, float (*dst)[ND]) {
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
+      for (int rr = 0; rr < 4; ++rr) {
+        const int kt = g >> 2, r = (g & 3) * 4 + rr;
+        const int key = min(kt * 32 + rowmap(r) + 4 * h, T - 1);
+        const float* Vp = a.v + (rowbase + key) * a.ld + hd * HS;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = min(kt * 32 + rowmap(r) + 4 * h, T - 1);
-      const float* Vp = a.v + (rowbase + key) * a.ld + hd * HS;
-#pragma unroll
-      for (int dt = 0; dt < ND; ++dt) {
-        const int d = dt * 32 + l31;
-        const float vv = d < HS ? Vp[d] : 0.f;
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv, s[kt][r], o[dt], 0, 0, 0);
+        for (int dt = 0; dt < ND; ++dt) {
+          const int d = dt * 32 + l31;
+          dst[rr][dt] = d < HS ? Vp[d] : 0.f;
+        }
       }
+    };
+    vload(0, vv[0]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g + 1 < G) vload(g + 1, vv[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[g & 1][rr][dt], s[g >> 2][(g & 3) * 4 + rr], o[dt], 0, 0, 0);
     }
+  }
   if (qvalid) {
     float* Op = a.o + (rowbase + q) * a.ldo + hd * HS;
 #pragma unroll
@@ -162,32 +193,44 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const AttnArgs a) {
   // attention is near-uniform and dS is a small difference of large terms)
   f32x16 ds[NKT], dpt[NKT];
   float dl = 0.f, psum = 0.f;
+  {
+    // chunk-granular software pipeline of the K and V fragments (see attn_fwd_kernel)
+    constexpr int PF = (NC < 4 ? NC : 4), TOT = NKT * NC;
+    f32x4 rk[PF], rv[PF];
+    auto off = [&](int i) {
+      const int kt = i / NC, c = i % NC;
+      return (rowbase + min(kt * 32 + l31, T - 1)) * a.ld + hd * HS + 4 * h + 8 * c;
+    };
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) {
-    f32x16 st, dp;
+    for (int i = 0; i < PF; ++i) { rk[i] = ld4g(a.k + off(i)); rv[i] = ld4g(a.v + off(i)); }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
-    const size_t krow = (rowbase + min(kt * 32 + l31, T - 1)) * a.ld + hd * HS + 4 * h;
+    for (int kt = 0; kt < NKT; ++kt) {
+      f32x16 st, dp;
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const f32x4 kf = ld4g(a.k + krow + 8 * c);
-      const f32x4 vf = ld4g(a.v + krow + 8 * c);
+      for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[c][j], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[j], dof[c][j], dp, 0, 0, 0);
+      for (int c = 0; c < NC; ++c) {
+        const int i = kt * NC + c;
+        const f32x4 kf = rk[i % PF], vf = rv[i % PF];
+        if (i + PF < TOT) { rk[i % PF] = ld4g(a.k + off(i + PF)); rv[i % PF] = ld4g(a.v + off(i + PF)); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[c][j], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[j], dof[c][j], dp, 0, 0, 0);
+        }
       }
-    }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt * 32 + rowmap(r) + 4 * h;
-      const float p = key < kvlen ? expf(st[r] * a.scale - lse) : 0.f;
-      float dpv = dp[r];
-      if (drop) dpv *= mmfn_dropout_scale(key64, pbase + (uint64_t)key, a.drop_p, inv_keep);
-      ds[kt][r] = p;
-      dpt[kt][r] = dpv;
-      dl += p * dpv;
-      psum += p;
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + rowmap(r) + 4 * h;
+        const float p = key < kvlen ? expf(st[r] * a.scale - lse) : 0.f;
+        float dpv = dp[r];
+        if (drop) dpv *= mmfn_dropout_scale(key64, pbase + (uint64_t)key, a.drop_p, inv_keep);
+        ds[kt][r] = p;
+        dpt[kt][r] = dpv;
+        dl += p * dpv;
+        psum += p;
+      }
     }
   }
   // P is recomputed from the rounded log-sum-exp, so sum_j P_j = 1 + O(1e-6); dividing by it keeps
@@ -206,19 +249,34 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const AttnArgs a) {
   for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[dt][r] = 0.f;
+  {
+    constexpr int G = NKT * 4;
+    float kk[2][4][ND];
+    auto kload = [&](int g, float (*dst)[ND]) {
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt)
+      for (int rr = 0; rr < 4; ++rr) {
+        const int kt = g >> 2, r = (g & 3) * 4 + rr;
+        const int key = min(kt * 32 + rowmap(r) + 4 * h, T - 1);
+        const float* Kp = a.k + (rowbase + key) * a.ld + hd * HS;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = min(kt * 32 + rowmap(r) + 4 * h, T - 1);
-      const float* Kp = a.k + (rowbase + key) * a.ld + hd * HS;
-#pragma unroll
-      for (int dt = 0; dt < ND; ++dt) {
-        const int d = dt * 32 + l31;
-        const float kk = d < HS ? Kp[d] : 0.f;
-        dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk, ds[kt][r], dq[dt], 0, 0, 0);
+        for (int dt = 0; dt < ND; ++dt) {
+          const int d = dt * 32 + l31;
+          dst[rr][dt] = d < HS ? Kp[d] : 0.f;
+        }
       }
+    };
+    kload(0, kk[0]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (g + 1 < G) kload(g + 1, kk[(g + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kk[g & 1][rr][dt], ds[g >> 2][(g & 3) * 4 + rr], dq[dt], 0, 0, 0);
     }
+  }
   if (qvalid) {
     float* Gp = a.dq + (rowbase + q) * a.ldg + hd * HS;
 #pragma unroll
@@ -266,37 +324,64 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const AttnArgs a) {
     const int qa = min(qt * 32 + l31, T - 1);
     const float* Qp = a.q + (rowbase + qa) * a.ld + hd * HS + 4 * h;
     const float* dOp = a.dO + (rowbase + qa) * a.ldo + hd * HS + 4 * h;
+    {
+      constexpr int PF = (NC < 4 ? NC : 4);
+      f32x4 rq[PF], rd[PF];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const f32x4 qf = ld4g(Qp + 8 * c);
-      const f32x4 dof = ld4g(dOp + 8 * c);
+      for (int i = 0; i < PF; ++i) { rq[i] = ld4g(Qp + 8 * i); rd[i] = ld4g(dOp + 8 * i); }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        st = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j], kf[c][j], st, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dof[j], vf[c][j], dp, 0, 0, 0);
+      for (int c = 0; c < NC; ++c) {
+        const f32x4 qf = rq[c % PF], dof = rd[c % PF];
+        if (c + PF < NC) { rq[c % PF] = ld4g(Qp + 8 * (c + PF)); rd[c % PF] = ld4g(dOp + 8 * (c + PF)); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          st = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[j], kf[c][j], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dof[j], vf[c][j], dp, 0, 0, 0);
+        }
       }
     }
+    // per accumulator row: probabilities / dS, then rank-1-per-row updates of dV and dK; the dO and Q rows
+    // they need are prefetched in groups of 4 rows
+    float a1[2][4][ND], a2[2][4][ND], lsev[2][4], dlt[2][4];
+    auto rload = [&](int g, int buf) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int qrow = qt * 32 + rowmap(r) + 4 * h;
-      const bool valid = qrow < T;
-      const int qc = min(qrow, T - 1);
-      const float lse = a.lse[statbase + qc];
-      const float delta = a.delta[statbase + qc];
-      const float p = (valid && kin) ? expf(st[r] * a.scale - lse) : 0.f;
-      float msc = 1.f;
-      if (drop) msc = mmfn_dropout_scale(key64, (statbase + qc) * (uint64_t)T + (uint64_t)key, a.drop_p, inv_keep);
-      const float pd = p * msc;
-      const float dsv = p * (dp[r] * msc - delta) * a.scale;
-      const float* dOr = a.dO + (rowbase + qc) * a.ldo + hd * HS;
-      const float* Qr = a.q + (rowbase + qc) * a.ld + hd * HS;
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = g * 4 + rr;
+        const int qc = min(qt * 32 + rowmap(r) + 4 * h, T - 1);
+        lsev[buf][rr] = a.lse[statbase + qc];
+        dlt[buf][rr] = a.delta[statbase + qc];
+        const float* dOr = a.dO + (rowbase + qc) * a.ldo + hd * HS;
+        const float* Qr = a.q + (rowbase + qc) * a.ld + hd * HS;
 #pragma unroll
-      for (int dt = 0; dt < ND; ++dt) {
-        const int d = dt * 32 + l31;
-        const float a1 = d < HS ? dOr[d] : 0.f;
-        const float a2 = d < HS ? Qr[d] : 0.f;
-        dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, pd, dv[dt], 0, 0, 0);
-        dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, dsv, dk[dt], 0, 0, 0);
+        for (int dt = 0; dt < ND; ++dt) {
+          const int d = dt * 32 + l31;
+          a1[buf][rr][dt] = d < HS ? dOr[d] : 0.f;
+          a2[buf][rr][dt] = d < HS ? Qr[d] : 0.f;
+        }
+      }
+    };
+    rload(0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g + 1 < 4) rload(g + 1, (g + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int r = g * 4 + rr;
+        const int qrow = qt * 32 + rowmap(r) + 4 * h;
+        const bool valid = qrow < T;
+        const int qc = min(qrow, T - 1);
+        const float p = (valid && kin) ? expf(st[r] * a.scale - lsev[g & 1][rr]) : 0.f;
+        float msc = 1.f;
+        if (drop) msc = mmfn_dropout_scale(key64, (statbase + qc) * (uint64_t)T + (uint64_t)key, a.drop_p, inv_keep);
+        const float pd = p * msc;
+        const float dsv = p * (dp[r] * msc - dlt[g & 1][rr]) * a.scale;
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[g & 1][rr][dt], pd, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[g & 1][rr][dt], dsv, dk[dt], 0, 0, 0);
+        }
       }
     }
   }
