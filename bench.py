@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--variant", default="vec")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="disable encoder-branch concurrency (profiling runs)")
     ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps for the roofline block")
     args = ap.parse_args()
 
@@ -139,6 +140,8 @@ def main():
     if dp is not None:
         dp.broadcast_parameters()
     eng = net._engine_for()
+    if args.single_stream:
+        eng.multi_stream = False
 
     def step():
         return eng.train_step(inp, gt, lr=1e-4, dp=dp)
@@ -182,17 +185,21 @@ def main():
         "config": {"workload": "full MMFN %s (ResNet34 img + ResNet18 LiDAR-BEV + VectorNet -> 4 GPT fusion -> GRU), "
                                "train step fwd+L1+bwd+AdamW, batch %d/GPU, 400x300x3 u8 RGB + 16384-pt LiDAR + 64x10x5 lanes"
                                % (args.variant, B),
-                   "global_batch": B * world, "parallelism": "dp%d" % world, "hipgraph": graph is not None},
+                   "global_batch": B * world, "parallelism": "dp%d" % world, "hipgraph": graph is not None,
+                   "branch_streams": 1 if args.single_stream else 3},
         "loss": round(loss_val, 6),
     }
     if rank == 0:
         # ---- roofline of the dominant kernel family (fp32 MFMA GEMM / implicit conv)
         prof = ops.GemmProfiler()
         ops.set_gemm_profiler(prof)
+        eng.multi_stream = False  # time each launch alone: with branch concurrency on, kernels of other
+        #                           streams share the CUs and per-launch durations are not comparable
         for _ in range(max(1, args.profile_steps)):
             eng.train_step(inp, gt, lr=1e-4, dp=None)
         torch.cuda.synchronize()
         ops.set_gemm_profiler(None)
+        eng.multi_stream = not args.single_stream
         n_launch, flops, ms = prof.summary()
         traffic, traffic_src = None, None
         import glob

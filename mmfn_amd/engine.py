@@ -671,6 +671,12 @@ class Engine(object):
         self.norm_inv_std = torch.tensor([1.0 / s for s in IMAGENET_STD], dtype=torch.float32, device=dev)
         ops.norm_workspace(dev)
         ops.workspace(64 << 20, dev)
+        # The three encoder branches (camera ResNet-34, LiDAR ResNet-18, map branch) only meet at the four
+        # fusion transformers.  Between those points they run on separate HIP streams, so the many small
+        # kernels of the deep stages (M = 2048..8192 rows at B = 32) overlap each other's tails and launch
+        # gaps; captured into the hipGraph this becomes a fork/join DAG.
+        self.side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        self.multi_stream = True
 
     # ------------------------------------------------------------------ inputs
     def _bufs_for(self, B):
@@ -706,6 +712,27 @@ class Engine(object):
             mp = ops.nchw_to_nhwc(x, bufs.get("in.map", (B, x.shape[2], x.shape[3], 3)))  # NOT normalised (model_img.py:337)
         return img, lid, mp
 
+    # ------------------------------------------------------------------ branch concurrency
+    def _branches(self, fns):
+        """Run fns[0] on the current stream and fns[1:] on the side streams, fork/join with events."""
+        if not self.multi_stream:
+            return [f() for f in fns]
+        main = torch.cuda.current_stream()
+        fork = torch.cuda.Event()
+        fork.record(main)
+        outs = [None] * len(fns)
+        for i, f in enumerate(fns[1:]):
+            st = self.side[i]
+            st.wait_event(fork)
+            with torch.cuda.stream(st), ops.lane(i + 1):
+                outs[i + 1] = f()
+        outs[0] = fns[0]()
+        for i in range(len(fns) - 1):
+            done = torch.cuda.Event()
+            done.record(self.side[i])
+            main.wait_event(done)
+        return outs
+
     # ------------------------------------------------------------------ forward / backward
     def forward(self, inp, training, gt=None):
         B = inp["target_point"].shape[0]
@@ -713,26 +740,35 @@ class Engine(object):
         self._last = (ctx, B)
         img, lid, mp = self._ingest(ctx, inp)
         vel = inp["velocity"]
-        f_img = self.img.layer_fwd(ctx, 1, self.img.stem_fwd(ctx, img))
-        f_lid = self.lid.layer_fwd(ctx, 1, self.lid.stem_fwd(ctx, lid))
-        if self.variant == "img":
-            f_map = self.map.layer_fwd(ctx, 1, self.map.stem_fwd(ctx, mp))
-        else:
-            f_map = self.vec.fwd(ctx, inp["lane"], inp["lane_num"])
-        self.taps = {"stage1": (f_img, f_lid, f_map)}
-        feats = [f_img, f_lid, f_map]
         trunks = [self.img, self.lid, self.map]
+
+        def map_stage1():
+            if self.variant == "img":
+                return self.map.layer_fwd(ctx, 1, self.map.stem_fwd(ctx, mp))
+            return self.vec.fwd(ctx, inp["lane"], inp["lane_num"])
+
+        feats = self._branches([lambda: self.img.layer_fwd(ctx, 1, self.img.stem_fwd(ctx, img)),
+                                lambda: self.lid.layer_fwd(ctx, 1, self.lid.stem_fwd(ctx, lid)),
+                                map_stage1])
+        self.taps = {"stage1": tuple(feats)}
         self.pre_add = []
+        tok = None
         for s in range(4):
             if s > 0:
-                feats = [t.layer_fwd(ctx, s + 1, f) for t, f in zip(trunks, feats)]
+                # per branch: add the previous scale's fusion output, then the next ResNet stage
+                prev, ptok = feats, tok
+
+                def stage(m, prev=prev, ptok=ptok, s=s):
+                    f = ops.upsample_add_fwd(prev[m], ptok, ctx.bufs.get("fuse%d.%d" % (s - 1, m), prev[m].shape), m)
+                    return trunks[m].layer_fwd(ctx, s + 1, f)
+
+                feats = self._branches([lambda m=m: stage(m) for m in range(3)])
             if s == 3 and self.rad is not None:  # radar joins only the deepest fusion (model_rad.py:585-593)
                 feats = feats + [self.rad.fwd(ctx, inp["radar"], inp["radar_adj"])]
             tok = self.gpts[s].fwd(ctx, feats, vel)
             self.taps["gpt%d" % (s + 1)] = tok
             self.pre_add.append(feats)
-            Bq, S, _, C = feats[0].shape
-            feats = [ops.upsample_add_fwd(f, tok, ctx.bufs.get("fuse%d.%d" % (s, m), f.shape), m) for m, f in enumerate(feats)]
+        feats = [ops.upsample_add_fwd(f, tok, ctx.bufs.get("fuse3.%d" % m, f.shape), m) for m, f in enumerate(feats)]
         fused = ops.gap_sum_fwd(feats, ctx.bufs.get("fused", (B, 512)))
         self.taps["fused"] = fused
         pred, loss = self.head.fwd(ctx, fused, inp["target_point"], gt)
@@ -755,22 +791,34 @@ class Engine(object):
             for m, g in enumerate(G):
                 ops.upsample_adj(g, gtok, m)
             gin = gpt.bwd(ctx, gtok)
-            dF = [ops.pool_bcast_add(g, gin, bufs.get("dF%d.%d" % (s, m), g.shape), m) for m, g in enumerate(G)]
             if s == 3 and self.rad is not None:
-                self.rad.bwd(ctx, dF[3])
+                dF3 = ops.pool_bcast_add(G[3], gin, bufs.get("dF3.3", G[3].shape), 3)
+                self.rad.bwd(ctx, dF3)
             if s > 0:
-                G = [t.layer_bwd(ctx, s + 1, d) for t, d in zip(trunks, dF[:3])]
+                def stage(m, G=G, gin=gin, s=s):
+                    d = ops.pool_bcast_add(G[m], gin, bufs.get("dF%d.%d" % (s, m), G[m].shape), m)
+                    return trunks[m].layer_bwd(ctx, s + 1, d)
+
+                G = self._branches([lambda m=m: stage(m) for m in range(3)])
                 if on_stage is not None:
                     on_stage(3 - s)
-        g_img = self.img.layer_bwd(ctx, 1, dF[0])
-        self.img.stem_bwd(ctx, g_img)
-        g_lid = self.lid.layer_bwd(ctx, 1, dF[1])
-        self.lid.stem_bwd(ctx, g_lid)
-        if self.variant == "img":
-            g_map = self.map.layer_bwd(ctx, 1, dF[2])
-            self.map.stem_bwd(ctx, g_map)
-        else:
-            self.vec.bwd(ctx, dF[2])
+            else:
+                def img_tail(G=G, gin=gin):
+                    d = ops.pool_bcast_add(G[0], gin, bufs.get("dF0.0", G[0].shape), 0)
+                    self.img.stem_bwd(ctx, self.img.layer_bwd(ctx, 1, d))
+
+                def lid_tail(G=G, gin=gin):
+                    d = ops.pool_bcast_add(G[1], gin, bufs.get("dF0.1", G[1].shape), 1)
+                    self.lid.stem_bwd(ctx, self.lid.layer_bwd(ctx, 1, d))
+
+                def map_tail(G=G, gin=gin):
+                    d = ops.pool_bcast_add(G[2], gin, bufs.get("dF0.2", G[2].shape), 2)
+                    if self.variant == "img":
+                        self.map.stem_bwd(ctx, self.map.layer_bwd(ctx, 1, d))
+                    else:
+                        self.vec.bwd(ctx, d)
+
+                self._branches([img_tail, lid_tail, map_tail])
         if on_stage is not None:
             on_stage(3)
 

@@ -14,6 +14,23 @@ from ._lib import (A_COLMAJOR, A_DGRAD, A_IM2COL, A_ROWMAJOR, B_DGRADW, B_IM2COL
                    GemmDesc, check, lib, ptr, stream)
 
 _workspace = {}
+_lane = 0  # logical execution lane (0 = main stream, 1.. = engine side streams); scratch buffers are per lane
+
+
+class lane(object):
+    """Context manager: kernels launched inside use the scratch buffers of logical lane `i`.  (Keying by the
+    raw stream pointer would break under hipGraph capture, where the capturing stream is a fresh one.)"""
+
+    def __init__(self, i):
+        self.i = i
+
+    def __enter__(self):
+        global _lane
+        self.prev, _lane = _lane, self.i
+
+    def __exit__(self, *exc):
+        global _lane
+        _lane = self.prev
 
 
 class GemmProfiler(object):
@@ -49,8 +66,9 @@ def set_gemm_profiler(p):
 
 
 def workspace(nbytes, device):
-    """Grow-only scratch buffer (split-K slabs); never freed so captured graphs stay valid."""
-    key = str(device)
+    """Grow-only scratch buffer (split-K slabs); never freed so captured graphs stay valid.
+    One buffer per (device, lane): branches running concurrently on side streams must not share slabs."""
+    key = (str(device), _lane)
     buf = _workspace.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         if torch.cuda.is_current_stream_capturing():
@@ -215,8 +233,8 @@ _norm_ws = {}
 
 
 def norm_workspace(device, nbytes=None):
-    """Scratch for norm / colsum / token-bwd reductions (grow-only, fp64-aligned)."""
-    key = str(device)
+    """Scratch for norm / colsum / token-bwd reductions (grow-only, fp64-aligned), per (device, lane)."""
+    key = (str(device), _lane)
     need = max(nbytes or 0, lib().mmfn_norm_workspace_bytes(1024) + 8192)
     buf = _norm_ws.get(key)
     if buf is None or buf.numel() * 8 < need:
