@@ -89,7 +89,7 @@ typedef struct mmfn_gemm_desc {
   /* batched GEMM (radar GAT, model_rad.py:816-824): problem z uses A + z*strideA, ... (floats);
    * batch <= 1 means a single problem.  Split-K is disabled for batch > 1. */
   int32_t batch;
-  int32_t reserved;
+  int32_t dg_parity; /* internal: set by the launcher for stride-2 dgrad (output-parity decomposition) */
   int64_t strideA, strideB, strideC;
 } mmfn_gemm_desc;
 

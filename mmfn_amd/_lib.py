@@ -32,7 +32,7 @@ class GemmDesc(ctypes.Structure):
         ("KH", _i32), ("KW", _i32), ("stride", _i32), ("pad", _i32),
         ("flags", _i32), ("splitk", _i32), ("tile", _i32),
         ("rng_stream", ctypes.c_uint32), ("drop_p", _f32),
-        ("batch", _i32), ("reserved", _i32), ("strideA", _i64), ("strideB", _i64), ("strideC", _i64),
+        ("batch", _i32), ("dg_parity", _i32), ("strideA", _i64), ("strideB", _i64), ("strideC", _i64),
     ]
 
 

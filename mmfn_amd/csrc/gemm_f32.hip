@@ -407,7 +407,21 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 template <int AM, int BMODE, int BM, int BN>
 __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, const int tiles_n,
                                                            const int log2_ow, const int log2_ohw) {
-  const mmfn_gemm_desc d = batch_view(d_in);
+  const mmfn_gemm_desc d = d_in.dg_parity ? d_in : batch_view(d_in);
+  // Stride-2 transposed convolution, decomposed by output-pixel parity (blockIdx.z = 2*py + px): an input
+  // pixel (ih, iw) only receives taps with kh == (ih + pad) mod 2, kw == (iw + pad) mod 2, so each of the
+  // four parity classes is a dense GEMM over its own 1/2/2/4 (3x3) taps instead of 9 taps of which 3/4
+  // multiply zeros.
+  const bool dgp = (AM == MMFN_A_DGRAD) && d.dg_parity;
+  int py = 0, px = 0, kh0 = 0, kw0 = 0, nkw = d.KW, Mloc = d.M, Kloc = d.K;
+  if (dgp) {
+    py = blockIdx.z >> 1; px = blockIdx.z & 1;
+    kh0 = (py + d.pad) & 1; kw0 = (px + d.pad) & 1;
+    const int nkh = (d.KH - kh0 + 1) >> 1;
+    nkw = (d.KW - kw0 + 1) >> 1;
+    Mloc = d.M >> 2;
+    Kloc = nkh * nkw * d.Cout;
+  }
   constexpr bool A_KC = (AM != MMFN_A_COLMAJOR);
   constexpr bool B_KC = (BMODE == MMFN_B_NK);
   constexpr int WAVES_N = 2;
@@ -433,7 +447,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
   }
 #endif
   const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
-  const int nkt = d.K / BK;
+  const int nkt = Kloc / BK;
   const int kt_begin = blockIdx.y * kt_per_split;
   const int kt_end = min(nkt, kt_begin + kt_per_split);
   const int KHW = d.KH * d.KW;
@@ -459,10 +473,21 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
       ax0[i] = ow * d.stride - d.pad;
       pa[i] = d.A + (size_t)b * d.H * d.W * d.Cin + SRCQ(u) * 4;
     } else {
-      const int m = min(m0 + u / KQ, d.M - 1);
-      const int hw = d.H * d.W;
-      const int b = m / hw, rem = m - b * hw;
-      const int ih = rem / d.W, iw = rem - ih * d.W;
+      const int m = min(m0 + u / KQ, Mloc - 1);
+      int b, ih, iw;
+      if (dgp) {
+        const int w2 = d.W >> 1, hw2 = (d.H >> 1) * w2;
+        b = m / hw2;
+        const int rem = m - b * hw2;
+        ih = 2 * (rem / w2) + py;
+        iw = 2 * (rem % w2) + px;
+      } else {
+        const int hw = d.H * d.W;
+        b = m / hw;
+        const int rem = m - b * hw;
+        ih = rem / d.W;
+        iw = rem - ih * d.W;
+      }
       ay0[i] = ih + d.pad;
       ax0[i] = iw + d.pad;
       pa[i] = d.A + (size_t)b * d.OH * d.OW * d.Cout + SRCQ(u) * 4;
@@ -497,14 +522,14 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
       const int k0 = kt_begin * BK;
       const int tap = k0 / chan;
       t_c0 = k0 - tap * chan;
-      t_kh = tap / d.KW;
-      t_kw = tap - t_kh * d.KW;
+      t_kh = tap / nkw;
+      t_kw = tap - t_kh * nkw;
     }
   }
   auto advance_tap = [&]() {
     const int chan = (AM == MMFN_A_IM2COL) ? d.Cin : d.Cout;
     t_c0 += BK;
-    if (t_c0 == chan) { t_c0 = 0; if (++t_kw == d.KW) { t_kw = 0; ++t_kh; } }
+    if (t_c0 == chan) { t_c0 = 0; if (++t_kw == nkw) { t_kw = 0; ++t_kh; } }
   };
 
   auto src_a = [&](int i, int kt) -> const float* {
@@ -515,7 +540,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
       const bool ok = (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
       return ok ? pa[i] + ((size_t)ih * d.W + iw) * d.Cin + t_c0 : zero;
     }
-    int oh = ay0[i] - t_kh, ow = ax0[i] - t_kw;
+    int oh = ay0[i] - (dgp ? kh0 + 2 * t_kh : t_kh), ow = ax0[i] - (dgp ? kw0 + 2 * t_kw : t_kw);
     bool ok = oh >= 0 && ow >= 0;
     if (d.stride == 2) { ok = ok && !((oh | ow) & 1); oh >>= 1; ow >>= 1; }
     else if (d.stride != 1) { ok = ok && (oh % d.stride == 0) && (ow % d.stride == 0); oh /= d.stride; ow /= d.stride; }
@@ -525,7 +550,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
   auto src_b = [&](int i, int kt) -> const float* {
     if (BMODE == MMFN_B_NK) return pb[i] + (size_t)kt * BK;
     if (BMODE == MMFN_B_KN) return pb[i] + (size_t)kt * BK * d.ldb;
-    if (BMODE == MMFN_B_DGRADW) return pb[i] + ((size_t)t_c0 * KHW + (t_kh * d.KW + t_kw)) * d.Cin;
+    if (BMODE == MMFN_B_DGRADW)
+      return pb[i] + ((size_t)t_c0 * KHW + (dgp ? (kh0 + 2 * t_kh) * d.KW + (kw0 + 2 * t_kw) : t_kh * d.KW + t_kw)) * d.Cin;
     const int kk = kt * BK + (tid + i * NT) / (BN / 4);
     const int b = kk >> log2_ohw, rem = kk & ((1 << log2_ohw) - 1);
     const int oh = rem >> log2_ow, ow = rem & ((1 << log2_ow) - 1);
@@ -642,8 +668,13 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
       if (col >= d.N) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row >= d.M) continue;
+        int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= Mloc) continue;
+        if (dgp) {  // local (b, i, j) -> input pixel (b, 2i+py, 2j+px)
+          const int w2 = d.W >> 1, hw2 = (d.H >> 1) * w2;
+          const int bb = row / hw2, rem = row - bb * hw2;
+          row = (bb * d.H + 2 * (rem / w2) + py) * d.W + 2 * (rem % w2) + px;
+        }
         if (to_slab) slab[(size_t)row * d.N + col] = acc[i][q][r];
         else epilogue_store(d, key, row, col, acc[i][q][r]);
       }
@@ -730,6 +761,21 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
   dd.splitk = zdim;
 #ifndef MMFN_GEMM_NO_FAST
   if (fast_ok(d)) {
+    if (AM == MMFN_A_DGRAD && d.stride == 2 && !(d.H & 1) && !(d.W & 1) && d.batch <= 1) {
+      // four output-parity classes in one launch (grid.z), no split-K: each class already has M/4 rows
+      dd.dg_parity = 1;
+      dd.splitk = 1;
+      const int mloc = d.M / 4;
+      const int bm = (tile == 1 || tile == 3) ? 128 : 64, bn = (tile == 1 || tile == 4) ? 128 : 64;
+      const int tn = ceil_div(d.N, bn);
+      dim3 grid(ceil_div(mloc, bm) * tn, 1, 4);
+      if (tile == 1) hipLaunchKernelGGL((gemm_f32_fast_kernel<AM, BMODE, 128, 128>), grid, dim3(NT), 0, s, dd, 1 << 20, tn, 0, 0);
+      else if (tile == 3) hipLaunchKernelGGL((gemm_f32_fast_kernel<AM, BMODE, 128, 64>), grid, dim3(NT), 0, s, dd, 1 << 20, tn, 0, 0);
+      else if (tile == 4) hipLaunchKernelGGL((gemm_f32_fast_kernel<AM, BMODE, 64, 128>), grid, dim3(NT), 0, s, dd, 1 << 20, tn, 0, 0);
+      else hipLaunchKernelGGL((gemm_f32_fast_kernel<AM, BMODE, 64, 64>), grid, dim3(NT), 0, s, dd, 1 << 20, tn, 0, 0);
+      MMFN_LAUNCH_CHECK();
+      return 0;
+    }
     const int l_ow = (BMODE == MMFN_B_IM2COL) ? ilog2_exact(d.OW) : 0;
     const int l_ohw = (BMODE == MMFN_B_IM2COL) ? ilog2_exact(d.OH * d.OW) : 0;
 #define MMFN_LAUNCH_FAST(BM_, BN_)                                                                                   \
