@@ -21,6 +21,7 @@
 // tile t runs on the matrix pipe (fp32 MFMA issues every 64 cycles, so one barrier per 16-k
 // tile is far off the critical path).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -821,40 +822,34 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
 }
 
 void pick_config(const mmfn_gemm_desc& d, int* tile, int* splitk) {
+  // Time model per candidate tile (microseconds, constants fitted to tools/gemm_bench.py on MI355X):
+  //   compute  = padded FLOPs / (95 TF/s * tile efficiency * fill), fill = min(1, blocks*sk / saturating blocks)
+  //   split-K  = slab write + slab read at ~3 TB/s + one extra launch (~3 us)
+  // and the split factor is the smallest one that saturates the chip (capped so slabs stay small).
   const int nkt = ceil_div(d.K, BK);
   const bool can_split = d.workspace != nullptr && d.splitk != 1 && d.batch <= 1;
-  const int sk_cap_base = 48;  // slab traffic grows with the split factor ...
-  int best = -1;
-  float best_cost = 0.f;
-  int best_skmax = 1;
+  int best = -1, best_sk = 1;
+  double best_t = 0.0;
   for (int i = 0; i < 4; ++i) {
     const TileCand& c = kTiles[i];
     if (d.tile >= 1 && d.tile <= 4 && d.tile != c.id) continue;
     const int64_t tm = ceil_div(d.M, c.bm), tn = ceil_div(d.N, c.bn);
-    // ... except when the output is only a handful of tiles (weight gradients of the first layers:
-    // K = B*H*W is in the 1e5..1e6 range): then slabs are tiny and a deep split is the only parallelism
-    const int sk_cap = (int)std::max<int64_t>(sk_cap_base, std::min<int64_t>(512, 1024 / (tm * tn)));
+    const int64_t blocks = tm * tn;
+    // outputs of only a handful of tiles (first-layer weight gradients, K = B*H*W ~ 1e5..1e6) may split deeper
+    const int sk_cap = (int)std::max<int64_t>(48, std::min<int64_t>(512, 1024 / blocks));
     const int sk_max = can_split ? std::min(sk_cap, std::max(1, nkt / 8)) : 1;
-    const float waste = (float)(tm * c.bm * tn * c.bn) / ((float)d.M * (float)d.N);
-    const int64_t par = tm * tn * sk_max;
-    // enough tiles to saturate the chip -> no penalty; reachable only through split-K -> pay for the
-    // slab round trip + reduce launch; not reachable at all -> proportional under-fill
-    float fill = 1.0f;
-    if (tm * tn < c.target) fill = par >= c.target ? 1.3f : 1.3f * (float)c.target / (float)par;
-    const float cost = waste / c.eff * fill;
-    if (best < 0 || cost < best_cost) { best = i; best_cost = cost; best_skmax = sk_max; }
+    int sk = 1;
+    if (d.splitk > 1) sk = std::min(d.splitk, std::max(1, nkt));
+    else if (d.splitk < 1 && blocks < c.target) sk = (int)std::min<int64_t>((c.target + blocks - 1) / blocks, sk_max);
+    if (!can_split) sk = 1;
+    const double flops = 2.0 * (double)(tm * c.bm) * (double)(tn * c.bn) * (double)d.K;
+    const double fill = std::min(1.0, (double)(blocks * sk) / (double)c.target);
+    double t = flops / (95e6 * c.eff * fill);  // us
+    if (sk > 1) t += (double)sk * (double)d.M * (double)d.N * 8.0 / 3e6 + 3.0;
+    if (best < 0 || t < best_t) { best = i; best_t = t; best_sk = sk; }
   }
-  const TileCand& c = kTiles[best];
-  const int64_t blocks = (int64_t)ceil_div(d.M, c.bm) * ceil_div(d.N, c.bn);
-  int sk = d.splitk;
-  if (sk < 1) {
-    sk = 1;
-    if (blocks < c.target) sk = (int)std::min<int64_t>((c.target + blocks - 1) / blocks, best_skmax);
-  }
-  if (!can_split) sk = 1;
-  if (sk > nkt) sk = std::max(1, nkt);
-  *tile = c.id;
-  *splitk = sk;
+  *tile = kTiles[best].id;
+  *splitk = best_sk;
 }
 
 }  // namespace
