@@ -118,13 +118,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if os.environ.get("MMFN_BENCH_SINGLE_DEVICE"):  # CI on a 1-GPU box: all ranks share cuda:0 (with gloo, see below)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("MMFN_DIST_BACKEND", "nccl")  # nccl == RCCL over xGMI on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from mmfn_amd import ops
     from mmfn_amd.config import GlobalConfig
@@ -156,6 +162,11 @@ def main():
         with torch.cuda.graph(graph):
             loss_buf = step()
         runner = graph.replay
+    elif not args.no_graph:
+        # multi-GPU: five graphs cut at the gradient-bucket boundaries, RCCL all-reduces in between
+        from mmfn_amd.parallel import GraphedStep
+        graph = GraphedStep(eng, dp, inp, gt, lr=1e-4, warm=0)
+        runner = graph
 
     def barrier():
         if dist is not None:

@@ -778,49 +778,60 @@ class Engine(object):
         """Backward of the last training forward.  dpred None => gradient of the fused L1 loss.
         on_stage(i) is called as soon as every gradient of backward stage i (params.FlatLayout.stage_of)
         has been written, so a data-parallel wrapper can start reducing that bucket."""
+        self.backward_begin(dpred, gscale)
+        for s in range(3, -1, -1):
+            self.backward_scale(s)
+            if on_stage is not None:
+                on_stage(3 - s)
+
+    def backward_begin(self, dpred=None, gscale=None):
+        """Head backward + gradient of the global-average-pool/sum: seeds the per-branch gradients."""
         ctx, B = self._last
         bufs = ctx.bufs
         g_fused = self.head.bwd(ctx, dpred, gscale)
-        trunks = [self.img, self.lid, self.map]
         shapes = [f.shape for f in self.pre_add[3]]
-        G = [bufs.get("G3.%d" % m, shp) for m, shp in enumerate(shapes)]
-        ops.gap_sum_bwd(g_fused, G)
-        for s in range(3, -1, -1):
-            gpt = self.gpts[s]
-            gtok = bufs.get("gtok%d" % s, (B, gpt.T, gpt.C))
-            for m, g in enumerate(G):
-                ops.upsample_adj(g, gtok, m)
-            gin = gpt.bwd(ctx, gtok)
-            if s == 3 and self.rad is not None:
-                dF3 = ops.pool_bcast_add(G[3], gin, bufs.get("dF3.3", G[3].shape), 3)
-                self.rad.bwd(ctx, dF3)
-            if s > 0:
-                def stage(m, G=G, gin=gin, s=s):
-                    d = ops.pool_bcast_add(G[m], gin, bufs.get("dF%d.%d" % (s, m), G[m].shape), m)
-                    return trunks[m].layer_bwd(ctx, s + 1, d)
+        self._G = [bufs.get("G3.%d" % m, shp) for m, shp in enumerate(shapes)]
+        ops.gap_sum_bwd(g_fused, self._G)
 
-                G = self._branches([lambda m=m: stage(m) for m in range(3)])
-                if on_stage is not None:
-                    on_stage(3 - s)
+    def backward_scale(self, s):
+        """Backward of fusion scale s (3 = deepest): GPT_s, then ResNet stage s+1 of the three branches
+        (s = 0: layer1 + stems + VectorNet).  After it returns (enqueues), backward stage 3-s is complete."""
+        ctx, B = self._last
+        bufs = ctx.bufs
+        trunks = [self.img, self.lid, self.map]
+        G = self._G
+        gpt = self.gpts[s]
+        gtok = bufs.get("gtok%d" % s, (B, gpt.T, gpt.C))
+        for m, g in enumerate(G):
+            ops.upsample_adj(g, gtok, m)
+        gin = gpt.bwd(ctx, gtok)
+        if s == 3 and self.rad is not None:
+            dF3 = ops.pool_bcast_add(G[3], gin, bufs.get("dF3.3", G[3].shape), 3)
+            self.rad.bwd(ctx, dF3)
+        if s > 0:
+            def stage(m):
+                d = ops.pool_bcast_add(G[m], gin, bufs.get("dF%d.%d" % (s, m), G[m].shape), m)
+                return trunks[m].layer_bwd(ctx, s + 1, d)
+
+            self._G = self._branches([lambda m=m: stage(m) for m in range(3)])
+            return
+
+        def img_tail():
+            d = ops.pool_bcast_add(G[0], gin, bufs.get("dF0.0", G[0].shape), 0)
+            self.img.stem_bwd(ctx, self.img.layer_bwd(ctx, 1, d))
+
+        def lid_tail():
+            d = ops.pool_bcast_add(G[1], gin, bufs.get("dF0.1", G[1].shape), 1)
+            self.lid.stem_bwd(ctx, self.lid.layer_bwd(ctx, 1, d))
+
+        def map_tail():
+            d = ops.pool_bcast_add(G[2], gin, bufs.get("dF0.2", G[2].shape), 2)
+            if self.variant == "img":
+                self.map.stem_bwd(ctx, self.map.layer_bwd(ctx, 1, d))
             else:
-                def img_tail(G=G, gin=gin):
-                    d = ops.pool_bcast_add(G[0], gin, bufs.get("dF0.0", G[0].shape), 0)
-                    self.img.stem_bwd(ctx, self.img.layer_bwd(ctx, 1, d))
+                self.vec.bwd(ctx, d)
 
-                def lid_tail(G=G, gin=gin):
-                    d = ops.pool_bcast_add(G[1], gin, bufs.get("dF0.1", G[1].shape), 1)
-                    self.lid.stem_bwd(ctx, self.lid.layer_bwd(ctx, 1, d))
-
-                def map_tail(G=G, gin=gin):
-                    d = ops.pool_bcast_add(G[2], gin, bufs.get("dF0.2", G[2].shape), 2)
-                    if self.variant == "img":
-                        self.map.stem_bwd(ctx, self.map.layer_bwd(ctx, 1, d))
-                    else:
-                        self.vec.bwd(ctx, d)
-
-                self._branches([img_tail, lid_tail, map_tail])
-        if on_stage is not None:
-            on_stage(3)
+        self._branches([img_tail, lid_tail, map_tail])
 
     def optimizer_step(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
         L = self.layout

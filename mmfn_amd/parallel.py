@@ -51,3 +51,51 @@ class DataParallel(object):
         for w in self.pending:
             w.wait()
         self.pending = []
+
+
+class GraphedStep(object):
+    """One data-parallel training step as five hipGraphs with the RCCL bucket reductions in between.
+
+    A single graph cannot contain the collectives (they run on RCCL's own stream through torch.distributed),
+    and an eager step is ~1900 Python-issued launches, which makes the host the bottleneck once eight ranks
+    share the node's cores.  So the step is cut at the backward-stage boundaries:
+        g0 = RNG advance + forward + loss + head backward + backward of fusion scale 4   -> all-reduce bucket 0
+        g1 = backward of scale 3 -> bucket 1;  g2 = scale 2 -> bucket 2;  g3 = scale 1 + stems -> bucket 3
+        g4 = fused AdamW (after every reduction has been waited on)
+    Each replay is one host call; the reductions still overlap the later backward graphs."""
+
+    def __init__(self, engine, dp, inp, gt, lr=1e-4, warm=2):
+        self.engine, self.dp = engine, dp
+        eng = engine
+        for _ in range(warm):  # size every buffer / scratch lane eagerly before capture
+            eng.train_step(inp, gt, lr=lr, dp=dp)
+        torch.cuda.synchronize()
+        scale = 1.0 / (dp.world if dp is not None else 1)
+
+        def first():
+            from . import ops
+            ops.rng_advance(eng.rng_state)
+            eng.forward(inp, True, gt)
+            eng.backward_begin()
+            eng.backward_scale(3)
+
+        parts = [first, lambda: eng.backward_scale(2), lambda: eng.backward_scale(1), lambda: eng.backward_scale(0),
+                 lambda: eng.optimizer_step(lr=lr, grad_scale=scale)]
+        self.graphs = []
+        for fn in parts:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self.graphs.append(g)
+        self.loss = eng._bufs_for(inp["target_point"].shape[0]).get("head.loss", (1,))
+
+    def __call__(self):
+        g, dp = self.graphs, self.dp
+        for i in range(4):
+            g[i].replay()
+            if dp is not None:
+                dp.on_stage(i)
+        if dp is not None:
+            dp.finish()
+        g[4].replay()
+        return self.loss

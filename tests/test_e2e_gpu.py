@@ -169,3 +169,25 @@ def test_raw_sensor_ingest_path_equals_tensor_path():
         raw["lidar_pts"] = batch["lidar_pts"].to(DEV)
         pred, _ = net._engine_for().forward(raw, False, None)
     assert torch.equal(pred, ref)
+
+
+def test_segmented_graph_step_equals_eager_steps():
+    """parallel.GraphedStep (five hipGraphs cut at the gradient-bucket boundaries) replays to exactly the
+    parameters the eager train_step produces, dropout included (counter RNG advances on the device)."""
+    from mmfn_amd.parallel import GraphedStep
+    _, net_a, batch, args = _setup("vec", dropout=0.1)
+    _, net_b, _, _ = _setup("vec", dropout=0.1)
+    dargs = _dev_args(args)
+    gt = batch["gt_wp"].to(DEV)
+    net_a.train(), net_b.train()
+    inp_a, inp_b = net_a._pack(*dargs), net_b._pack(*dargs)
+    for _ in range(3):
+        loss_a = net_a.train_step(inp_a, gt)
+    step = GraphedStep(net_b._engine_for(), None, inp_b, gt, warm=1)
+    for _ in range(2):
+        loss_b = step()
+    torch.cuda.synchronize()
+    assert loss_a.item() == loss_b.item()
+    sa, sb = net_a.state_dict(), net_b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
