@@ -28,10 +28,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
-ALGO_GFLOP_PER_SAMPLE = {"vec": 106.6, "img": 112.4}  # SURVEY.md section 8d (train step, matmul/conv)
+ALGO_GFLOP_PER_SAMPLE = {"vec": 106.6, "img": 112.4, "rad": 117.7, "image-only": 28.4}
 
 
-def synth_inputs(B, device, seed, lanes=64, n_lidar=16384):
+def synth_inputs(B, device, seed, lanes=64, n_lidar=16384, variant="vec"):
     g = torch.Generator().manual_seed(seed)
     rgb = torch.randint(0, 256, (B, 300, 400, 3), generator=g, dtype=torch.uint8)
     pts = torch.empty(B, n_lidar, 4)
@@ -51,7 +51,42 @@ def synth_inputs(B, device, seed, lanes=64, n_lidar=16384):
         "target_point": torch.randn(B, 2, generator=g) * 10.0, "velocity": torch.rand(B, generator=g) * 8.0,
     }
     gt = torch.randn(B, 4, 2, generator=g) * 5.0
+    if variant == "img":  # raster map instead of lanes (model_img.py:337: not normalised)
+        del inp["lane"], inp["lane_num"]
+        inp["map"] = torch.randint(0, 256, (B, 3, 256, 256), generator=g, dtype=torch.uint8).float()
+    if variant == "rad":
+        radar = torch.randn(B, 81, 5, generator=g)
+        radar[..., 3] = radar[..., 3].abs() + 0.5
+        inp["radar"] = radar
+        inp["radar_adj"] = radar[:, None, :, 1] - radar[:, :, None, 1]  # adj[i, j] = r[j, 1] - r[i, 1] (dataloader.py:381-384)
     return {k: v.to(device).contiguous() for k, v in inp.items()}, gt.to(device)
+
+
+class ImageBranchOnly(object):
+    """BASELINE.json configs[3]: the ResNet-34 camera branch alone (ingest -> stem -> layer1..4 -> global average
+    pool), forward + backward (dgrad + wgrad + BN), no fusion transformers and no optimizer: a conv/MFMA run."""
+
+    def __init__(self, eng, rgb_u8):
+        from mmfn_amd import ops
+        self.eng, self.ops, self.rgb = eng, ops, rgb_u8
+        self.B = rgb_u8.shape[0]
+        self.gseed = torch.full((self.B, 512), 1.0 / (self.B * 512), device=rgb_u8.device)
+
+    def __call__(self):
+        eng, ops, B = self.eng, self.ops, self.B
+        ctx = eng._ctx(B, True)
+        bufs = ctx.bufs
+        x = ops.ingest_rgb_u8(self.rgb, bufs.get("in.img", (B, 256, 256, 3)))
+        f = eng.img.stem_fwd(ctx, x)
+        for li in range(1, 5):
+            f = eng.img.layer_fwd(ctx, li, f)
+        pooled = ops.gap_sum_fwd([f], bufs.get("fused", (B, 512)))
+        g = bufs.get("G3.0", f.shape)
+        ops.gap_sum_bwd(self.gseed, [g])
+        for li in range(4, 0, -1):
+            g = eng.img.layer_bwd(ctx, li, g)
+        eng.img.stem_bwd(ctx, g)
+        return pooled
 
 
 def usable_cores():
@@ -106,7 +141,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
-    ap.add_argument("--variant", default="vec")
+    ap.add_argument("--variant", default="vec", choices=["vec", "img", "rad"])
+    ap.add_argument("--workload", default="train", choices=["train", "image-only"],
+                    help="train = full step (BASELINE configs[1]); image-only = ResNet-34 branch fwd+bwd (configs[3])")
+    ap.add_argument("--n-lidar", type=int, default=16384, help="LiDAR points per sample (configs[4]: 65536)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="disable encoder-branch concurrency (profiling runs)")
@@ -134,14 +172,14 @@ def main():
 
     from mmfn_amd import ops
     from mmfn_amd.config import GlobalConfig
-    from mmfn_amd.model import MMFN, MMFNImg
+    from mmfn_amd.model import MMFN, MMFNImg, MMFNRad
     from mmfn_amd.parallel import DataParallel
 
     torch.manual_seed(42)  # init_torch(): run_steps/utils.py:77-84
-    net = {"vec": MMFN, "img": MMFNImg}[args.variant](GlobalConfig(), dev)
+    net = {"vec": MMFN, "img": MMFNImg, "rad": MMFNRad}[args.variant](GlobalConfig(), dev)
     net.train()
     B = args.batch
-    inp, gt = synth_inputs(B, dev, seed=42 + rank)
+    inp, gt = synth_inputs(B, dev, seed=42 + rank, n_lidar=args.n_lidar, variant=args.variant)
     dp = DataParallel(net, dist) if world > 1 else None
     if dp is not None:
         dp.broadcast_parameters()
@@ -149,8 +187,14 @@ def main():
     if args.single_stream:
         eng.multi_stream = False
 
-    def step():
-        return eng.train_step(inp, gt, lr=1e-4, dp=dp)
+    image_only = args.workload == "image-only"
+    if image_only:
+        if world > 1:
+            raise SystemExit("the image-only ablation is a single-GPU run")
+        step = ImageBranchOnly(eng, inp["rgb_u8"])
+    else:
+        def step():
+            return eng.train_step(inp, gt, lr=1e-4, dp=dp)
 
     # two eager steps size every buffer, then (optionally) capture one step into a hipGraph
     step(); step()
@@ -187,18 +231,23 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
-    loss_val = float(eng._bufs_for(B).get("head.loss", (1,)).item())
+    loss_val = None if image_only else float(eng._bufs_for(B).get("head.loss", (1,)).item())
+    workload = ("full MMFN %s (ResNet34 img + ResNet18 LiDAR-BEV + %s -> 4 GPT fusion -> GRU), train step fwd+L1+bwd+AdamW, "
+                "batch %d/GPU, 400x300x3 u8 RGB + %d-pt LiDAR + %s"
+                % (args.variant, {"vec": "VectorNet", "img": "ResNet34 raster map", "rad": "VectorNet + radar GAT"}[args.variant], B,
+                   args.n_lidar, "256x256x3 raster map" if args.variant == "img" else "64x10x5 lanes"
+                   + (" + 81x5 radar" if args.variant == "rad" else "")))
+    if image_only:
+        workload = "ResNet-34 camera branch alone, fwd+bwd (no optimizer), batch %d, 400x300x3 u8 RGB" % B
 
     result = {
-        "metric": "train samples/sec (RGB+LiDAR+vec-map fusion)", "value": round(value, 2), "unit": "samples/s",
+        "metric": "image-branch fwd+bwd samples/sec" if image_only else "train samples/sec (RGB+LiDAR+vec-map fusion)", "value": round(value, 2), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "full MMFN %s (ResNet34 img + ResNet18 LiDAR-BEV + VectorNet -> 4 GPT fusion -> GRU), "
-                               "train step fwd+L1+bwd+AdamW, batch %d/GPU, 400x300x3 u8 RGB + 16384-pt LiDAR + 64x10x5 lanes"
-                               % (args.variant, B),
+        "config": {"workload": workload,
                    "global_batch": B * world, "parallelism": "dp%d" % world, "hipgraph": graph is not None,
                    "branch_streams": 1 if args.single_stream else 3},
-        "loss": round(loss_val, 6),
+        "loss": None if loss_val is None else round(loss_val, 6),
     }
     if rank == 0:
         # ---- roofline of the dominant kernel family (fp32 MFMA GEMM / implicit conv)
@@ -207,7 +256,7 @@ def main():
         eng.multi_stream = False  # time each launch alone: with branch concurrency on, kernels of other
         #                           streams share the CUs and per-launch durations are not comparable
         for _ in range(max(1, args.profile_steps)):
-            eng.train_step(inp, gt, lr=1e-4, dp=None)
+            step() if image_only else eng.train_step(inp, gt, lr=1e-4, dp=None)
         torch.cuda.synchronize()
         ops.set_gemm_profiler(None)
         eng.multi_stream = not args.single_stream
@@ -215,7 +264,8 @@ def main():
         traffic, traffic_src = None, None
         import glob
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-        if tfiles:  # PMC-derived HBM bytes per launch of this kernel family (tools/profile_round.sh)
+        default_workload = (not image_only and args.variant == "vec" and B == 32 and args.n_lidar == 16384)
+        if tfiles and default_workload:  # PMC-derived HBM bytes per launch of this kernel family (tools/profile_round.sh)
             rec = json.load(open(tfiles[-1]))
             traffic, traffic_src = round(rec["hbm_bytes_per_launch"]), os.path.basename(tfiles[-1])
         if os.environ.get("MMFN_BENCH_BREAKDOWN"):
@@ -232,9 +282,9 @@ def main():
             "launches_per_step": n_launch // steps_p,
             "algorithmic_gflop_per_step": round(flops / steps_p / 1e9, 1),
             "kernel_ms_per_step": round(ms / steps_p, 3),
-            "whole_step_algorithmic_tflops": round(ALGO_GFLOP_PER_SAMPLE.get(args.variant, 0) * B / ms_per_step, 2),
+            "whole_step_algorithmic_tflops": round(ALGO_GFLOP_PER_SAMPLE.get("image-only" if image_only else args.variant, 0) * B / ms_per_step, 2),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and not image_only and args.variant == "vec":
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))
     if dist is not None:

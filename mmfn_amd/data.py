@@ -1,0 +1,255 @@
+"""Data side of the training path: the PRE_Data sample store, batch collation and host->device staging.
+
+Mirrors, for the formats either side of the hot path:
+  FrameStore        <- PRE_Data                    (mmfn_utils/datasets/dataloader.py:349-385)
+  collate           <- collate_single_cpu          (mmfn_utils/datasets/data_utils.py:9-67)
+  stage_batch       <- the H2D block of Engine.train (run_steps/phase2_train_net.py:63-103)
+  radar_to_size / radar_adjacency / ego_transform / local_waypoints / local_target_point
+                    <- dataloader.py:336-346, 381-384, 311-334, 240-261
+The sample dict, the collated dict and the tensors handed to MMFN.forward keep the reference's keys,
+nesting, dtypes and shapes.  What differs is where bytes are widened: uint8 camera / raster-map frames
+cross PCIe as uint8 (the reference widens them to fp32 on the host first, 4x the traffic) and the
+float64 lane / radar / label tensors are narrowed to fp32 on the host before the copy.
+
+Host-side only (numpy / torch CPU tensors + async copies): no kernels live here, and nothing here is
+part of the CPU oracle.
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+RADAR_ROWS = 81
+
+
+# ------------------------------------------------------------------------------------------ per-sample geometry
+def radar_to_size(points, rows=RADAR_ROWS, cols=5):
+    """Force a radar return list to exactly `rows` rows (dataloader.py:336-346): short lists are zero
+    padded; long ones lose the surplus rows with the largest |depth / velocity| (time to collision),
+    in the order a descending argsort names them."""
+    pts = np.asarray(points)
+    n = pts.shape[0]
+    if n < rows:
+        out = np.zeros((rows, cols))
+        out[:n, :] = pts[:n, :]
+        return out
+    ttc = np.abs(pts[:, 0] / pts[:, 3])
+    surplus = np.argsort(-ttc)[:n - rows]
+    return np.delete(pts, surplus, 0)
+
+
+def radar_adjacency(radar):
+    """adj[i, j] = radar[j, 1] - radar[i, 1] (dataloader.py:381-384); only its sign is used downstream."""
+    col = np.asarray(radar)[:, 1]
+    return col[None, :] - col[:, None]
+
+
+def ego_transform(xyz, r1, t1_x, t1_y, r2, t2_x, t2_y):
+    """Move 2-D points from frame 1 (rotation r1, translation t1) into frame 2 (dataloader.py:311-334).
+    The z column rides along unchanged."""
+    xyz = np.asarray(xyz, dtype=np.float64)
+    h = np.stack([xyz[:, 0], xyz[:, 1], np.ones(len(xyz))], 0)
+
+    def frame(r, tx, ty):
+        c, s = np.cos(r), np.sin(r)
+        return np.array([[c, s, tx], [-s, c, ty], [0.0, 0.0, 1.0]])
+
+    world = frame(r1, t1_x, t1_y) @ h
+    local = np.linalg.inv(frame(r2, t2_x, t2_y)) @ world
+    out = local.T.copy()
+    out[:, 2] = xyz[:, 2]
+    return out
+
+
+def local_waypoints(xs, ys, thetas, ego_index):
+    """Ego-frame positions of the recorded poses (dataloader.py:240-248): pose i's origin seen from the
+    pose at `ego_index`, using 90deg - theta as the reference does."""
+    ex, ey, et = xs[ego_index], ys[ego_index], thetas[ego_index]
+    out = []
+    for x, y, t in zip(xs, ys, thetas):
+        p = ego_transform(np.zeros((1, 3)), np.pi / 2 - t, -x, -y, np.pi / 2 - et, -ex, -ey)
+        out.append((float(p[0, 0]), float(p[0, 1])))
+    return out
+
+
+def local_target_point(x_command, y_command, ego_x, ego_y, ego_theta):
+    """Route command point in the ego frame (dataloader.py:250-261): R(90deg + theta)^T (p - ego)."""
+    a = np.pi / 2 + ego_theta
+    rot = np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]])
+    return tuple(rot.T.dot(np.array([x_command - ego_x, y_command - ego_y])))
+
+
+# ------------------------------------------------------------------------------------------ sample store
+class FrameStore(torch.utils.data.Dataset):
+    """Reader of the phase-1 output: one pickle per frame (written by run_steps/phase1_preprocess_data.py:42-48)
+    plus the `rg_vec_mmfn_diag_pl_<seq>_<pred>_<use>.npy` file-list cache, created on first use exactly as
+    PRE_Data does (dataloader.py:356-371) so both implementations can share a directory."""
+
+    def __init__(self, root, config, data_use="train"):
+        self.seq_len, self.pred_len = config.seq_len, config.pred_len
+        index = os.path.join(root, "rg_vec_mmfn_diag_pl_%d_%d_%s.npy" % (self.seq_len, self.pred_len, data_use))
+        if not os.path.exists(index):
+            files = [str(root) + "/" + f for f in os.listdir(root) if f.split(".")[-1] == "pkl"]
+            np.save(index, files)
+        self.files = np.load(index)
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, i):
+        with open(self.files[i], "rb") as fd:
+            sample = pickle.load(fd)
+        sample["radar_adj"] = radar_adjacency(sample["radar"][0])
+        return sample
+
+
+PRE_Data = FrameStore  # reference name
+
+
+# ------------------------------------------------------------------------------------------ collation
+def _stack(items):
+    first = items[0]
+    if isinstance(first, torch.Tensor):
+        return torch.stack(list(items), 0)
+    if isinstance(first, np.ndarray):
+        return torch.stack([torch.as_tensor(x) for x in items], 0)
+    if isinstance(first, (float, np.floating)):
+        return torch.tensor([float(x) for x in items], dtype=torch.float64)
+    if isinstance(first, (bool, int, np.integer)):
+        return torch.tensor(list(items))
+    if isinstance(first, (str, bytes)):
+        return list(items)
+    if isinstance(first, (tuple, list)):
+        width = len(first)
+        if any(len(x) != width for x in items):
+            raise RuntimeError("each element in list of batch should be of equal size")
+        return [_stack([x[j] for x in items]) for j in range(width)]
+    raise TypeError("collate: unsupported field type %s" % type(first))
+
+
+def _pad_lanes(lanes):
+    """Ragged per-sample lane sets [L_b, 10, 5] -> [padded [B, Lmax, 10, 5], lane_nums i64[B], int Lmax]
+    (data_utils.py:19-25)."""
+    lanes = [torch.as_tensor(x) for x in lanes]
+    nums = torch.tensor([x.shape[0] for x in lanes])
+    lmax = int(nums.max().item())
+    out = lanes[0].new_zeros((len(lanes), lmax) + tuple(lanes[0].shape[1:]))
+    for b, x in enumerate(lanes):
+        out[b, :x.shape[0]] = x
+    return [out, nums, lmax]
+
+
+def collate(samples):
+    """List of FrameStore samples -> the batch dict Engine.train consumes."""
+    out = {}
+    for key in samples[0]:
+        column = [s[key] for s in samples]
+        if key == "vectormaps":
+            seq = len(column[0])
+            out[key] = [_pad_lanes([c[i] for c in column]) for i in range(seq)]
+        else:
+            out[key] = _stack(column)
+    return out
+
+
+collate_single_cpu = collate  # reference name
+
+
+# ------------------------------------------------------------------------------------------ host -> device
+def stage_batch(data, device, config, non_blocking=True):
+    """Collated batch -> (MMFN.forward argument tuple, gt_waypoints [B, pred_len, 2]) on `device`
+    (phase2_train_net.py:63-103).  uint8 frames are copied as uint8 and widened on the device."""
+    dev = torch.device(device)
+
+    def f32(t, narrow_first=True):
+        t = torch.as_tensor(t)
+        if t.dtype == torch.uint8:  # 1 byte/pixel over PCIe, widened by the GPU
+            return t.to(dev, non_blocking=non_blocking).to(torch.float32)
+        if narrow_first and t.dtype != torch.float32:
+            t = t.to(torch.float32)
+        return t.to(dev, non_blocking=non_blocking)
+
+    n = config.seq_len
+    fronts = [f32(data["fronts"][i]) for i in range(n)]
+    lidars = [f32(data["lidars"][i]) for i in range(n)]
+    maps = [f32(data["maps"][i]) for i in range(n)]
+    lanes = [f32(data["vectormaps"][i][0]) for i in range(n)]
+    lane_nums = [f32(data["vectormaps"][i][1]) for i in range(n)]
+    vectormaps = [lanes, lane_nums, data["vectormaps"][0][2]]
+    radar = [f32(data["radar"][i]) for i in range(n)]
+    radar_adj = [f32(data["radar_adj"]) for _ in range(n)]
+    velocity = f32(data["velocity"])
+    target_point = f32(torch.stack(list(data["target_point"]), dim=1))
+    wps = data["waypoints"]
+    gt = torch.stack([torch.stack(list(wps[i]), dim=1) for i in range(n, len(wps))], dim=1)
+    return (fronts, lidars, maps, vectormaps, radar, radar_adj, target_point, velocity), f32(gt)
+
+
+class DevicePrefetcher(object):
+    """Iterates a loader of collated batches one batch ahead: the next batch's host->device copies run on a
+    dedicated copy stream while the current step computes (the reference copies synchronously inside the
+    step, phase2_train_net.py:78-91)."""
+
+    def __init__(self, loader, device, config):
+        self.loader, self.device, self.config = loader, torch.device(device), config
+        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, data):
+        if self.stream is None:
+            return stage_batch(data, self.device, self.config, non_blocking=False), None
+        with torch.cuda.stream(self.stream):
+            staged = stage_batch(_pin(data), self.device, self.config)
+            ready = torch.cuda.Event()
+            ready.record(self.stream)
+        return staged, ready
+
+    def __iter__(self):
+        nxt = None
+        for data in self.loader:
+            cur, nxt = nxt, self._stage(data)
+            if cur is not None:
+                yield self._hand_over(cur)
+        if nxt is not None:
+            yield self._hand_over(nxt)
+
+    def _hand_over(self, item):
+        staged, ready = item
+        if ready is not None:
+            torch.cuda.current_stream(self.device).wait_event(ready)
+            for t in _tensors(staged):
+                t.record_stream(torch.cuda.current_stream(self.device))
+        return staged
+
+
+def _pin(obj):
+    if isinstance(obj, torch.Tensor):
+        return obj if obj.is_pinned() else obj.pin_memory()
+    if isinstance(obj, dict):
+        return {k: _pin(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_pin(v) for v in obj)
+    return obj
+
+
+def _tensors(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            for t in _tensors(v):
+                yield t
+
+
+def make_loader(store, batch_size, shuffle=False, sampler=None, num_workers=8, pin_memory=False):
+    """DataLoader with this module's collate (phase2_train_net.py:268-274)."""
+    return torch.utils.data.DataLoader(store, batch_size=batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
+                                       num_workers=num_workers, pin_memory=pin_memory, collate_fn=collate)
+
+
+def shard_sampler(store, rank, world, shuffle=True, seed=0):
+    """Per-rank sample shard, as DistributedSampler does for the reference (phase2_train_net.py:265-266)."""
+    return torch.utils.data.distributed.DistributedSampler(store, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed)

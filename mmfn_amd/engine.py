@@ -702,7 +702,7 @@ class Engine(object):
             B = x.shape[0]
             img = ops.nchw_to_nhwc(x, bufs.get("in.img", (B, x.shape[2], x.shape[3], 3)), self.norm_mean, self.norm_inv_std)
         if "lidar_pts" in inp:
-            lid = ops.lidar_splat(inp["lidar_pts"], bufs.get("in.lid", (B, 256, 256, 2)))
+            lid = ops.lidar_splat(inp["lidar_pts"], bufs.get("in.lid", (B, 256, 256, 2)), flip_y=bool(inp.get("lidar_flip_y", False)))
         else:
             x = inp["lidar"]
             lid = ops.nchw_to_nhwc(x, bufs.get("in.lid", (B, x.shape[2], x.shape[3], x.shape[1])))
@@ -839,17 +839,18 @@ class Engine(object):
         ops.adamw(L.params, L.grads, L.exp_avg, L.exp_avg_sq, self.step_count, lr, betas[0], betas[1], eps, weight_decay,
                   grad_scale, n=L.tail)
 
-    def train_step(self, inp, gt, lr=1e-4, dp=None):
+    def train_step(self, inp, gt, lr=1e-4, dp=None, **adam):
         """zero-grad (implicit: every gradient is overwritten) + forward + L1 + backward + AdamW
         (phase2_train_net.py:60-110).  `dp` (mmfn_amd.parallel.DataParallel) reduces the gradient
-        buckets across ranks while the backward is still running.  Returns the device loss scalar."""
+        buckets across ranks while the backward is still running.  `adam` may carry betas / eps /
+        weight_decay.  Returns the device loss scalar."""
         ops.rng_advance(self.rng_state)
         _, loss = self.forward(inp, True, gt)
         if dp is None:
             self.backward()
-            self.optimizer_step(lr=lr)
+            self.optimizer_step(lr=lr, **adam)
         else:
             self.backward(on_stage=dp.on_stage)
             dp.finish()
-            self.optimizer_step(lr=lr, grad_scale=1.0 / dp.world)
+            self.optimizer_step(lr=lr, grad_scale=1.0 / dp.world, **adam)
         return loss

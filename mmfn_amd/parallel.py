@@ -39,6 +39,14 @@ class DataParallel(object):
         self.dist.broadcast(L.params, src)
         self.dist.broadcast(L.buffers_flat, src)
         self.dist.broadcast(L.counters_flat, src)
+        # optimizer moments + step counter too, so a run resumed on rank 0 continues identically everywhere
+        self.dist.broadcast(L.exp_avg, src)
+        self.dist.broadcast(L.exp_avg_sq, src)
+        if L.device.type == "cuda":  # (the CPU unit tests exercise the bucket logic without an engine)
+            eng = self.module._engine_for()
+            self.dist.broadcast(eng.step_count, src)
+            self.dist.broadcast(eng.rng_state, src)
+            eng.rng_state[0] += self.dist.get_rank()  # per-rank dropout streams
 
     def on_stage(self, stage):
         """Called by Engine.backward when every gradient of `stage` has been written (enqueued)."""

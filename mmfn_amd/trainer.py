@@ -1,0 +1,153 @@
+"""Epoch loop, validation and checkpoint / resume around the HIP training step.
+
+Restates the reference's `Engine` (run_steps/phase2_train_net.py:44-220) and the resume block of its
+`main` (:288-302).  Same attributes (`cur_epoch, cur_iter, bestval, bestval_epoch, train_loss, val_loss`),
+same files in the log directory:
+    recent.log        JSON {epoch, iter, bestval, bestval_epoch, train_loss, val_loss}        (:193-204)
+    best_model.pth    model.state_dict() when the validation loss improved                    (:207-211)
+    best_optim.pth    optimizer.state_dict() (torch.optim.AdamW layout)                       (:209)
+    model.pth, recent_optim.pth   always                                                      (:215-216)
+so a run can be resumed by either implementation.  Differences, all on the host side:
+  * the step is the fused one (forward + L1 + backward + bucketed all-reduce + AdamW on device buffers);
+    `fused=False` runs the reference's literal sequence through autograd instead;
+  * the loss is accumulated on the device and read back once per `log_every` steps, not every step
+    (:109 forces a host sync per step; anomaly mode :107 is not reproduced);
+  * checkpoints always carry un-prefixed keys (the reference mixes `module.`-prefixed and plain keys
+    under DDP, :208 vs :216).
+"""
+import json
+import os
+
+import torch
+
+from . import data as D
+from . import ops
+
+
+class Trainer(object):
+    def __init__(self, device, log_dir, cur_epoch=0, cur_iter=0):
+        self.cur_epoch = cur_epoch
+        self.cur_iter = cur_iter
+        self.bestval_epoch = cur_epoch
+        self.train_loss = []
+        self.val_loss = []
+        self.bestval = 1e10
+        self.device = device
+        self.logdir = log_dir
+
+    # ------------------------------------------------------------------ one epoch of training
+    def train(self, model, dataloader_train, config, optimizer, dp=None, fused=True, log_every=50, on_log=None):
+        model.train()
+        eng = model._engine_for()
+        total = torch.zeros(1, dtype=torch.float32, device=model._layout.device)
+        window = torch.zeros_like(total)
+        num_batches = 0
+        for args, gt in D.DevicePrefetcher(dataloader_train, self.device, config):
+            if fused:
+                g = optimizer.param_groups[0]
+                loss = eng.train_step(model._pack(*args), gt, lr=g["lr"], dp=dp, betas=tuple(g["betas"]), eps=g["eps"],
+                                      weight_decay=g["weight_decay"])
+            else:
+                if dp is not None:
+                    raise NotImplementedError("the autograd path is single-GPU; use fused=True under data parallelism")
+                for p in model.parameters():
+                    p.grad = None
+                pred = model(*args)
+                loss = torch.nn.functional.l1_loss(pred, gt, reduction="none").mean()
+                loss.backward()
+                optimizer.step()
+                loss = loss.detach().view(1)
+            total += loss
+            window += loss
+            self.cur_iter += 1
+            num_batches += 1
+            if on_log is not None and num_batches % log_every == 0:
+                on_log({"loss": float(window.item()) / log_every, "iter": self.cur_iter})
+                window.zero_()
+        self.train_loss.append(float(total.item()) / max(num_batches, 1))
+        self.cur_epoch += 1
+        return self.train_loss[-1]
+
+    # ------------------------------------------------------------------ validation (no grad, eval-mode BN, no dropout)
+    def validate(self, model, dataloader_val, config):
+        model.eval()
+        eng = model._engine_for()
+        total = torch.zeros(1, dtype=torch.float32, device=model._layout.device)
+        num_batches = 0
+        with torch.no_grad():
+            for args, gt in D.DevicePrefetcher(dataloader_val, self.device, config):
+                _, loss = eng.forward(model._pack(*args), False, gt)
+                total += loss
+                num_batches += 1
+        if num_batches:
+            self.val_loss.append(float(total.item()) / num_batches)
+            return self.val_loss[-1]
+        return None
+
+    # ------------------------------------------------------------------ checkpoints
+    def _log_table(self):
+        return {"epoch": self.cur_epoch, "iter": self.cur_iter, "bestval": self.bestval, "bestval_epoch": self.bestval_epoch,
+                "train_loss": self.train_loss, "val_loss": self.val_loss}
+
+    def save(self, model, optimizer, logdir=None):
+        logdir = logdir or self.logdir
+        os.makedirs(logdir, exist_ok=True)
+        best = bool(self.val_loss) and self.val_loss[-1] <= self.bestval
+        if best:
+            self.bestval = self.val_loss[-1]
+            self.bestval_epoch = self.cur_epoch
+        weights = _plain_state_dict(model)
+        opt_state = optimizer.state_dict()
+        if best:
+            torch.save(weights, os.path.join(logdir, "best_model.pth"))
+            torch.save(opt_state, os.path.join(logdir, "best_optim.pth"))
+        torch.save(weights, os.path.join(logdir, "model.pth"))
+        torch.save(opt_state, os.path.join(logdir, "recent_optim.pth"))
+        with open(os.path.join(logdir, "recent.log"), "w") as f:
+            f.write(json.dumps(self._log_table()))
+        return best
+
+    def resume(self, model, optimizer, logdir=None, which="best"):
+        """Pick a run up from its log directory (phase2_train_net.py:288-302 loads the `best_*` pair)."""
+        logdir = logdir or self.logdir
+        path = os.path.join(logdir, "recent.log")
+        if not os.path.isfile(path):
+            return False
+        with open(path) as f:
+            table = json.load(f)
+        self.cur_epoch = table["epoch"]
+        self.cur_iter = table.get("iter", self.cur_iter)
+        self.bestval = table["bestval"]
+        self.bestval_epoch = table.get("bestval_epoch", self.cur_epoch)
+        self.train_loss = table["train_loss"]
+        self.val_loss = table["val_loss"]
+        names = ("best_model.pth", "best_optim.pth") if which == "best" else ("model.pth", "recent_optim.pth")
+        weights = torch.load(os.path.join(logdir, names[0]), map_location="cpu")
+        model.load_state_dict({k[7:] if k.startswith("module.") else k: v for k, v in weights.items()})
+        optimizer.load_state_dict(torch.load(os.path.join(logdir, names[1]), map_location="cpu"))
+        return True
+
+
+def _plain_state_dict(model):
+    return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+
+def fit(model, optimizer, train_loader, val_loader, config, logdir, epochs, val_every=1, save_every=1, dp=None, rank=0,
+        on_log=None):
+    """The epoch loop of phase2_train_net.py:307-322: train every epoch; rank 0 validates every `val_every`
+    epochs and saves every `save_every`."""
+    trainer = Trainer(model._layout.device, logdir)
+    if rank == 0:
+        trainer.resume(model, optimizer)
+    if dp is not None:
+        dp.broadcast_parameters()
+    for epoch in range(trainer.cur_epoch, epochs):
+        sampler = getattr(train_loader, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
+        trainer.train(model, train_loader, config, optimizer, dp=dp, on_log=on_log if rank == 0 else None)
+        if epoch % val_every == 0 and rank == 0 and val_loader is not None:
+            trainer.validate(model, val_loader, config)
+            if epoch % save_every == 0:
+                trainer.save(model, optimizer)
+    return trainer

@@ -94,3 +94,27 @@ def synthetic_batch(batch, variant="vec", seed=42, n_lidar=16384, lanes=64, ragg
     out["velocity"] = torch.rand(b, generator=g) * 8.0
     out["gt_wp"] = torch.randn(b, 4, 2, generator=g) * 5.0
     return out
+
+
+def synthetic_samples(lane_counts=(5, 9, 3), seed=11, radar_counts=(50, 100, 81)):
+    """Per-frame dicts in the schema phase 1 pickles (CARLA_Data.__getitem__, dataloader.py:183-268):
+    u8 camera crop, f32 BEV histogram, f64 lanes [L,10,5], radar forced to [81,5], u8 raster map,
+    seq_len+pred_len local waypoints, target point and the scalar labels."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for n_lane, n_rad in zip(lane_counts, radar_counts):
+        radar = np.zeros((81, 5))
+        m = min(n_rad, 81)
+        radar[:m] = rng.randn(m, 5)
+        out.append({
+            "fronts": [torch.from_numpy(rng.randint(0, 256, (3, 256, 256)).astype(np.uint8))],
+            "lidars": [(rng.randint(0, 6, (2, 256, 256)) / 5.0).astype(np.float32)],
+            "vectormaps": [torch.from_numpy(rng.randn(n_lane, 10, 5))],
+            "radar": [radar],
+            "maps": [torch.from_numpy(rng.randint(0, 256, (3, 256, 256)).astype(np.uint8))],
+            "waypoints": [tuple(rng.randn(2)) for _ in range(5)],
+            "target_point": tuple(rng.randn(2) * 10.0),
+            "steer": float(rng.uniform(-1, 1)), "throttle": float(rng.uniform(0, 0.75)), "brake": bool(n_lane % 2),
+            "command": int(rng.randint(1, 5)), "velocity": float(rng.uniform(0, 8)),
+        })
+    return out

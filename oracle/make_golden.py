@@ -222,6 +222,51 @@ def preprocessing_vectors(ref_dl, ref_du, out_dir):
     np.savez_compressed(os.path.join(out_dir, "preprocess.npz"), **res)
 
 
+def dataio_vectors(ref_dl, ref_du, out_dir):
+    """Full-schema collate (data_utils.py:9-67), PRE_Data's radar_adj (dataloader.py:381-384), and the pose /
+    command-point geometry of CARLA_Data.__getitem__ (dataloader.py:233-261) evaluated with the reference's
+    own transform_2d_points."""
+    res = {}
+    samples = fixtures.synthetic_samples()
+    for s in samples:  # PRE_Data.__getitem__ adds the adjacency row by row
+        s["radar_adj"] = np.array([s["radar"][0][:, 1] - s["radar"][0][i, 1] for i in range(81)])
+    col = ref_du.collate_single_cpu(samples)
+    res["radar_adj"] = col["radar_adj"].numpy()
+    res["lane"] = col["vectormaps"][0][0].numpy()
+    res["lane_num"] = col["vectormaps"][0][1].numpy()
+    res["lmax"] = np.int64(col["vectormaps"][0][2])
+    res["radar"] = col["radar"][0].numpy()
+    res["waypoints"] = np.stack([np.stack([c.numpy() for c in wp]) for wp in col["waypoints"]])  # [5, 2, B]
+    res["target_point"] = np.stack([c.numpy() for c in col["target_point"]])
+    for k in ("steer", "throttle", "brake", "command", "velocity"):
+        res[k] = col[k].numpy()
+    for k in ("fronts", "lidars", "maps"):
+        t = col[k][0]
+        res[k + "_shape"] = np.array(t.shape)
+        res[k + "_dtype"] = np.array(str(t.dtype))
+        res[k + "_sum"] = np.float64(t.double().sum().item())
+    res["dtypes"] = np.array([str(col[k].dtype) for k in ("steer", "throttle", "brake", "command", "velocity", "radar_adj")]
+                             + [str(col["vectormaps"][0][0].dtype), str(col["vectormaps"][0][1].dtype), str(col["radar"][0].dtype),
+                                str(col["waypoints"][0][0].dtype), str(col["target_point"][0].dtype)])
+    # geometry
+    rng = np.random.RandomState(5)
+    pts = rng.randn(64, 3) * 10.0
+    res["tf_pts"] = pts
+    res["tf_args"] = np.array([0.3, 1.5, -2.0, -0.7, 4.0, 0.25])
+    res["tf_out"] = ref_dl.transform_2d_points(pts, *res["tf_args"])
+    xs, ys, th = rng.randn(5) * 5.0, rng.randn(5) * 5.0, rng.uniform(-3, 3, 5)
+    res["pose_x"], res["pose_y"], res["pose_theta"] = xs, ys, th
+    ego = 0
+    res["pose_waypoints"] = np.array([ref_dl.transform_2d_points(np.zeros((1, 3)), np.pi / 2 - th[i], -xs[i], -ys[i],
+                                                                  np.pi / 2 - th[ego], -xs[ego], -ys[ego])[0, :2] for i in range(5)])
+    R = np.array([[np.cos(np.pi / 2 + th[ego]), -np.sin(np.pi / 2 + th[ego])],
+                  [np.sin(np.pi / 2 + th[ego]), np.cos(np.pi / 2 + th[ego])]])
+    cmd = np.array([7.5, -3.25])
+    res["pose_cmd"] = cmd
+    res["pose_target"] = R.T.dot(np.array([cmd[0] - xs[ego], cmd[1] - ys[ego]]))
+    np.savez_compressed(os.path.join(out_dir, "dataio.npz"), **res)
+
+
 def pid_vectors(ref_models, ref_cfg, out_dir):
     cfg = ref_cfg.GlobalConfig()
     # control_pid only touches config + the two PID controllers; avoid building a 105 M-param net
@@ -260,6 +305,9 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     torch.set_num_threads(8)
     preprocessing_vectors(ref_dl, ref_du, out_dir)
+    dataio_vectors(ref_dl, ref_du, out_dir)
+    if "--only-io" in sys.argv:
+        return
     pid_vectors(ref_models, ref_cfg, out_dir)
     for variant in ("vec", "img", "rad"):
         run_variant(variant, ref_models, ref_dl, ref_cfg, out_dir)

@@ -1,0 +1,94 @@
+"""Host-side data path (mmfn_amd.data) against vectors produced by the reference's own collate / dataset code."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from mmfn_amd import data as D
+from mmfn_amd.config import GlobalConfig
+from oracle import fixtures
+
+
+@pytest.fixture(scope="module")
+def io(golden_dir):
+    return np.load(os.path.join(golden_dir, "dataio.npz"))
+
+
+def _samples():
+    samples = fixtures.synthetic_samples()
+    for s in samples:
+        s["radar_adj"] = D.radar_adjacency(s["radar"][0])
+    return samples
+
+
+def test_collate_matches_reference_layout(io):
+    col = D.collate(_samples())
+    lane, nums, lmax = col["vectormaps"][0]
+    assert np.array_equal(lane.numpy(), io["lane"]) and np.array_equal(nums.numpy(), io["lane_num"]) and lmax == int(io["lmax"])
+    assert isinstance(lmax, int)
+    assert np.array_equal(col["radar"][0].numpy(), io["radar"])
+    assert np.array_equal(col["radar_adj"].numpy(), io["radar_adj"])
+    wps = np.stack([np.stack([c.numpy() for c in wp]) for wp in col["waypoints"]])
+    assert np.array_equal(wps, io["waypoints"])
+    assert np.array_equal(np.stack([c.numpy() for c in col["target_point"]]), io["target_point"])
+    for k in ("steer", "throttle", "brake", "command", "velocity"):
+        assert np.array_equal(col[k].numpy(), io[k]), k
+    for k in ("fronts", "lidars", "maps"):
+        t = col[k][0]
+        assert list(t.shape) == list(io[k + "_shape"]) and str(t.dtype) == str(io[k + "_dtype"])
+        assert t.double().sum().item() == float(io[k + "_sum"])
+    got = [str(col[k].dtype) for k in ("steer", "throttle", "brake", "command", "velocity", "radar_adj")] + \
+          [str(lane.dtype), str(nums.dtype), str(col["radar"][0].dtype), str(col["waypoints"][0][0].dtype),
+           str(col["target_point"][0].dtype)]
+    assert got == list(io["dtypes"])
+
+
+def test_collate_rejects_ragged_sequences():
+    a, b = _samples()[:2]
+    b = dict(b, waypoints=b["waypoints"][:4])
+    with pytest.raises(RuntimeError):
+        D.collate([a, b])
+
+
+def test_radar_and_pose_geometry(io, golden_dir):
+    pre = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    assert np.array_equal(D.radar_to_size(pre["radar_small"]), pre["radar_small_out"])
+    assert np.array_equal(D.radar_to_size(pre["radar_big"]), pre["radar_big_out"])
+    assert D.radar_to_size(np.zeros((0, 5))).shape == (81, 5)
+    out = D.ego_transform(io["tf_pts"], *io["tf_args"])
+    assert np.abs(out - io["tf_out"]).max() <= 1e-12
+    wps = np.array(D.local_waypoints(io["pose_x"], io["pose_y"], io["pose_theta"], 0))
+    assert np.abs(wps - io["pose_waypoints"]).max() <= 1e-12
+    tgt = D.local_target_point(io["pose_cmd"][0], io["pose_cmd"][1], io["pose_x"][0], io["pose_y"][0], io["pose_theta"][0])
+    assert np.abs(np.array(tgt) - io["pose_target"]).max() <= 1e-12
+
+
+def test_frame_store_and_staging(tmp_path, io):
+    cfg = GlobalConfig()
+    for i, s in enumerate(fixtures.synthetic_samples()):
+        with open(tmp_path / ("%d.pkl" % i), "wb") as fd:
+            pickle.dump(s, fd)
+    (tmp_path / "notes.txt").write_text("ignored")
+    store = D.FrameStore(str(tmp_path), cfg, "train")
+    assert len(store) == 3
+    assert os.path.exists(tmp_path / "rg_vec_mmfn_diag_pl_1_4_train.npy")
+    assert len(D.FrameStore(str(tmp_path), cfg, "train")) == 3  # second open reads the cached file list
+    loader = D.make_loader(store, batch_size=3, num_workers=0)
+    batch = next(iter(loader))
+    order = [int(os.path.basename(f).split(".")[0]) for f in store.files]
+    assert np.array_equal(batch["radar_adj"].numpy(), io["radar_adj"][order])
+    args, gt = D.stage_batch(batch, "cpu", cfg, non_blocking=False)
+    fronts, lidars, maps, vm, radar, adj, tp, vel = args
+    assert fronts[0].dtype == torch.float32 and fronts[0].shape == (3, 3, 256, 256)
+    assert vm[0][0].dtype == torch.float32 and vm[0][0].shape == (3, 9, 10, 5) and vm[2] == 9
+    assert vm[1][0].dtype == torch.float32 and sorted(vm[1][0].tolist()) == [3.0, 5.0, 9.0]
+    assert radar[0].shape == (3, 81, 5) and adj[0].shape == (3, 81, 81)
+    assert tp.shape == (3, 2) and vel.shape == (3,) and gt.shape == (3, 4, 2) and gt.dtype == torch.float32
+    # waypoints[1:5] of sample 0 in file order
+    s0 = fixtures.synthetic_samples()[order[0]]
+    assert np.allclose(gt[0].numpy(), np.array(s0["waypoints"][1:5], dtype=np.float32))
+    # the prefetcher hands out the same thing
+    (args2, gt2), = list(D.DevicePrefetcher(loader, "cpu", cfg))
+    assert torch.equal(gt2, gt) and torch.equal(args2[0][0], fronts[0])

@@ -191,3 +191,42 @@ def test_segmented_graph_step_equals_eager_steps():
     sa, sb = net_a.state_dict(), net_b.state_dict()
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+def test_driving_session_equals_reference_pipeline(golden_dir):
+    """Batch-1 closed-loop entry (raw u8 frame + XYZI sweep + ragged lanes, hipGraph) == the agent's sequence:
+    oracle crop / y-flip / histogram on the CPU, then the oracle network, then control_pid."""
+    from mmfn_amd.inference import DrivingSession
+    from oracle import harness, preprocess
+    oracle, net, batch, args = _setup("vec", B=2)
+    harness.calibrate_bn(oracle, args)
+    net.load_state_dict(oracle.state_dict(), strict=True)
+    oracle.eval()
+    sess = DrivingSession(net, max_points=1 << 15, max_lanes=32)
+    eager = DrivingSession(net, max_points=1 << 15, max_lanes=32, use_graph=False)
+    rng = np.random.RandomState(0)
+    prev = None
+    for tick in range(3):
+        rgb = rng.randint(0, 256, (300, 400, 3)).astype(np.uint8)
+        pts = np.stack([rng.uniform(-20, 20, 6000), rng.uniform(-12, 28, 6000), rng.uniform(-3, 1, 6000),
+                        rng.uniform(0, 1, 6000)], 1).astype(np.float32)
+        L = [7, 3, 12][tick]
+        lanes = rng.randn(L, 10, 5).astype(np.float32)
+        tp, speed = (float(rng.randn() * 10), float(rng.randn() * 10)), float(rng.uniform(0, 8))
+        got = sess.predict(rgb, pts, lanes, tp, speed)
+        assert torch.equal(got, eager.predict(rgb, pts, lanes, tp, speed))
+        # reference-side pipeline on the CPU
+        sweep = pts if prev is None else np.append(pts, prev, axis=0)
+        prev = pts
+        flipped = sweep[:, :3].astype(np.float64).copy()
+        flipped[:, 1] *= -1
+        bev = torch.from_numpy(preprocess.lidar_histogram(flipped))[None]
+        img = torch.from_numpy(preprocess.crop_chw(rgb).astype(np.float32))[None]
+        vm = [[torch.from_numpy(lanes)[None]], [torch.tensor([float(L)])], L]
+        with torch.no_grad():
+            ref = oracle([img], [bev], None, vm, None, None, torch.tensor([tp], dtype=torch.float32), torch.tensor([speed]))
+        assert (got - ref).abs().max().item() <= 1e-4, tick
+    out = sess.run_step(rgb, pts, lanes, tp, speed)
+    assert set(out) == {"steer", "throttle", "brake", "pred_wp", "pid"} and -1.0 <= out["steer"] <= 1.0
+    with pytest.raises(ValueError):
+        sess.predict(rgb[:100], pts, lanes, tp, speed)

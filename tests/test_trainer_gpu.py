@@ -1,0 +1,120 @@
+"""Trainer / FusedAdamW / data staging on the GPU: reference-style loop equivalence, checkpoint formats, resume."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _net(seed_from=None):
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd import model as M
+    from oracle import harness
+    cfg = GlobalConfig(embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    net = M.MMFN(cfg, DEV)
+    net.load_state_dict((seed_from or harness.build_oracle("vec", dropout=0.0)).state_dict(), strict=True)
+    return net, cfg
+
+
+@pytest.fixture(scope="module")
+def store(tmp_path_factory):
+    from mmfn_amd import data as D
+    from mmfn_amd.config import GlobalConfig
+    from oracle import fixtures
+    root = tmp_path_factory.mktemp("pro_train")
+    samples = fixtures.synthetic_samples((5, 9, 3, 7), seed=3, radar_counts=(50, 81, 81, 20))
+    for i, s in enumerate(samples):
+        with open(root / ("%d.pkl" % i), "wb") as fd:
+            pickle.dump(s, fd)
+    return D.FrameStore(str(root), GlobalConfig(), "train")
+
+
+def test_fused_epoch_equals_reference_style_loop(store):
+    """Trainer.train(fused=True) == zero-grad / forward / F.l1_loss / backward / torch.optim.AdamW.step()."""
+    from mmfn_amd import data as D
+    from mmfn_amd.optim import FusedAdamW
+    from mmfn_amd.trainer import Trainer
+    from oracle import harness
+    oracle = harness.build_oracle("vec", dropout=0.0)
+    net_a, cfg = _net(oracle)
+    net_b, _ = _net(oracle)
+    loader = D.make_loader(store, batch_size=4, num_workers=0)  # one step per epoch
+    ta, tb = Trainer(DEV, None), Trainer(DEV, None)
+    opt_a, opt_b = FusedAdamW(net_a, lr=1e-4), torch.optim.AdamW(net_b.parameters(), lr=1e-4)
+    la = ta.train(net_a, loader, cfg, opt_a)
+    lb = tb.train(net_b, loader, cfg, opt_b, fused=False)
+    assert ta.cur_iter == tb.cur_iter == 1 and ta.cur_epoch == tb.cur_epoch == 1
+    assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb))
+    sa, sb = net_a.state_dict(), net_b.state_dict()
+    for k in sa:
+        if sa[k].dtype == torch.float32:
+            assert (sa[k] - sb[k]).abs().max().item() <= 2e-6 * max(1.0, sb[k].abs().max().item()), k
+    # second epoch: gradients at B=4 with these weights are ill-conditioned (test_e2e_gpu), so one-ulp differences
+    # after step one already move individual updates; the epoch losses still have to agree
+    la = ta.train(net_a, loader, cfg, opt_a)
+    lb = tb.train(net_b, loader, cfg, opt_b, fused=False)
+    assert abs(la - lb) <= 1e-4 * max(1.0, abs(lb)) and ta.train_loss[1] == la and ta.cur_iter == 2
+    # validate() == the reference's eval loop written out (phase2_train_net.py:124-177) on the same weights
+    va = ta.validate(net_a, loader, cfg)
+    net_a.eval()
+    ref, n = 0.0, 0
+    with torch.no_grad():
+        for batch in loader:
+            args, gt = D.stage_batch(batch, DEV, cfg)
+            ref += float(torch.nn.functional.l1_loss(net_a(*args), gt, reduction="none").mean())
+            n += 1
+    assert abs(va - ref / n) <= 1e-5 * max(1.0, abs(ref / n)) and ta.val_loss == [va]
+
+
+def test_checkpoint_files_and_resume(store, tmp_path):
+    from mmfn_amd import data as D
+    from mmfn_amd.optim import FusedAdamW
+    from mmfn_amd.trainer import Trainer
+    from oracle import harness
+    oracle = harness.build_oracle("vec", dropout=0.0)
+    loader = D.make_loader(store, batch_size=2, num_workers=0)
+    logdir = str(tmp_path / "log")
+
+    net, cfg = _net(oracle)
+    opt = FusedAdamW(net, lr=1e-4)
+    tr = Trainer(DEV, logdir)
+    tr.train(net, loader, cfg, opt)
+    tr.validate(net, loader, cfg)
+    assert tr.save(net, opt) is True
+    for f in ("recent.log", "best_model.pth", "best_optim.pth", "model.pth", "recent_optim.pth"):
+        assert os.path.isfile(os.path.join(logdir, f)), f
+    table = json.load(open(os.path.join(logdir, "recent.log")))
+    assert set(table) == {"epoch", "iter", "bestval", "bestval_epoch", "train_loss", "val_loss"} and table["epoch"] == 1
+
+    # the optimizer file is a torch.optim.AdamW state dict: torch loads it onto the same parameter list
+    osd = torch.load(os.path.join(logdir, "best_optim.pth"))
+    n_params = len(list(net.parameters()))
+    assert len(osd["param_groups"]) == 1 and osd["param_groups"][0]["params"] == list(range(n_params))
+    assert len(osd["state"]) == n_params - 21  # vec: raster-map stem + layer1 never get a gradient
+    ref_opt = torch.optim.AdamW(net.parameters(), lr=1e-4)
+    ref_opt.load_state_dict(osd)
+    w = dict(net.named_parameters())["encoder.image_encoder.features.conv1.weight"]
+    idx = [i for i, p in enumerate(net.parameters()) if p is w][0]
+    assert ref_opt.state[w]["exp_avg"].shape == w.shape == osd["state"][idx]["exp_avg"].shape
+    assert float(ref_opt.state[w]["step"]) == 2.0
+    # ... and the weights file holds the reference's keys
+    wsd = torch.load(os.path.join(logdir, "best_model.pth"))
+    assert list(wsd.keys()) == list(oracle.state_dict().keys())
+
+    # continue the original run for one more epoch; a fresh process resumes from disk and must land on the same weights
+    tr.train(net, loader, cfg, opt)
+    net2, _ = _net(oracle)
+    opt2 = FusedAdamW(net2, lr=5e-4)
+    tr2 = Trainer(DEV, logdir)
+    assert tr2.resume(net2, opt2) is True
+    assert tr2.cur_epoch == 1 and tr2.cur_iter == 2 and opt2.lr == 1e-4
+    tr2.train(net2, loader, cfg, opt2)
+    s1, s2 = net.state_dict(), net2.state_dict()
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
+    assert tr2.train_loss == tr.train_loss
