@@ -245,56 +245,77 @@ __global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const float* __restri
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
 
-template <int MAXPL>
+// One row per wave iteration; lane l owns VW consecutive columns per 64*VW-column chunk (4/8/16-byte accesses),
+// NCH chunks per row (C = 64 * VW * NCH).  Blocks are small (8 rows at M = 6144 -> 768 blocks) so the whole chip
+// streams rows; the per-block dweight / dbias partial rows are combined by colsum_finalize_kernel in fp64.
+template <int VW, int NCH>
 __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ dres, float* __restrict__ dx,
-                                                           float* __restrict__ partials /* [grid][2][C] */, int M, int C,
+                                                           float* __restrict__ partials /* [grid][2][C] */, int M,
                                                            int act, int rows_per_block) {
+  typedef float vec __attribute__((ext_vector_type(VW)));
+  constexpr int C = 64 * VW * NCH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pl = C >> 6;
-  float dw[MAXPL], db[MAXPL];
+  vec dw[NCH], db[NCH], wv[NCH], bv[NCH];
 #pragma unroll
-  for (int i = 0; i < MAXPL; ++i) { dw[i] = 0.f; db[i] = 0.f; }
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (i * 64 + lane) * VW;
+    wv[i] = *reinterpret_cast<const vec*>(w + c);
+    bv[i] = *reinterpret_cast<const vec*>(b + c);
+#pragma unroll
+    for (int j = 0; j < VW; ++j) { dw[i][j] = 0.f; db[i][j] = 0.f; }
+  }
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
   for (int row = r0 + wave; row < r1; row += NT / 64) {
     const float mu = mean[row], rs = rstd[row];
-    float a[MAXPL], xh[MAXPL];
+    vec a[NCH], xh[NCH];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXPL; ++i)
-      if (i < pl) {
-        const int c = lane + 64 * i;
-        const size_t off = (size_t)row * C + c;
-        xh[i] = (x[off] - mu) * rs;
-        float gg = g[off];
+    for (int i = 0; i < NCH; ++i) {
+      const size_t off = (size_t)row * C + (i * 64 + lane) * VW;
+      const vec xv = *reinterpret_cast<const vec*>(x + off);
+      vec gg = *reinterpret_cast<const vec*>(g + off);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        const float xhat = (xv[j] - mu) * rs;
+        float gj = gg[j];
         if (act != 0) {
-          const float pre = xh[i] * w[c] + b[c];
-          if (act == 1) gg = pre > 0.f ? gg : 0.f;
-          else gg *= mmfn_gelu_grad(pre);
+          const float pre = xhat * wv[i][j] + bv[i][j];
+          if (act == 1) gj = pre > 0.f ? gj : 0.f;
+          else gj *= mmfn_gelu_grad(pre);
         }
-        dw[i] += gg * xh[i];
-        db[i] += gg;
-        a[i] = gg * w[c];
-        c1 += a[i];
-        c2 += a[i] * xh[i];
+        dw[i][j] += gj * xhat;
+        db[i][j] += gj;
+        const float aj = gj * wv[i][j];
+        xh[i][j] = xhat;
+        a[i][j] = aj;
+        c1 += aj;
+        c2 += aj * xhat;
       }
+    }
     c1 = wave_sum(c1) / (float)C;
     c2 = wave_sum(c2) / (float)C;
 #pragma unroll
-    for (int i = 0; i < MAXPL; ++i)
-      if (i < pl) {
-        const size_t off = (size_t)row * C + lane + 64 * i;
-        float o = rs * (a[i] - c1 - xh[i] * c2);
-        if (dres) o += dres[off];
-        dx[off] = o;
-      }
-  }
-  __shared__ float red[2][NT / 64][64 * MAXPL];
+    for (int i = 0; i < NCH; ++i) {
+      const size_t off = (size_t)row * C + (i * 64 + lane) * VW;
+      vec o;
 #pragma unroll
-  for (int i = 0; i < MAXPL; ++i) { red[0][wave][lane + 64 * i] = dw[i]; red[1][wave][lane + 64 * i] = db[i]; }
+      for (int j = 0; j < VW; ++j) o[j] = rs * (a[i][j] - c1 - xh[i][j] * c2);
+      if (dres) o += *reinterpret_cast<const vec*>(dres + off);
+      *reinterpret_cast<vec*>(dx + off) = o;
+    }
+  }
+  __shared__ float red[2][NT / 64][C];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i)
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      red[0][wave][(i * 64 + lane) * VW + j] = dw[i][j];
+      red[1][wave][(i * 64 + lane) * VW + j] = db[i][j];
+    }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += NT) {
     float sw = 0.f, sb = 0.f;
@@ -418,13 +439,22 @@ extern "C" int mmfn_layernorm_fwd_f32(const float* x, const float* weight, const
 extern "C" int mmfn_layernorm_bwd_f32(const float* g, const float* x, const float* weight, const float* bias,
                                       const float* mean, const float* rstd, const float* dres, float* dx, float* dweight,
                                       float* dbias, int M, int C, int act, void* workspace, void* stream) {
-  if (C % 64 || C > 512 || M <= 0 || !workspace) return MMFN_EINVAL;
+  if (M <= 0 || !workspace) return MMFN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const int rpb = std::max(32, ceil_div(M, 256));
+  const int rpb = std::max(8, ceil_div(M, 768));
   const int nblk = ceil_div(M, rpb);
   float* partials = (float*)workspace;
-  hipLaunchKernelGGL(layernorm_bwd_kernel<8>, dim3(nblk), dim3(NT), 0, s, g, x, weight, bias, mean, rstd, dres, dx, partials,
-                     M, C, act, rpb);
+#define MMFN_LN_BWD(VW, NCH) \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<VW, NCH>), dim3(nblk), dim3(NT), 0, s, g, x, weight, bias, mean, rstd, dres, dx, \
+                     partials, M, act, rpb)
+  switch (C) {
+    case 64: MMFN_LN_BWD(1, 1); break;
+    case 128: MMFN_LN_BWD(2, 1); break;
+    case 256: MMFN_LN_BWD(4, 1); break;
+    case 512: MMFN_LN_BWD(4, 2); break;
+    default: return MMFN_EINVAL;  // the MMFN transformers / VectorNet use exactly these widths
+  }
+#undef MMFN_LN_BWD
   MMFN_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, partials, nblk, C, dweight, dbias);
   MMFN_LAUNCH_CHECK();
