@@ -31,6 +31,10 @@ int mmfn_device_selftest(void* stream);
 
 /* ---- utility ------------------------------------------------------------------------- */
 int mmfn_fill_f32(float* p, float v, int64_t n, void* stream);
+/* filter of the transposed convolution: w[Co][T][Ci] -> wt[Ci][T][Co], taps reversed.  With it the stride-1 data
+ * gradient (aten convolution_backward input grad under every torchvision BasicBlock conv, model_vec.py:509-593) is
+ * the forward implicit GEMM of dY with k-contiguous weights. */
+int mmfn_conv_weight_flip_f32(const float* w, float* wt, int Co, int T, int Ci, void* stream);
 /* y = a*x + b*y (b == 0 ignores the old y) */
 int mmfn_axpby_f32(float* y, const float* x, float a, float b, int64_t n, void* stream);
 /* out = y > 0 ? g : 0  (ReLU backward) */

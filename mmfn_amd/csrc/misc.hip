@@ -39,6 +39,35 @@ extern "C" int mmfn_device_selftest(void* stream) {
   return 0;
 }
 
+// w[Co][T][Ci] -> wt[Ci][T][Co] with the taps reversed (t -> T-1-t): the filter of the transposed convolution.
+// One 32x32 (co, ci) tile per block through LDS so both the read (ci contiguous) and the write (co contiguous)
+// are 128-byte runs.
+__global__ __launch_bounds__(256) void conv_weight_flip_kernel(const float* __restrict__ w, float* __restrict__ wt, int Co,
+                                                               int T, int Ci) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < Co && ci < Ci) ? w[((size_t)co * T + t) * Ci + ci] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < Ci && co < Co) wt[((size_t)ci * T + (T - 1 - t)) * Co + co] = tile[tx][r];
+  }
+}
+
+extern "C" int mmfn_conv_weight_flip_f32(const float* w, float* wt, int Co, int T, int Ci, void* stream) {
+  if (Co <= 0 || T <= 0 || Ci <= 0 || !w || !wt) return MMFN_EINVAL;
+  hipLaunchKernelGGL(conv_weight_flip_kernel, dim3((Ci + 31) / 32, (Co + 31) / 32, T), dim3(256), 0, (hipStream_t)stream, w, wt,
+                     Co, T, Ci);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmfn_fill_f32(float* p, float v, int64_t n, void* stream) {
   if (n <= 0) return 0;
   int blocks = (int)std::min<int64_t>((n + 255) / 256, 2048);
