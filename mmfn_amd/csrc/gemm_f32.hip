@@ -721,6 +721,53 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const mmfn_gemm_desc
   }
 }
 
+// Deep splits (first-layer weight gradients: K = B*OH*OW ~ 5e5, a handful of output tiles, 100+ slabs): 64 consecutive
+// elements per block, 16 waves each summing one z-chunk with coalesced 256-byte reads, then a fixed-order LDS combine.
+// (The flat kernel above walks all slabs serially per thread: 600 us for the 2-channel LiDAR stem.)
+__global__ __launch_bounds__(1024) void splitk_reduce_deep_kernel(const mmfn_gemm_desc d) {
+  __shared__ float part[16][64];
+  const size_t total = (size_t)d.M * d.N;
+  const int e = threadIdx.x & 63, zc = threadIdx.x >> 6;
+  const size_t idx = (size_t)blockIdx.x * 64 + e;
+  const int per = (d.splitk + 15) / 16;
+  const int z0 = zc * per, z1 = min(d.splitk, z0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (idx < total) {
+    const float* p = d.workspace + idx;
+    int z = z0;
+    for (; z + 3 < z1; z += 4) {
+      s0 += p[(size_t)z * total];
+      s1 += p[(size_t)(z + 1) * total];
+      s2 += p[(size_t)(z + 2) * total];
+      s3 += p[(size_t)(z + 3) * total];
+    }
+    for (; z < z1; ++z) s0 += p[(size_t)z * total];
+  }
+  part[zc][e] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (zc == 0 && idx < total) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += part[k][e];
+    uint64_t key = 0;
+    if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
+    const int row = (int)(idx / d.N), col = (int)(idx - (size_t)row * d.N);
+    epilogue_store(d, key, row, col, v);
+  }
+}
+
+void launch_splitk_reduce(const mmfn_gemm_desc& dd, hipStream_t s) {
+  const size_t total = (size_t)dd.M * dd.N;
+  if (dd.splitk >= 32 && total <= ((size_t)1 << 20)) {
+    hipLaunchKernelGGL(splitk_reduce_deep_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, s, dd);
+    return;
+  }
+  const bool vec = (dd.N & 3) == 0;
+  const size_t work = vec ? total / 4 : total;
+  const int blocks = (int)std::min<size_t>((work + 255) / 256 + 1, 4096);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, dd);
+}
+
 struct TileCand { int id, bm, bn; float eff; int target; };
 // id: 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128.  eff = measured relative MFMA efficiency of the
 // tile shape; target = resident blocks that saturate the chip (256 CUs x blocks/CU that fit).
@@ -792,9 +839,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
 #undef MMFN_LAUNCH_FAST
     MMFN_LAUNCH_CHECK();
     if (zdim > 1) {
-      const size_t total = (size_t)d.M * d.N;
-      const int blocks = (int)std::min<size_t>((total / 4 + 255) / 256 + 1, 4096);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, dd);
+      launch_splitk_reduce(dd, s);
       MMFN_LAUNCH_CHECK();
     }
     return 0;
@@ -813,9 +858,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
 #undef MMFN_LAUNCH_TILE
   MMFN_LAUNCH_CHECK();
   if (zdim > 1) {
-    const size_t total = (size_t)d.M * d.N;
-    const int blocks = (int)std::min<size_t>((total / 4 + 255) / 256 + 1, 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, dd);
+    launch_splitk_reduce(dd, s);
     MMFN_LAUNCH_CHECK();
   }
   return 0;
