@@ -246,7 +246,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": B * world, "parallelism": "dp%d" % world, "hipgraph": graph is not None,
-                   "branch_streams": 1 if args.single_stream else 3},
+                   "branch_streams": 1 if args.single_stream else eng.n_lanes},
         "loss": None if loss_val is None else round(loss_val, 6),
     }
     if rank == 0:

@@ -14,6 +14,8 @@ straight into the flat gradient buffer (each parameter has exactly one writer pe
 """
 import math
 
+import os
+
 import torch
 
 from . import ops
@@ -44,11 +46,31 @@ class Buffers(object):
 class Ctx(object):
     """Per-call execution context."""
 
-    def __init__(self, bufs, training, drop_p, rng_state):
+    def __init__(self, bufs, training, drop_p, rng_state, side=None):
         self.bufs = bufs
         self.training = training
         self.drop = drop_p if training else (0.0, 0.0, 0.0)  # (embd, attn, resid)
         self.rng_state = rng_state
+        self.side = side  # side stream for work that is off the critical path (weight gradients), or None
+
+    def offload(self, fn):
+        """Run fn (launches that only produce parameter gradients) on the side stream, ordered after everything
+        enqueued so far on the current stream.  Inline when no side stream is configured."""
+        if self.side is None:
+            return fn()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side), ops.lane(1):
+            fn()
+
+    def rejoin(self):
+        """Current stream waits for all offloaded work (before its input buffers are reused)."""
+        if self.side is None:
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.side)
+        torch.cuda.current_stream().wait_event(ev)
 
 
 # ----------------------------------------------------------------------------- conv + BN
@@ -281,36 +303,35 @@ class GPT(object):
             blk = self.blocks[i]
             sb = self.stream_base + 1 + 3 * i
             x, a, qkv, o, lse, x1, a2, h = self.acts[i]
+            # Weight / bias gradients only feed the optimizer, so they go to the side stream (ctx.offload) while the
+            # dX chain continues; the block-end rejoin keeps the shared scratch buffers (gh, dqkv, ...) safe to reuse.
             # ---- MLP branch: x2 = x1 + drop(fc2(relu(fc1(ln2(x1)))))
             gp = g
             if p_resid > 0.0:
                 gp = ops.dropout_apply(g, bufs.get(nm + ".gdrop", (M, C)), p_resid, ctx.rng_state, sb + 2)
-            ops.colsum(gp, blk["fc2"].gb)
-            ops.linear_dw(gp, h, out=blk["fc2"].gw)
+            ctx.offload(lambda gp=gp: (ops.colsum(gp, blk["fc2"].gb), ops.linear_dw(gp, h, out=blk["fc2"].gw)))
             gh = bufs.get(nm + ".gh", (M, 4 * C))
             ops.linear_dx(gp, blk["fc2"].w, out=gh, aux=h, ldaux=4 * C)
-            ops.colsum(gh, blk["fc1"].gb)
-            ops.linear_dw(gh, a2, out=blk["fc1"].gw)
+            ctx.offload(lambda: (ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
             ga2 = bufs.get(nm + ".ga", (M, C))
             ops.linear_dx(gh, blk["fc1"].w, out=ga2)
             g1 = blk["ln2"].bwd(ctx, ga2, dres=g, out=bufs.get(nm + ".g1", (M, C)))
             # ---- attention branch: x1 = x + drop(proj(att(ln1(x))))
             gp = g1
             if p_resid > 0.0:
-                gp = ops.dropout_apply(g1, bufs.get(nm + ".gdrop", (M, C)), p_resid, ctx.rng_state, sb + 1)
-            ops.colsum(gp, blk["proj"].gb)
-            ops.linear_dw(gp, o, out=blk["proj"].gw)
+                gp = ops.dropout_apply(g1, bufs.get(nm + ".gdrop2", (M, C)), p_resid, ctx.rng_state, sb + 1)
+            ctx.offload(lambda gp=gp: (ops.colsum(gp, blk["proj"].gb), ops.linear_dw(gp, o, out=blk["proj"].gw)))
             go = bufs.get(nm + ".go", (M, C))
             ops.linear_dx(gp, blk["proj"].w, out=go)
             dqkv = bufs.get(nm + ".dqkv", (M, 3 * C))
             delta = bufs.get(nm + ".delta", (B, nh, T))
             ops.attention_bwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, go, C, lse, delta, dqkv[:, C:], dqkv, dqkv[:, 2 * C:],
                               3 * C, B, T, nh, hs, scale, drop_p=p_attn, rng_state=ctx.rng_state, rng_stream=sb)
-            ops.colsum(dqkv, blk["g_bqkv"])
-            ops.linear_dw(dqkv, a, out=blk["g_wqkv"])
-            ga = bufs.get(nm + ".ga", (M, C))
+            ctx.offload(lambda: (ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
+            ga = bufs.get(nm + ".ga2", (M, C))
             ops.linear_dx(dqkv, blk["wqkv"], out=ga)
             g = blk["ln1"].bwd(ctx, ga, dres=g1, out=bufs.get(nm + ".g0_%d" % (i & 1), (M, C)))
+            ctx.rejoin()
         gtok = g.view(B, T, C)
         ops.tokens_bwd(gtok, self.velocity, self.g_pos.view(T, C), self.vel.gw.view(C), self.vel.gb, p_embd, ctx.rng_state,
                        self.stream_base)
@@ -677,6 +698,8 @@ class Engine(object):
         # gaps; captured into the hipGraph this becomes a fork/join DAG.
         self.side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         self.multi_stream = True
+        self.n_lanes = int(os.environ.get("MMFN_BRANCH_LANES", "2"))
+        self.offload_wgrad = os.environ.get("MMFN_OFFLOAD_WGRAD", "1") == "1"
 
     # ------------------------------------------------------------------ inputs
     def _bufs_for(self, B):
@@ -688,7 +711,8 @@ class Engine(object):
 
     def _ctx(self, B, training):
         cfg = self.cfg
-        return Ctx(self._bufs_for(B), training, (cfg.embd_pdrop, cfg.attn_pdrop, cfg.resid_pdrop), self.rng_state)
+        side = self.side[0] if (self.multi_stream and self.offload_wgrad and training) else None
+        return Ctx(self._bufs_for(B), training, (cfg.embd_pdrop, cfg.attn_pdrop, cfg.resid_pdrop), self.rng_state, side)
 
     def _ingest(self, ctx, inp):
         """inp: dict of device tensors -> NHWC network inputs."""
@@ -721,6 +745,19 @@ class Engine(object):
         fork = torch.cuda.Event()
         fork.record(main)
         outs = [None] * len(fns)
+        if self.n_lanes == 2:
+            # two lanes: the camera ResNet-34 alone on the main stream, LiDAR ResNet-18 + map branch back to back on
+            # the side stream (measured best on MI355X: the hipGraph runtime co-schedules two queues well, three badly)
+            st = self.side[0]
+            st.wait_event(fork)
+            with torch.cuda.stream(st), ops.lane(1):
+                for i in range(1, len(fns)):
+                    outs[i] = fns[i]()
+            outs[0] = fns[0]()
+            done = torch.cuda.Event()
+            done.record(st)
+            main.wait_event(done)
+            return outs
         for i, f in enumerate(fns[1:]):
             st = self.side[i]
             st.wait_event(fork)
