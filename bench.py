@@ -203,14 +203,22 @@ def main():
     graph = None
     if not args.no_graph and world == 1:
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             loss_buf = step()
         runner = graph.replay
     elif not args.no_graph:
         # multi-GPU: five graphs cut at the gradient-bucket boundaries, RCCL all-reduces in between
         from mmfn_amd.parallel import GraphedStep
-        graph = GraphedStep(eng, dp, inp, gt, lr=1e-4, warm=0)
-        runner = graph
+        try:
+            graph = GraphedStep(eng, dp, inp, gt, lr=1e-4, warm=0)
+            runner = graph
+        except Exception as exc:  # keep the run alive: eager launches give the same numbers' meaning, only slower
+            sys.stderr.write("rank %d: segmented hipGraph capture failed (%s: %s); falling back to eager launches\n"
+                             % (rank, type(exc).__name__, exc))
+            graph = None
+            torch.cuda.synchronize()
+            step()
+            torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:

@@ -92,7 +92,9 @@ class GraphedStep(object):
         self.graphs = []
         for fn in parts:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: RCCL's watchdog thread polls events while we capture; under the default global mode
+            # any such call from another thread invalidates the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 fn()
             self.graphs.append(g)
         self.loss = eng._bufs_for(inp["target_point"].shape[0]).get("head.loss", (1,))
