@@ -201,25 +201,32 @@ __global__ __launch_bounds__(NT) void upsample_add_fwd_kernel(const float* __res
 }
 
 // adjoint: gtok[b, m*64 + a, c] = sum_{pixels} weight(a, pixel) * G[b, pixel, c]
-// one thread per (b, anchor, c4); loops over the pixels whose bilinear footprint touches the anchor
+// YS threads per (b, anchor, c4) share the rows of the anchor's bilinear footprint (consecutive lanes, combined with
+// xor shuffles in a fixed order); with one thread per output the 64x64 maps ran 128 blocks of ~300 serial loads each.
+template <int YS>
 __global__ __launch_bounds__(NT) void upsample_adj_kernel(const float* __restrict__ G, float* __restrict__ gtok, int B, int S,
                                                           int C, int T, int m) {
   const int cq = C >> 2;
-  const int64_t total = (int64_t)B * 64 * cq;
+  const int64_t total = (int64_t)B * 64 * cq * YS;
   const float r = (S > 1) ? (float)(8 - 1) / (float)(S - 1) : 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % cq) * 4;
-    const int a = (int)((i / cq) % 64), b = (int)(i / cq / 64);
-    const int ay = a >> 3, ax = a & 7;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // grid covers `total` rounded up to the block size, so every lane of a shuffle group is alive
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < total;
+  const int64_t o = live ? i / YS : 0;
+  const int ys = (int)(i % YS);
+  const int c4 = (int)(o % cq) * 4;
+  const int a = (int)((o / cq) % 64), b = (int)(o / cq / 64);
+  const int ay = a >> 3, ax = a & 7;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
     if (S == 8) {
-      acc = *reinterpret_cast<const f32x4*>(G + ((size_t)(b * 8 + ay) * 8 + ax) * C + c4);
+      if (ys == 0) acc = *reinterpret_cast<const f32x4*>(G + ((size_t)(b * 8 + ay) * 8 + ax) * C + c4);
     } else {
       // pixels y with floor(r*y) in {ay-1, ay}
       const int step = (S - 1) / 7 + 2;
       const int ylo = max(0, (int)((float)(ay - 1) / r) - 1), yhi = min(S - 1, ylo + 2 * step + 2);
       const int xlo = max(0, (int)((float)(ax - 1) / r) - 1), xhi = min(S - 1, xlo + 2 * step + 2);
-      for (int y = ylo; y <= yhi; ++y) {
+      for (int y = ylo + ys; y <= yhi; y += YS) {
         const float h1r = r * (float)y;
         const int h1 = (int)h1r;
         const int h1p = (h1 < 7) ? 1 : 0;
@@ -244,8 +251,12 @@ __global__ __launch_bounds__(NT) void upsample_adj_kernel(const float* __restric
         }
       }
     }
-    *reinterpret_cast<f32x4*>(gtok + ((size_t)b * T + m * 64 + a) * C + c4) = acc;
   }
+#pragma unroll
+  for (int d = 1; d < YS; d <<= 1)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], d, 64);
+  if (live && ys == 0) *reinterpret_cast<f32x4*>(gtok + ((size_t)b * T + m * 64 + a) * C + c4) = acc;
 }
 
 // dF[b,y,x,c] = G[b,y,x,c] + gtok[b, m*64 + (y/k)*8 + x/k, c] / k^2      (avgpool adjoint + identity)
@@ -377,8 +388,13 @@ extern "C" int mmfn_upsample_add_fwd_f32(const float* feat, const float* tok, fl
 
 extern "C" int mmfn_upsample_adj_f32(const float* G, float* gtok, int B, int S, int C, int T, int m, void* stream) {
   if (C % 4) return MMFN_EINVAL;
-  hipLaunchKernelGGL(upsample_adj_kernel, dim3(grid_for((int64_t)B * 64 * (C / 4))), dim3(NT), 0, (hipStream_t)stream, G, gtok, B,
-                     S, C, T, m);
+  const int64_t outs = (int64_t)B * 64 * (C / 4);
+  if (S >= 32)
+    hipLaunchKernelGGL(upsample_adj_kernel<8>, dim3((unsigned)((outs * 8 + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, G, gtok,
+                       B, S, C, T, m);
+  else
+    hipLaunchKernelGGL(upsample_adj_kernel<1>, dim3((unsigned)((outs + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, G, gtok, B,
+                       S, C, T, m);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
