@@ -191,18 +191,23 @@ class DevicePrefetcher(object):
     dedicated copy stream while the current step computes (the reference copies synchronously inside the
     step, phase2_train_net.py:78-91)."""
 
-    def __init__(self, loader, device, config):
-        self.loader, self.device, self.config = loader, torch.device(device), config
+    def __init__(self, loader, device, config, variant="vec"):
+        self.loader, self.device, self.config, self.variant = loader, torch.device(device), config, variant
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 
     def __len__(self):
         return len(self.loader)
 
+    def _do_stage(self, data, non_blocking):
+        if "rgb_u8" in data:  # RawFrameStore / collate_raw batches
+            return stage_raw_batch(data, self.device, self.config, self.variant, non_blocking=non_blocking)
+        return stage_batch(data, self.device, self.config, non_blocking=non_blocking)
+
     def _stage(self, data):
         if self.stream is None:
-            return stage_batch(data, self.device, self.config, non_blocking=False), None
+            return self._do_stage(data, False), None
         with torch.cuda.stream(self.stream):
-            staged = stage_batch(_pin(data), self.device, self.config)
+            staged = self._do_stage(_pin(data), True)
             ready = torch.cuda.Event()
             ready.record(self.stream)
         return staged, ready
@@ -238,6 +243,10 @@ def _pin(obj):
 def _tensors(obj):
     if isinstance(obj, torch.Tensor):
         yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            for t in _tensors(v):
+                yield t
     elif isinstance(obj, (list, tuple)):
         for v in obj:
             for t in _tensors(v):
@@ -245,11 +254,157 @@ def _tensors(obj):
 
 
 def make_loader(store, batch_size, shuffle=False, sampler=None, num_workers=8, pin_memory=False):
-    """DataLoader with this module's collate (phase2_train_net.py:268-274)."""
+    """DataLoader with this module's collate (phase2_train_net.py:268-274); raw-route stores get collate_raw."""
+    fn = collate_raw if isinstance(store, RawFrameStore) else collate
     return torch.utils.data.DataLoader(store, batch_size=batch_size, shuffle=shuffle and sampler is None, sampler=sampler,
-                                       num_workers=num_workers, pin_memory=pin_memory, collate_fn=collate)
+                                       num_workers=num_workers, pin_memory=pin_memory, collate_fn=fn)
 
 
 def shard_sampler(store, rank, world, shuffle=True, seed=0):
     """Per-rank sample shard, as DistributedSampler does for the reference (phase2_train_net.py:265-266)."""
     return torch.utils.data.distributed.DistributedSampler(store, num_replicas=world, rank=rank, shuffle=shuffle, seed=seed)
+
+
+# ------------------------------------------------------------------------------------------ raw recorded routes (row f2)
+class RawFrameStore(torch.utils.data.Dataset):
+    """Reader of the recorded CARLA routes themselves (`CARLA_Data`, dataloader.py:11-268): <root>/<route>/{rgb_front,
+    maps,lidar,radar,vectormap,measurements}/NNNN.{png,npy,json}.  Frame indexing follows the reference exactly
+    (first frame of a route skipped, the last pred_len + 1 frames have no future waypoints, dataloader.py:72-75).
+
+    Unlike the reference, a sample carries the RAW sensor frames - the uint8 camera image as recorded and the XYZI
+    point list - because crop / normalise / y-flip / histogram run on the GPU inside the network's ingest kernels
+    (csrc/ingest.hip); the host only decodes files and does the O(10) pose arithmetic.  seq_len must be 1."""
+
+    def __init__(self, roots, config):
+        if config.seq_len != 1:
+            raise NotImplementedError("raw-route reader is built for seq_len = 1 (the reference's configuration)")
+        self.seq_len, self.pred_len = config.seq_len, config.pred_len
+        self.frames = []
+        for sub_root in ([roots] if isinstance(roots, str) else list(roots)):
+            for route in sorted(os.listdir(sub_root)):
+                route_dir = os.path.join(sub_root, route)
+                if os.path.isfile(route_dir):
+                    continue
+                n = (len(os.listdir(os.path.join(route_dir, "rgb_front"))) - self.pred_len - 2) // self.seq_len
+                for seq in range(n):
+                    ids = ["%04d" % (seq * self.seq_len + 1 + i) for i in range(self.seq_len + self.pred_len)]
+                    meas = [_read_json(os.path.join(route_dir, "measurements", k + ".json")) for k in ids]
+                    cur = meas[self.seq_len - 1]
+                    thetas = [m["theta"] for m in meas]
+                    # (the reference zeroes a NaN heading only for the future frames at scan time and for the current
+                    # ones at load time, dataloader.py:133-137,224-226: same effect)
+                    thetas = [0.0 if np.isnan(t) else t for t in thetas]
+                    self.frames.append({
+                        "rgb": os.path.join(route_dir, "rgb_front", ids[0] + ".png"),
+                        "map": os.path.join(route_dir, "maps", ids[0] + ".png"),
+                        "lidar": os.path.join(route_dir, "lidar", ids[0] + ".npy"),
+                        "radar": os.path.join(route_dir, "radar", ids[0] + ".npy"),
+                        "vectormap": os.path.join(route_dir, "vectormap", ids[0] + ".npy"),
+                        "x": [m["x"] for m in meas], "y": [m["y"] for m in meas], "theta": thetas,
+                        "x_command": cur["x_command"], "y_command": cur["y_command"], "steer": cur["steer"],
+                        "throttle": cur["throttle"], "brake": cur["brake"], "command": cur["command"], "velocity": cur["speed"],
+                    })
+
+    def __len__(self):
+        return len(self.frames)
+
+    def __getitem__(self, i):
+        from PIL import Image
+        f = self.frames[i]
+        vm = f["vectormap"]
+        j = i
+        while not os.path.exists(vm):  # frames recorded without a lane file borrow a neighbour's (dataloader.py:199-207)
+            j = j - 1 if j - 1 >= 0 else j + 1
+            vm = self.frames[j]["vectormap"]
+        ego = self.seq_len - 1
+        sample = {
+            "rgb_u8": torch.from_numpy(np.ascontiguousarray(np.asarray(Image.open(f["rgb"]).convert("RGB"), dtype=np.uint8))),
+            "lidar_pts": torch.from_numpy(np.load(f["lidar"]).astype(np.float32)[:, :4]),
+            "vectormaps": [torch.from_numpy(np.load(vm))],
+            "radar": [radar_to_size(np.load(f["radar"]))],
+            "waypoints": local_waypoints(f["x"], f["y"], f["theta"], ego),
+            "target_point": local_target_point(f["x_command"], f["y_command"], f["x"][ego], f["y"][ego], f["theta"][ego]),
+            "steer": f["steer"], "throttle": f["throttle"], "brake": f["brake"], "command": f["command"], "velocity": f["velocity"],
+        }
+        if os.path.exists(f["map"]):
+            sample["maps"] = [torch.from_numpy(np.ascontiguousarray(np.transpose(np.asarray(Image.open(f["map"])), (2, 0, 1))))]
+        sample["radar_adj"] = radar_adjacency(sample["radar"][0])
+        return sample
+
+
+def _read_json(path):
+    import json
+    with open(path) as f:
+        return json.load(f)
+
+
+FAR_POINT = 1.0e6  # padding x coordinate: outside every histogram bin (np.histogramdd ignores it the same way)
+
+
+def collate_raw(samples):
+    """RawFrameStore samples -> batch with `rgb_u8` [B,H,W,3] u8 and `lidar_pts` [B,Nmax,4] padded with far points;
+    everything else as `collate`."""
+    rest = [{k: v for k, v in s.items() if k not in ("rgb_u8", "lidar_pts")} for s in samples]
+    out = collate(rest)
+    out["rgb_u8"] = torch.stack([s["rgb_u8"] for s in samples], 0)
+    nmax = max(int(s["lidar_pts"].shape[0]) for s in samples)
+    nmax = (nmax + 1023) // 1024 * 1024  # few distinct shapes -> few buffer sets / graph captures downstream
+    pts = torch.zeros(len(samples), nmax, 4, dtype=torch.float32)
+    pts[:, :, 0] = FAR_POINT
+    for b, s in enumerate(samples):
+        p = s["lidar_pts"]
+        pts[b, :p.shape[0], :p.shape[1]] = p
+    out["lidar_pts"] = pts
+    return out
+
+
+def stage_raw_batch(data, device, config, variant="vec", non_blocking=True):
+    """collate_raw batch -> (Engine input dict, gt_waypoints) on `device`: the frames stay uint8 / XYZI; the y flip of
+    dataloader.py:233 is requested from the splat kernel."""
+    dev = torch.device(device)
+    to = lambda t, dt=None: torch.as_tensor(t).to(dt or torch.as_tensor(t).dtype).to(dev, non_blocking=non_blocking)
+    lane, lane_num, _ = data["vectormaps"][0]
+    inp = {
+        "rgb_u8": to(data["rgb_u8"]), "lidar_pts": to(data["lidar_pts"]), "lidar_flip_y": True,
+        "target_point": to(torch.stack(list(data["target_point"]), dim=1), torch.float32),
+        "velocity": to(data["velocity"], torch.float32),
+    }
+    if variant == "img":
+        inp["map"] = to(data["maps"][0]).to(torch.float32)
+    else:
+        inp["lane"] = to(lane, torch.float32)
+        inp["lane_num"] = to(lane_num, torch.int32)
+    if variant == "rad":
+        inp["radar"] = to(data["radar"][0], torch.float32)
+        inp["radar_adj"] = to(data["radar_adj"], torch.float32)
+    wps = data["waypoints"]
+    n = config.seq_len
+    gt = torch.stack([torch.stack(list(wps[i]), dim=1) for i in range(n, len(wps))], dim=1)
+    return inp, to(gt, torch.float32)
+
+
+def preprocess_routes(store, out_dir, device, batch_size=16):
+    """Phase 1 on the GPU (run_steps/phase1_preprocess_data.py:42-48): RawFrameStore -> one PRE_Data pickle per frame, with
+    the camera crop and the LiDAR histogram produced by the ingest kernels.  Returns the number of files written."""
+    from . import ops
+    os.makedirs(out_dir, exist_ok=True)
+    dev = torch.device(device)
+    n = 0
+    for start in range(0, len(store), batch_size):
+        samples = [store[i] for i in range(start, min(len(store), start + batch_size))]
+        batch = collate_raw(samples)
+        pts = batch["lidar_pts"].to(dev)
+        bev = ops.lidar_splat(pts, torch.empty(len(samples), 256, 256, 2, device=dev), flip_y=True).permute(0, 3, 1, 2).cpu().numpy()
+        for k, s in enumerate(samples):
+            rgb = s["rgb_u8"].numpy()
+            H, W = rgb.shape[:2]
+            crop = rgb[H // 2 - 128:H // 2 + 128, W // 2 - 128:W // 2 + 128]
+            rec = {key: s[key] for key in ("vectormaps", "radar", "waypoints", "target_point", "steer", "throttle", "brake", "command",
+                                           "velocity") if key in s}
+            rec["fronts"] = [torch.from_numpy(np.ascontiguousarray(np.transpose(crop, (2, 0, 1))))]
+            rec["lidars"] = [np.ascontiguousarray(bev[k])]
+            rec["maps"] = s.get("maps", [torch.zeros(3, 256, 256, dtype=torch.uint8)])
+            with open(os.path.join(out_dir, "%d.pkl" % (start + k)), "wb") as fd:
+                pickle.dump(rec, fd)
+            n += 1
+    return n

@@ -42,14 +42,15 @@ class Trainer(object):
         total = torch.zeros(1, dtype=torch.float32, device=model._layout.device)
         window = torch.zeros_like(total)
         num_batches = 0
-        for args, gt in D.DevicePrefetcher(dataloader_train, self.device, config):
+        for args, gt in D.DevicePrefetcher(dataloader_train, self.device, config, variant=model.variant):
             if fused:
                 g = optimizer.param_groups[0]
-                loss = eng.train_step(model._pack(*args), gt, lr=g["lr"], dp=dp, betas=tuple(g["betas"]), eps=g["eps"],
+                inp = args if isinstance(args, dict) else model._pack(*args)  # raw-frame batches are engine inputs already
+                loss = eng.train_step(inp, gt, lr=g["lr"], dp=dp, betas=tuple(g["betas"]), eps=g["eps"],
                                       weight_decay=g["weight_decay"])
             else:
-                if dp is not None:
-                    raise NotImplementedError("the autograd path is single-GPU; use fused=True under data parallelism")
+                if dp is not None or isinstance(args, dict):
+                    raise NotImplementedError("the autograd path takes reference-format batches on one GPU; use fused=True")
                 for p in model.parameters():
                     p.grad = None
                 pred = model(*args)
@@ -75,8 +76,8 @@ class Trainer(object):
         total = torch.zeros(1, dtype=torch.float32, device=model._layout.device)
         num_batches = 0
         with torch.no_grad():
-            for args, gt in D.DevicePrefetcher(dataloader_val, self.device, config):
-                _, loss = eng.forward(model._pack(*args), False, gt)
+            for args, gt in D.DevicePrefetcher(dataloader_val, self.device, config, variant=model.variant):
+                _, loss = eng.forward(args if isinstance(args, dict) else model._pack(*args), False, gt)
                 total += loss
                 num_batches += 1
         if num_batches:

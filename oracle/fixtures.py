@@ -118,3 +118,35 @@ def synthetic_samples(lane_counts=(5, 9, 3), seed=11, radar_counts=(50, 100, 81)
             "command": int(rng.randint(1, 5)), "velocity": float(rng.uniform(0, 8)),
         })
     return out
+
+
+def write_synthetic_route(root, seed=21, n_frames=9, route="route00"):
+    """A recorded-route folder in the layout CARLA_Data scans (dataloader.py:64-139): rgb_front/ maps/ lidar/ radar/
+    vectormap/ measurements/ with NNNN.{png,npy,json}, frames 0000..n_frames-1.  Deterministic in `seed`."""
+    import json
+    import os
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    d = os.path.join(root, route)
+    for sub in ("rgb_front", "maps", "lidar", "radar", "vectormap", "measurements"):
+        os.makedirs(os.path.join(d, sub), exist_ok=True)
+    x = y = 0.0
+    theta = 0.3
+    for i in range(n_frames):
+        k = "%04d" % i
+        Image.fromarray(rng.randint(0, 256, (300, 400, 3)).astype(np.uint8)).save(os.path.join(d, "rgb_front", k + ".png"))
+        Image.fromarray(rng.randint(0, 256, (256, 256, 3)).astype(np.uint8)).save(os.path.join(d, "maps", k + ".png"))
+        n = 3000 + 100 * i
+        pts = np.stack([rng.uniform(-20, 20, n), rng.uniform(-12, 28, n), rng.uniform(-3, 1, n), rng.uniform(0, 1, n)], 1).astype(np.float32)
+        np.save(os.path.join(d, "lidar", k + ".npy"), pts)
+        rad = rng.randn(40 + 15 * i, 5)
+        rad[:, 3] = np.abs(rad[:, 3]) + 0.5
+        np.save(os.path.join(d, "radar", k + ".npy"), rad)
+        np.save(os.path.join(d, "vectormap", k + ".npy"), rng.randn(3 + i, 10, 5))
+        x, y, theta = x + rng.uniform(0.5, 1.5), y + rng.uniform(-0.3, 0.3), theta + rng.uniform(-0.05, 0.05)
+        meas = {"x": x, "y": y, "theta": theta, "x_command": x + 20.0, "y_command": y - 5.0, "steer": float(rng.uniform(-1, 1)),
+                "throttle": float(rng.uniform(0, 0.75)), "brake": bool(i % 3 == 0), "command": int(rng.randint(1, 5)),
+                "speed": float(rng.uniform(0, 8))}
+        with open(os.path.join(d, "measurements", k + ".json"), "w") as f:
+            json.dump(meas, f)
+    return d

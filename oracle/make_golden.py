@@ -15,6 +15,7 @@ histogram, crop, radar_to_size, PID) executes the reference's own source.
 
 Usage:  python oracle/make_golden.py
 """
+import hashlib
 import os
 import sys
 import types
@@ -267,6 +268,30 @@ def dataio_vectors(ref_dl, ref_du, out_dir):
     np.savez_compressed(os.path.join(out_dir, "dataio.npz"), **res)
 
 
+def raw_route_vectors(ref_dl, ref_cfg, out_dir):
+    """CARLA_Data (dataloader.py:11-268) run on the synthetic recorded route of fixtures.write_synthetic_route."""
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        fixtures.write_synthetic_route(tmp)
+        cfg = ref_cfg.GlobalConfig()
+        ds = ref_dl.CARLA_Data([tmp], cfg)
+        res["n"] = np.int64(len(ds))
+        for i in range(len(ds)):
+            s = ds[i]
+            # uint8 frames are incompressible noise: keep their SHA-256 (exact comparison) instead of 200 KB each
+            res["fronts%d_sha" % i] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(s["fronts"][0].numpy()).tobytes()).digest(), dtype=np.uint8)
+            res["fronts%d_shape" % i] = np.array(s["fronts"][0].shape)
+            res["lidars%d" % i] = s["lidars"][0]
+            res["maps%d_sha" % i] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(s["maps"][0].numpy()).tobytes()).digest(), dtype=np.uint8)
+            res["lanes%d" % i] = s["vectormaps"][0].numpy()
+            res["radar%d" % i] = s["radar"][0]
+            res["waypoints%d" % i] = np.array(s["waypoints"])
+            res["target%d" % i] = np.array(s["target_point"])
+            res["labels%d" % i] = np.array([s["steer"], s["throttle"], float(s["brake"]), float(s["command"]), s["velocity"]])
+    np.savez_compressed(os.path.join(out_dir, "raw_route.npz"), **res)
+
+
 def pid_vectors(ref_models, ref_cfg, out_dir):
     cfg = ref_cfg.GlobalConfig()
     # control_pid only touches config + the two PID controllers; avoid building a 105 M-param net
@@ -306,6 +331,7 @@ def main():
     torch.set_num_threads(8)
     preprocessing_vectors(ref_dl, ref_du, out_dir)
     dataio_vectors(ref_dl, ref_du, out_dir)
+    raw_route_vectors(ref_dl, ref_cfg, out_dir)
     if "--only-io" in sys.argv:
         return
     pid_vectors(ref_models, ref_cfg, out_dir)

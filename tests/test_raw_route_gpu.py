@@ -1,0 +1,82 @@
+"""Recorded-route reader + GPU phase 1 against the reference's CARLA_Data run on the same
+synthetic route (tests/golden/raw_route.npz, made by oracle/make_golden.py)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def route(tmp_path_factory):
+    from oracle import fixtures
+    root = tmp_path_factory.mktemp("routes")
+    fixtures.write_synthetic_route(str(root))
+    return str(root)
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+
+
+def test_raw_store_and_gpu_phase1_match_reference(route, golden_dir, tmp_path):
+    from mmfn_amd import data as D
+    from mmfn_amd.config import GlobalConfig
+    g = np.load(os.path.join(golden_dir, "raw_route.npz"))
+    cfg = GlobalConfig()
+    store = D.RawFrameStore([route], cfg)
+    assert len(store) == int(g["n"]) == 3
+    for i in range(len(store)):
+        s = store[i]
+        assert s["rgb_u8"].shape == (300, 400, 3) and s["rgb_u8"].dtype == torch.uint8
+        assert np.array_equal(s["vectormaps"][0].numpy(), g["lanes%d" % i])
+        assert np.array_equal(s["radar"][0], g["radar%d" % i])
+        assert np.abs(np.array(s["waypoints"]) - g["waypoints%d" % i]).max() <= 1e-12
+        assert np.abs(np.array(s["target_point"]) - g["target%d" % i]).max() <= 1e-12
+        lab = np.array([s["steer"], s["throttle"], float(s["brake"]), float(s["command"]), s["velocity"]])
+        assert np.array_equal(lab, g["labels%d" % i])
+        assert np.array_equal(_sha(s["maps"][0].numpy()), g["maps%d_sha" % i])
+    # phase 1 on the GPU: crop by slicing, histogram (with the y flip) by the splat kernel -> PRE_Data pickles
+    out = str(tmp_path / "pro_train")
+    assert D.preprocess_routes(store, out, DEV, batch_size=2) == 3
+    pre = D.PRE_Data(out, cfg, "train")
+    by_index = {int(os.path.basename(f).split(".")[0]): k for k, f in enumerate(pre.files)}
+    for i in range(3):
+        s = pre[by_index[i]]
+        assert np.array_equal(_sha(s["fronts"][0].numpy()), g["fronts%d_sha" % i])
+        assert list(s["fronts"][0].shape) == list(g["fronts%d_shape" % i])
+        assert s["lidars"][0].dtype == np.float32 and np.array_equal(s["lidars"][0], g["lidars%d" % i])
+
+
+def test_training_from_raw_frames_equals_training_from_pickles(route, tmp_path):
+    """The same two frames through (a) RawFrameStore -> GPU ingest inside the step and (b) GPU phase 1 -> PRE_Data ->
+    tensors: identical loss and weights after one fused step."""
+    from mmfn_amd import data as D
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd.model import MMFN
+    from mmfn_amd.optim import FusedAdamW
+    from mmfn_amd.trainer import Trainer
+    from oracle import harness
+    cfg = GlobalConfig(embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    oracle = harness.build_oracle("vec", dropout=0.0)
+    store = D.RawFrameStore([route], cfg)
+    out = str(tmp_path / "pro")
+    D.preprocess_routes(store, out, DEV)
+    pre = D.PRE_Data(out, cfg, "train")
+    order = [int(os.path.basename(f).split(".")[0]) for f in pre.files]
+    raw_loader = torch.utils.data.DataLoader(torch.utils.data.Subset(store, order), batch_size=3, collate_fn=D.collate_raw)
+    pre_loader = D.make_loader(pre, batch_size=3, num_workers=0)
+    nets = []
+    for loader in (raw_loader, pre_loader):
+        net = MMFN(cfg, DEV)
+        net.load_state_dict(oracle.state_dict(), strict=True)
+        tr = Trainer(DEV, None)
+        loss = tr.train(net, loader, cfg, FusedAdamW(net, lr=1e-4))
+        nets.append((loss, net.state_dict()))
+    assert nets[0][0] == nets[1][0]
+    for k in nets[0][1]:
+        assert torch.equal(nets[0][1][k], nets[1][1][k]), k
