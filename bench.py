@@ -102,7 +102,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(batch=8, steps=3, warmup=1, budget_s=40.0):
+def cpu_baseline(batch=8, steps=10, warmup=1, budget_s=25.0):
     """The oracle's train step (fwd + L1 + bwd + AdamW, fp32) on the host cores."""
     from oracle import fixtures, harness
     threads = usable_cores()
