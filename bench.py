@@ -154,6 +154,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # host-side tensor ops (synthetic inputs, parameter init) must not fan out over every logical CPU of the box in
+    # every rank: under a cgroup quota the spinning OpenMP workers get the whole process throttled
+    torch.set_num_threads(max(1, min(8, usable_cores() // max(1, world))))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if os.environ.get("MMFN_BENCH_SINGLE_DEVICE"):  # CI on a 1-GPU box: all ranks share cuda:0 (with gloo, see below)
