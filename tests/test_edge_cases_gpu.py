@@ -1,0 +1,101 @@
+"""Edge cases of the input formats: batch 1, a single lane, many lanes, the lane-count limit, an empty LiDAR sweep,
+radar lists shorter/longer than 81 rows."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _pair(variant="vec", B=2, lanes=9, dropout=0.0):
+    from test_e2e_gpu import _setup
+    return _setup(variant, B=B, lanes=lanes, dropout=dropout)
+
+
+def _dev(args):
+    from test_e2e_gpu import _dev_args
+    return _dev_args(args)
+
+
+def test_batch_of_one_trains_like_the_oracle():
+    """B=1: BatchNorm statistics over the pixels of a single sample; loss and waypoints still match the CPU path."""
+    from oracle import harness
+    oracle, net, batch, args = _pair(B=1)
+    pred_ref, loss_ref, _ = harness.train_step(oracle, args, batch["gt_wp"])
+    net.train()
+    pred = net(*_dev(args))
+    loss = torch.nn.functional.l1_loss(pred, batch["gt_wp"].to(DEV), reduction="none").mean()
+    loss.backward()
+    assert (pred.detach().cpu() - pred_ref).abs().max().item() <= 1e-4
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("lanes", [1, 150])
+def test_lane_count_extremes_match_the_oracle(lanes):
+    from oracle import harness
+    oracle, net, batch, args = _pair(lanes=lanes)
+    harness.calibrate_bn(oracle, args)
+    net.load_state_dict(oracle.state_dict(), strict=True)
+    net.eval()
+    with torch.no_grad():
+        ref = oracle(*args)
+        got = net(*_dev(args)).cpu()
+    assert (got - ref).abs().max().item() <= 1e-4
+
+
+def test_more_than_256_lanes_is_rejected_cleanly():
+    from mmfn_amd._lib import MMFNLibraryError
+    oracle, net, batch, args = _pair(lanes=9)
+    img, lid, maps, vm, radar, adj, tp, vel = _dev(args)
+    wide = torch.zeros(2, 300, 10, 5, device=DEV)
+    wide[:, :9] = vm[0][0]
+    vm2 = [[wide], [torch.tensor([300.0, 9.0], device=DEV)], 300]
+    net.eval()
+    with torch.no_grad(), pytest.raises(MMFNLibraryError):
+        net(img, lid, maps, vm2, radar, adj, tp, vel)
+    with torch.no_grad():  # the module is still usable afterwards
+        assert torch.isfinite(net(img, lid, maps, vm, radar, adj, tp, vel)).all()
+
+
+def test_empty_lidar_sweep_gives_an_all_zero_bev_and_finite_outputs():
+    from mmfn_amd import ops
+    pts = torch.full((2, 4096, 4), 1e6, device=DEV)
+    bev = ops.lidar_splat(pts, torch.empty(2, 256, 256, 2, device=DEV))
+    assert bev.abs().max().item() == 0.0
+    oracle, net, batch, args = _pair()
+    net.eval()
+    dargs = _dev(args)
+    inp = net._pack(*dargs)
+    inp = dict(inp)
+    del inp["lidar"]
+    inp["lidar_pts"] = pts
+    with torch.no_grad():
+        pred, _ = net._engine_for().forward(inp, False, None)
+    assert torch.isfinite(pred).all()
+
+
+def test_radar_lists_of_any_length_feed_the_rad_model():
+    from mmfn_amd import data as D
+    from oracle import harness, preprocess
+    oracle, net, batch, args = _pair("rad")
+    rng = np.random.RandomState(5)
+    for n in (0, 3, 81, 200):
+        raw = rng.randn(n, 5)
+        if n:
+            raw[:, 3] = np.abs(raw[:, 3]) + 0.5
+        r = D.radar_to_size(raw)
+        assert r.shape == (81, 5) and np.array_equal(r, preprocess.radar_to_size(raw))
+        assert np.array_equal(D.radar_adjacency(r), preprocess.radar_adjacency(r))
+    harness.calibrate_bn(oracle, args)
+    net.load_state_dict(oracle.state_dict(), strict=True)
+    net.eval()
+    img, lid, maps, vm, radar, adj, tp, vel = args
+    r = torch.stack([torch.from_numpy(D.radar_to_size(rng.randn(3, 5))), torch.from_numpy(D.radar_to_size(np.abs(rng.randn(200, 5)) + 0.5))]).float()
+    a = torch.stack([torch.from_numpy(D.radar_adjacency(x.numpy())) for x in r]).float()
+    args2 = (img, lid, maps, vm, [r], [a], tp, vel)
+    with torch.no_grad():
+        ref = oracle(*args2)
+        got = net(*_dev(args2)).cpu()
+    assert (got - ref).abs().max().item() <= 1e-4
