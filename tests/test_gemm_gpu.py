@@ -100,3 +100,29 @@ def test_conv_forms(cfg, tile):
     _close(dw.permute(0, 3, 1, 2), wr.grad)
     dw2 = ops.conv2d_wgrad(dy_nhwc, x_nhwc, tuple(w_ohwi.shape), s, p, tile=tile, splitk=4)
     _close(dw2.permute(0, 3, 1, 2), wr.grad)
+
+
+@pytest.mark.parametrize("cfg", [(3, 16, 16, 256, 256), (2, 8, 8, 512, 512), (1, 4, 6, 256, 512)])
+def test_winograd_conv_and_dgrad(cfg):
+    """Winograd F(2x2,3x3) path (taken from 256 channels up) against torch and against the implicit-GEMM path."""
+    from mmfn_amd import ops
+    dev = _dev()
+    B, H, W, Cin, Cout = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, w, padding=1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    w_ohwi = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    dy_nhwc = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    assert ops.winograd_ok(x_nhwc.shape, w_ohwi.shape, 1, 1, {})
+    y = ops.conv2d_fwd(x_nhwc, w_ohwi, 1, 1)
+    _close(y.permute(0, 3, 1, 2), y_ref.detach())
+    direct = ops.conv2d_fwd(x_nhwc, w_ohwi, 1, 1, tile=1)  # explicit tile -> implicit GEMM
+    assert (y - direct).abs().max().item() <= 2e-5 * direct.abs().max().item()
+    res = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    dx = ops.conv2d_dgrad(dy_nhwc, w_ohwi, tuple(x_nhwc.shape), 1, 1, res=res, ldr=Cin)
+    _close((dx - res).permute(0, 3, 1, 2), xr.grad)
