@@ -36,13 +36,14 @@ int mmfn_fill_f32(float* p, float v, int64_t n, void* stream);
  * the forward implicit GEMM of dY with k-contiguous weights. */
 int mmfn_conv_weight_flip_f32(const float* w, float* wt, int Co, int T, int Ci, void* stream);
 
-/* ---- Winograd F(2x2,3x3) transforms for the 3x3 stride-1 convolutions of ResNet layer3/4 (cuDNN's choice under the same
- * aten::convolution calls, model_vec.py:509-593).  conv = output_tf( batched GEMM over t of V[t] . U[t]^T ):
- *   U[16][Co][Ci] = G w G^T,  V[16][tiles][C] = B^T x B  (tiles = B*(H/2)*(W/2), zero padding 1),
- *   y = A^T Mt A (+ res, NHWC like y).  H and W even, C % 4 == 0. */
-int mmfn_wino_weight_f32(const float* w, float* U, int Co, int Ci, void* stream);
-int mmfn_wino_input_f32(const float* x, float* V, int B, int H, int W, int C, void* stream);
-int mmfn_wino_output_f32(const float* Mt, const float* res, float* y, int B, int H, int W, int C, void* stream);
+/* ---- Winograd F(m x m, 3x3) transforms, m = 2 or 4, for the 3x3 stride-1 convolutions of ResNet layer3/4 (cuDNN's choice
+ * under the same aten::convolution calls, model_vec.py:509-593).  n = (m+2)^2 element-wise products:
+ *   conv = output_tf( batched GEMM over t < n of V[t] . U[t]^T ),
+ *   U[n][Co][Ci] = G w G^T,  V[n][tiles][C] = B^T x B  (tiles = B*(H/m)*(W/m), zero padding 1),
+ *   y = A^T Mt A (+ res, NHWC like y).  H and W multiples of m, C % 4 == 0. */
+int mmfn_wino_weight_f32(const float* w, float* U, int Co, int Ci, int m, void* stream);
+int mmfn_wino_input_f32(const float* x, float* V, int B, int H, int W, int C, int m, void* stream);
+int mmfn_wino_output_f32(const float* Mt, const float* res, float* y, int B, int H, int W, int C, int m, void* stream);
 /* y = a*x + b*y (b == 0 ignores the old y) */
 int mmfn_axpby_f32(float* y, const float* x, float a, float b, int64_t n, void* stream);
 /* out = y > 0 ? g : 0  (ReLU backward) */

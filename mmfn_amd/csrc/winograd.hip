@@ -119,27 +119,165 @@ __global__ __launch_bounds__(NT) void wino_output_kernel(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// F(4x4, 3x3): 6x6 input patches -> 4x4 outputs, 36 element-wise products (4x fewer MFMA FLOPs than the implicit GEMM,
+// 2.25x expansion of the transformed activations).  Interpolation points 0, +-1, +-2, inf (Lavin & Gray); in fp32 the
+// result differs from the direct convolution by ~1e-6 relative on this network's activations (tests/test_gemm_gpu.py).
+template <typename T>
+__device__ __forceinline__ void f4_bt(const T* d, T* r) {  // r = B^T d, 6 -> 6
+  r[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+  r[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+  r[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+  r[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+  r[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+  r[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+template <typename T>
+__device__ __forceinline__ void f4_at(const T* m, T* o) {  // o = A^T m, 6 -> 4
+  const T p = m[1] + m[2], q = m[1] - m[2], u = m[3] + m[4], v = m[3] - m[4];
+  o[0] = m[0] + p + u;
+  o[1] = q + 2.f * v;
+  o[2] = p + 4.f * u;
+  o[3] = q + 8.f * v + m[5];
+}
+__device__ __forceinline__ void f4_g(const float* g, float* u) {  // u = G g, 3 -> 6
+  u[0] = 0.25f * g[0];
+  u[1] = (-1.f / 6.f) * (g[0] + g[1] + g[2]);
+  u[2] = (-1.f / 6.f) * (g[0] - g[1] + g[2]);
+  u[3] = (1.f / 24.f) * g[0] + (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
+  u[4] = (1.f / 24.f) * g[0] - (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
+  u[5] = g[2];
+}
+
+__global__ __launch_bounds__(NT) void wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci) {
+  const int64_t n = (int64_t)Co * Ci;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i / Ci), ci = (int)(i % Ci);
+    float t[6][3];  // G g (columns of g transformed)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float g[3], u[6];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g[a] = w[(((size_t)co * 3 + a) * 3 + b) * Ci + ci];
+      f4_g(g, u);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) t[a][b] = u[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      float u[6];
+      f4_g(t[a], u);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) U[((size_t)(a * 6 + b) * Co + co) * Ci + ci] = u[b];
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W,
+                                                         int C) {
+  const int cq = C >> 2, th = H >> 2, tw = W >> 2;
+  const int64_t T = (int64_t)B * th * tw, n = T * cq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % cq) * 4;
+    const int64_t tile = i / cq;
+    const int j = (int)(tile % tw), ii = (int)((tile / tw) % th), b = (int)(tile / ((int64_t)tw * th));
+    f32x4 r[6][6];  // B^T d, built column by column so only one 6-vector of raw pixels is live
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int xx = 4 * j - 1 + e;
+      f32x4 d[6], c[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const int y = 4 * ii - 1 + a;
+        const bool ok = (unsigned)y < (unsigned)H && (unsigned)xx < (unsigned)W;
+        d[a] = ok ? *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + y) * W + xx) * C + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      f4_bt(d, c);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) r[a][e] = c[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      f32x4 v[6];
+      f4_bt(r[a], v);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) *reinterpret_cast<f32x4*>(V + ((size_t)(a * 6 + e) * T + tile) * C + c4) = v[e];
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void wino4_output_kernel(const float* __restrict__ Mt, const float* __restrict__ res,
+                                                          float* __restrict__ y, int B, int H, int W, int C) {
+  const int cq = C >> 2, th = H >> 2, tw = W >> 2;
+  const int64_t T = (int64_t)B * th * tw, n = T * cq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % cq) * 4;
+    const int64_t tile = i / cq;
+    const int j = (int)(tile % tw), ii = (int)((tile / tw) % th), b = (int)(tile / ((int64_t)tw * th));
+    f32x4 s[4][6];  // A^T m, column by column
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      f32x4 m[6], o[4];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const f32x4*>(Mt + ((size_t)(a * 6 + e) * T + tile) * C + c4);
+      f4_at(m, o);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) s[p][e] = o[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      f32x4 o[4];
+      f4_at(s[p], o);
+      const size_t off = (((size_t)b * H + 4 * ii + p) * W + 4 * j) * C + c4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = o[q];
+        if (res) v += *reinterpret_cast<const f32x4*>(res + off + (size_t)q * C);
+        *reinterpret_cast<f32x4*>(y + off + (size_t)q * C) = v;
+      }
+    }
+  }
+}
+
 inline int grid_for(int64_t n) { return (int)std::min<int64_t>((n + NT - 1) / NT, 65535 * 4); }
 
 }  // namespace
 
-extern "C" int mmfn_wino_weight_f32(const float* w, float* U, int Co, int Ci, void* stream) {
-  if (!w || !U || Co <= 0 || Ci <= 0) return MMFN_EINVAL;
+extern "C" int mmfn_wino_weight_f32(const float* w, float* U, int Co, int Ci, int m, void* stream) {
+  if (!w || !U || Co <= 0 || Ci <= 0 || (m != 2 && m != 4)) return MMFN_EINVAL;
+  if (m == 4) {
+    hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid_for((int64_t)Co * Ci)), dim3(NT), 0, (hipStream_t)stream, w, U, Co, Ci);
+    MMFN_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(wino_weight_kernel, dim3(grid_for((int64_t)Co * Ci)), dim3(NT), 0, (hipStream_t)stream, w, U, Co, Ci);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int mmfn_wino_input_f32(const float* x, float* V, int B, int H, int W, int C, void* stream) {
-  if (!x || !V || (H & 1) || (W & 1) || (C & 3) || B <= 0) return MMFN_EINVAL;
+extern "C" int mmfn_wino_input_f32(const float* x, float* V, int B, int H, int W, int C, int m, void* stream) {
+  if (!x || !V || (m != 2 && m != 4) || (H % m) || (W % m) || (C & 3) || B <= 0) return MMFN_EINVAL;
+  if (m == 4) {
+    hipLaunchKernelGGL(wino4_input_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0, (hipStream_t)stream, x,
+                       V, B, H, W, C);
+    MMFN_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(wino_input_kernel, dim3(grid_for((int64_t)B * (H / 2) * (W / 2) * (C / 4))), dim3(NT), 0, (hipStream_t)stream, x, V,
                      B, H, W, C);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int mmfn_wino_output_f32(const float* Mt, const float* res, float* y, int B, int H, int W, int C, void* stream) {
-  if (!Mt || !y || (H & 1) || (W & 1) || (C & 3) || B <= 0) return MMFN_EINVAL;
+extern "C" int mmfn_wino_output_f32(const float* Mt, const float* res, float* y, int B, int H, int W, int C, int m,
+                                    void* stream) {
+  if (!Mt || !y || (m != 2 && m != 4) || (H % m) || (W % m) || (C & 3) || B <= 0) return MMFN_EINVAL;
+  if (m == 4) {
+    hipLaunchKernelGGL(wino4_output_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
+                       Mt, res, y, B, H, W, C);
+    MMFN_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for((int64_t)B * (H / 2) * (W / 2) * (C / 4))), dim3(NT), 0, (hipStream_t)stream, Mt,
                      res, y, B, H, W, C);
   MMFN_LAUNCH_CHECK();

@@ -123,6 +123,10 @@ def test_winograd_conv_and_dgrad(cfg):
     _close(y.permute(0, 3, 1, 2), y_ref.detach())
     direct = ops.conv2d_fwd(x_nhwc, w_ohwi, 1, 1, tile=1)  # explicit tile -> implicit GEMM
     assert (y - direct).abs().max().item() <= 2e-5 * direct.abs().max().item()
+    for m in ((2, 4) if H % 4 == 0 and W % 4 == 0 else (2,)):  # both transform sizes explicitly
+        ym = ops.conv2d_winograd(x_nhwc, w_ohwi, torch.empty_like(direct), m=m)
+        err = (ym - direct).abs().max().item() / direct.abs().max().item()
+        assert err <= (2e-5 if m == 4 else 5e-6), (m, err)
     res = torch.randn(B, H, W, Cin, generator=g).to(dev)
     dx = ops.conv2d_dgrad(dy_nhwc, w_ohwi, tuple(x_nhwc.shape), 1, 1, res=res, ldr=Cin)
     _close((dx - res).permute(0, 3, 1, 2), xr.grad)
