@@ -44,6 +44,10 @@ int mmfn_conv_weight_flip_f32(const float* w, float* wt, int Co, int T, int Ci, 
 int mmfn_wino_weight_f32(const float* w, float* U, int Co, int Ci, int m, void* stream);
 int mmfn_wino_input_f32(const float* x, float* V, int B, int H, int W, int C, int m, void* stream);
 int mmfn_wino_output_f32(const float* Mt, const float* res, float* y, int B, int H, int W, int C, int m, void* stream);
+/* weight gradient in the F(4x4,3x3) domain: dw = G^T [ sum_tiles (A dY A^T) . (B^T x B) ] G
+ *   dMt[36][tiles][Co] = A dy A^T per 4x4 patch;  dU[t] = dMt[t]^T . V[t] (batched GEMM);  dw[Co][3][3][Ci] = G^T dU G */
+int mmfn_wino_outgrad_f32(const float* dy, float* dMt, int B, int H, int W, int C, void* stream);
+int mmfn_wino_wgrad_out_f32(const float* dU, float* dw, int Co, int Ci, void* stream);
 /* y = a*x + b*y (b == 0 ignores the old y) */
 int mmfn_axpby_f32(float* y, const float* x, float a, float b, int64_t n, void* stream);
 /* out = y > 0 ? g : 0  (ReLU backward) */

@@ -239,6 +239,77 @@ __global__ __launch_bounds__(NT) void wino4_output_kernel(const float* __restric
   }
 }
 
+// ---- weight gradient in the F(4x4,3x3) domain:  dw = G^T [ sum_tiles (A dY A^T) . (B^T x B) ] G
+// dMt[t][tile][c] = (A dy A^T)[t] for the 4x4 output-gradient patch of the tile (A = transpose of A^T above, 6x4)
+template <typename T>
+__device__ __forceinline__ void f4_a(const T* y, T* m) {  // m = A y, 4 -> 6
+  const T e = y[0] + y[2], o = y[1] + y[3];
+  m[0] = y[0];
+  m[1] = e + o;
+  m[2] = e - o;
+  m[3] = y[0] + 2.f * y[1] + 4.f * y[2] + 8.f * y[3];
+  m[4] = y[0] - 2.f * y[1] + 4.f * y[2] - 8.f * y[3];
+  m[5] = y[3];
+}
+__device__ __forceinline__ void f4_gt(const float* u, float* g) {  // g = G^T u, 6 -> 3
+  g[0] = 0.25f * u[0] - (1.f / 6.f) * (u[1] + u[2]) + (1.f / 24.f) * (u[3] + u[4]);
+  g[1] = (1.f / 6.f) * (u[2] - u[1]) + (1.f / 12.f) * (u[3] - u[4]);
+  g[2] = -(1.f / 6.f) * (u[1] + u[2]) + (1.f / 6.f) * (u[3] + u[4]) + u[5];
+}
+
+__global__ __launch_bounds__(NT) void wino4_outgrad_kernel(const float* __restrict__ dy, float* __restrict__ dMt, int B, int H, int W,
+                                                           int C) {
+  const int cq = C >> 2, th = H >> 2, tw = W >> 2;
+  const int64_t T = (int64_t)B * th * tw, n = T * cq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % cq) * 4;
+    const int64_t tile = i / cq;
+    const int j = (int)(tile % tw), ii = (int)((tile / tw) % th), b = (int)(tile / ((int64_t)tw * th));
+    f32x4 r[6][4];  // A dy, column by column
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 y[4], m[6];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) y[p] = *reinterpret_cast<const f32x4*>(dy + (((size_t)b * H + 4 * ii + p) * W + 4 * j + q) * C + c4);
+      f4_a(y, m);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) r[a][q] = m[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      f32x4 m[6];
+      f4_a(r[a], m);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) *reinterpret_cast<f32x4*>(dMt + ((size_t)(a * 6 + e) * T + tile) * C + c4) = m[e];
+    }
+  }
+}
+
+// dw[co][3][3][ci] = G^T dU[:, co, ci] G;  dU is [36][Co][Ci]
+__global__ __launch_bounds__(NT) void wino4_wgrad_out_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Co, int Ci) {
+  const int64_t n = (int64_t)Co * Ci;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i / Ci), ci = (int)(i % Ci);
+    float t[3][6];  // G^T dU
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      float u[6], g[3];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) u[a] = dU[((size_t)(a * 6 + e) * Co + co) * Ci + ci];
+      f4_gt(u, g);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) t[a][e] = g[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float g[3];
+      f4_gt(t[a], g);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) dw[(((size_t)co * 3 + a) * 3 + b) * Ci + ci] = g[b];
+    }
+  }
+}
+
 inline int grid_for(int64_t n) { return (int)std::min<int64_t>((n + NT - 1) / NT, 65535 * 4); }
 
 }  // namespace
@@ -280,6 +351,21 @@ extern "C" int mmfn_wino_output_f32(const float* Mt, const float* res, float* y,
   }
   hipLaunchKernelGGL(wino_output_kernel, dim3(grid_for((int64_t)B * (H / 2) * (W / 2) * (C / 4))), dim3(NT), 0, (hipStream_t)stream, Mt,
                      res, y, B, H, W, C);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_wino_outgrad_f32(const float* dy, float* dMt, int B, int H, int W, int C, void* stream) {
+  if (!dy || !dMt || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
+  hipLaunchKernelGGL(wino4_outgrad_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0, (hipStream_t)stream, dy,
+                     dMt, B, H, W, C);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_wino_wgrad_out_f32(const float* dU, float* dw, int Co, int Ci, void* stream) {
+  if (!dU || !dw || Co <= 0 || Ci <= 0) return MMFN_EINVAL;
+  hipLaunchKernelGGL(wino4_wgrad_out_kernel, dim3(grid_for((int64_t)Co * Ci)), dim3(NT), 0, (hipStream_t)stream, dU, dw, Co, Ci);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

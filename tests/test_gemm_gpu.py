@@ -130,3 +130,9 @@ def test_winograd_conv_and_dgrad(cfg):
     res = torch.randn(B, H, W, Cin, generator=g).to(dev)
     dx = ops.conv2d_dgrad(dy_nhwc, w_ohwi, tuple(x_nhwc.shape), 1, 1, res=res, ldr=Cin)
     _close((dx - res).permute(0, 3, 1, 2), xr.grad)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(x, wr, padding=1).backward(dy)
+    dw = ops.conv2d_wgrad(dy_nhwc, x_nhwc, tuple(w_ohwi.shape), 1, 1)  # Winograd domain when H, W are multiples of 4
+    _close(dw.permute(0, 3, 1, 2), wr.grad)
+    dw_direct = ops.conv2d_wgrad(dy_nhwc, x_nhwc, tuple(w_ohwi.shape), 1, 1, tile=2)
+    assert (dw - dw_direct).abs().max().item() <= 3e-5 * dw_direct.abs().max().item()
