@@ -91,7 +91,11 @@ class ConvBN(object):
         B = x.shape[0]
         _, oshape = ops.conv_geom(x.shape, self.w.shape, self.stride, self.pad)
         co = ctx.bufs.get(self.name + ".conv", oshape)
-        ops.conv2d_fwd(x, self.w, self.stride, self.pad, out=co)
+        keep_v = None
+        if ctx.training and ops.winograd_wgrad_ok(x.shape, self.w.shape, self.stride, self.pad):
+            # the transformed input of the Winograd path is what the weight gradient needs again: keep it per layer
+            keep_v = ctx.bufs.get(self.name + ".winoV", (ops.winograd_v_numel(x.shape),))
+        ops.conv2d_fwd(x, self.w, self.stride, self.pad, out=co, keep_v=keep_v)
         M = oshape[0] * oshape[1] * oshape[2]
         co2 = co.view(M, self.cout)
         mean = ctx.bufs.get(self.name + ".mean", (self.cout,))
@@ -105,6 +109,7 @@ class ConvBN(object):
         ops.bn_apply(co2, y.view(M, self.cout), mean, rstd, self.bn_w, self.bn_b, relu,
                      res=None if res is None else res.view(M, self.cout))
         self.saved = (x, co, y, mean, rstd, relu)
+        self.saved_v = keep_v
         return y
 
     def bwd(self, ctx, g, need_dx=True, ge_out=None, dx_res=None, mask_y=None):
@@ -119,7 +124,7 @@ class ConvBN(object):
             ymask = (y if mask_y is None else mask_y).view(M, self.cout)
         ops.bn_bwd(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.bn_w, dco.view(M, self.cout),
                    self.g_bn_w, self.g_bn_b, ge_out=None if ge_out is None else ge_out.view(M, self.cout))
-        ops.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, out=self.gw)
+        ops.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, out=self.gw, v=getattr(self, "saved_v", None))
         if not need_dx:
             return None
         dx = ctx.bufs.get(self.name + ".dx", x.shape)
