@@ -703,7 +703,7 @@ class Engine(object):
         # gaps; captured into the hipGraph this becomes a fork/join DAG.
         self.side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         self.multi_stream = True
-        self.n_lanes = int(os.environ.get("MMFN_BRANCH_LANES", "2"))
+        self.n_lanes = int(os.environ.get("MMFN_BRANCH_LANES", "3"))
         self.offload_wgrad = os.environ.get("MMFN_OFFLOAD_WGRAD", "1") == "1"
 
     # ------------------------------------------------------------------ inputs
@@ -752,7 +752,9 @@ class Engine(object):
         outs = [None] * len(fns)
         if self.n_lanes == 2:
             # two lanes: the camera ResNet-34 alone on the main stream, LiDAR ResNet-18 + map branch back to back on
-            # the side stream (measured best on MI355X: the hipGraph runtime co-schedules two queues well, three badly)
+            # the side stream.  Which lane count wins depends on the kernel mix: with the implicit-GEMM convolutions
+            # (few, chip-filling launches) two lanes beat three by 3 %; with the Winograd path (many small streaming
+            # transforms between the GEMMs) three lanes beat two by 3 %
             st = self.side[0]
             st.wait_event(fork)
             with torch.cuda.stream(st), ops.lane(1):
