@@ -272,6 +272,7 @@ def main():
         ops.set_gemm_profiler(None)
         eng.multi_stream = not args.single_stream
         n_launch, flops, ms = prof.summary()
+        executed = prof.executed_flops()
         traffic, traffic_src = None, None
         import glob
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
@@ -289,9 +290,13 @@ def main():
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch",
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(prof.algo_bytes() / max(n_launch, 1)),
-            "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32 GEMM / implicit-GEMM conv fwd+dgrad+wgrad)",
+            "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32 GEMM / implicit-GEMM conv fwd+dgrad+wgrad; 3x3 stride-1 "
+                      "convolutions with >=128 channels as Winograd F(4x4,3x3): their transform kernels are inside the timed span)",
             "launches_per_step": n_launch // steps_p,
             "algorithmic_gflop_per_step": round(flops / steps_p / 1e9, 1),
+            # what the MFMA units execute: less than the algorithmic count where Winograd replaces the direct convolution
+            "executed_gflop_per_step": round(executed / steps_p / 1e9, 1),
+            "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
             "kernel_ms_per_step": round(ms / steps_p, 3),
             "whole_step_algorithmic_tflops": round(ALGO_GFLOP_PER_SAMPLE.get("image-only" if image_only else args.variant, 0) * B / ms_per_step, 2),
         }
