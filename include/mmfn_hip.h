@@ -44,6 +44,10 @@ int mmfn_conv_weight_flip_f32(const float* w, float* wt, int Co, int T, int Ci, 
 int mmfn_wino_weight_f32(const float* w, float* U, int Co, int Ci, int m, void* stream);
 int mmfn_wino_input_f32(const float* x, float* V, int B, int H, int W, int C, int m, void* stream);
 int mmfn_wino_output_f32(const float* Mt, const float* res, float* y, int B, int H, int W, int C, int m, void* stream);
+/* F(4x4) output transform that also writes the BatchNorm batch-statistics partial rows of y ([*nblk_out][2][C] doubles, at most
+ * 512 rows; *nblk_out is a host int), to be finished by mmfn_bn_finalize_stats_f32 */
+int mmfn_wino_output_stats_f32(const float* Mt, float* y, double* partials, int* nblk_out, int B, int H, int W, int C,
+                               void* stream);
 /* weight gradient in the F(4x4,3x3) domain: dw = G^T [ sum_tiles (A dY A^T) . (B^T x B) ] G
  *   dMt[36][tiles][Co] = A dy A^T per 4x4 patch;  dU[t] = dMt[t]^T . V[t] (batched GEMM);  dw[Co][3][3][Ci] = G^T dU G */
 int mmfn_wino_outgrad_f32(const float* dy, float* dMt, int B, int H, int W, int C, void* stream);
@@ -127,6 +131,8 @@ int mmfn_bn_train_stats_f32(const float* x, int64_t M, int C, float eps, float m
                             float* running_mean, float* running_var, int64_t* num_batches_tracked, void* workspace,
                             void* stream);
 /* eval mode: mean = running_mean, rstd = 1/sqrt(running_var + eps) */
+int mmfn_bn_finalize_stats_f32(const double* partials, int nblk, int64_t M, int C, float eps, float momentum, float* mean,
+                               float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, void* stream);
 int mmfn_bn_eval_prepare_f32(const float* running_mean, const float* running_var, float eps, int C, float* mean,
                              float* rstd, void* stream);
 /* y = [relu]( (x - mean) * rstd * weight + bias [+ res] ) */

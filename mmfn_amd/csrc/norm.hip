@@ -386,6 +386,18 @@ extern "C" int mmfn_bn_train_stats_f32(const float* x, int64_t M, int C, float e
   return 0;
 }
 
+// Second half of mmfn_bn_train_stats_f32 for producers that emit the per-block (sum, sum of squares) rows themselves
+// (the Winograd output transform): partials is [nblk][2][C] doubles.
+extern "C" int mmfn_bn_finalize_stats_f32(const double* partials, int nblk, int64_t M, int C, float eps, float momentum,
+                                          float* mean, float* rstd, float* running_mean, float* running_var,
+                                          int64_t* num_batches_tracked, void* stream) {
+  if (!partials || nblk <= 0 || M <= 0 || C <= 0) return MMFN_EINVAL;
+  hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, (hipStream_t)stream, partials,
+                     nblk, M, C, eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmfn_bn_eval_prepare_f32(const float* running_mean, const float* running_var, float eps, int C, float* mean,
                                         float* rstd, void* stream) {
   hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, (hipStream_t)stream, running_mean,

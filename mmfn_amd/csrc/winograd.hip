@@ -310,6 +310,60 @@ __global__ __launch_bounds__(NT) void wino4_wgrad_out_kernel(const float* __rest
   }
 }
 
+// Output transform that also emits the BatchNorm batch statistics of what it writes: block b owns a contiguous run of
+// tiles, thread (tile lane, channel quad) accumulates sum / sum of squares of its 16 pixels x 4 channels in fp64, the tile
+// lanes are combined through LDS and row b of partials [gridDim][2][C] is written (same format as col_partial_kernel<0>,
+// finished by mmfn_bn_finalize_stats_f32).  Saves the separate statistics pass over the convolution output.
+__global__ __launch_bounds__(NT) void wino4_output_stats_kernel(const float* __restrict__ Mt, float* __restrict__ y,
+                                                                double* __restrict__ partials, int B, int H, int W, int C,
+                                                                int tiles_per_block) {
+  const int cq = C >> 2, th = H >> 2, tw = W >> 2;
+  const int64_t T = (int64_t)B * th * tw;
+  const int TL = NT / cq;  // tile lanes per block
+  const int cqi = threadIdx.x % cq, tl = threadIdx.x / cq;
+  const int c4 = cqi * 4;
+  const int64_t t0 = (int64_t)blockIdx.x * tiles_per_block;
+  const int64_t t1 = (t0 + tiles_per_block < T) ? t0 + tiles_per_block : T;
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  for (int64_t tile = t0 + tl; tile < t1; tile += TL) {
+    const int j = (int)(tile % tw), ii = (int)((tile / tw) % th), b = (int)(tile / ((int64_t)tw * th));
+    f32x4 s[4][6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      f32x4 m[6], o[4];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) m[a] = *reinterpret_cast<const f32x4*>(Mt + ((size_t)(a * 6 + e) * T + tile) * C + c4);
+      f4_at(m, o);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) s[p][e] = o[p];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      f32x4 o[4];
+      f4_at(s[p], o);
+      const size_t off = (((size_t)b * H + 4 * ii + p) * W + 4 * j) * C + c4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        *reinterpret_cast<f32x4*>(y + off + (size_t)q * C) = o[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const double v = o[q][e]; s1[e] += v; s2[e] += v * v; }
+      }
+    }
+  }
+  __shared__ double red[2][NT][4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+  __syncthreads();
+  if (tl == 0) {
+    for (int k = 1; k < TL; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1[e] += red[0][k * cq + cqi][e]; s2[e] += red[1][k * cq + cqi][e]; }
+    double* p = partials + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { p[c4 + e] = s1[e]; p[C + c4 + e] = s2[e]; }
+  }
+}
+
 inline int grid_for(int64_t n) { return (int)std::min<int64_t>((n + NT - 1) / NT, 65535 * 4); }
 
 }  // namespace
@@ -366,6 +420,21 @@ extern "C" int mmfn_wino_outgrad_f32(const float* dy, float* dMt, int B, int H, 
 extern "C" int mmfn_wino_wgrad_out_f32(const float* dU, float* dw, int Co, int Ci, void* stream) {
   if (!dU || !dw || Co <= 0 || Ci <= 0) return MMFN_EINVAL;
   hipLaunchKernelGGL(wino4_wgrad_out_kernel, dim3(grid_for((int64_t)Co * Ci)), dim3(NT), 0, (hipStream_t)stream, dU, dw, Co, Ci);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_wino_output_stats_f32(const float* Mt, float* y, double* partials, int* nblk_out, int B, int H, int W, int C,
+                                          void* stream) {
+  if (!Mt || !y || !partials || !nblk_out || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
+  const int cq = C / 4;
+  if (cq > NT || NT % cq) return MMFN_EINVAL;
+  const int64_t T = (int64_t)B * (H / 4) * (W / 4);
+  const int TL = NT / cq;
+  const int tpb = (int)std::max<int64_t>(TL, (T + 511) / 512);
+  const int nblk = (int)((T + tpb - 1) / tpb);
+  *nblk_out = nblk;
+  hipLaunchKernelGGL(wino4_output_stats_kernel, dim3(nblk), dim3(NT), 0, (hipStream_t)stream, Mt, y, partials, B, H, W, C, tpb);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

@@ -95,15 +95,15 @@ class ConvBN(object):
         if ctx.training and ops.winograd_wgrad_ok(x.shape, self.w.shape, self.stride, self.pad):
             # the transformed input of the Winograd path is what the weight gradient needs again: keep it per layer
             keep_v = ctx.bufs.get(self.name + ".winoV", (ops.winograd_v_numel(x.shape),))
-        ops.conv2d_fwd(x, self.w, self.stride, self.pad, out=co, keep_v=keep_v)
         M = oshape[0] * oshape[1] * oshape[2]
         co2 = co.view(M, self.cout)
         mean = ctx.bufs.get(self.name + ".mean", (self.cout,))
         rstd = ctx.bufs.get(self.name + ".rstd", (self.cout,))
         if ctx.training:
-            ops.bn_train_stats(co2, mean, rstd, self.bn.running_mean, self.bn.running_var, self.bn.num_batches_tracked,
-                               self.bn.eps, self.bn.momentum)
+            ops.conv2d_fwd_bn_stats(x, self.w, self.stride, self.pad, co, mean, rstd, self.bn.running_mean, self.bn.running_var,
+                                    self.bn.num_batches_tracked, self.bn.eps, self.bn.momentum, keep_v=keep_v)
         else:
+            ops.conv2d_fwd(x, self.w, self.stride, self.pad, out=co)
             ops.bn_eval_prepare(self.bn.running_mean, self.bn.running_var, mean, rstd, self.bn.eps)
         y = ctx.bufs.get(self.name + ".out", oshape)
         ops.bn_apply(co2, y.view(M, self.cout), mean, rstd, self.bn_w, self.bn_b, relu,
