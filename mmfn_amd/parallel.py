@@ -72,11 +72,11 @@ class GraphedStep(object):
         g4 = fused AdamW (after every reduction has been waited on)
     Each replay is one host call; the reductions still overlap the later backward graphs."""
 
-    def __init__(self, engine, dp, inp, gt, lr=1e-4, warm=2):
+    def __init__(self, engine, dp, inp, gt, lr=1e-4, warm=2, **adam):
         self.engine, self.dp = engine, dp
         eng = engine
         for _ in range(warm):  # size every buffer / scratch lane eagerly before capture
-            eng.train_step(inp, gt, lr=lr, dp=dp)
+            eng.train_step(inp, gt, lr=lr, dp=dp, **adam)
         torch.cuda.synchronize()
         scale = 1.0 / (dp.world if dp is not None else 1)
 
@@ -88,7 +88,7 @@ class GraphedStep(object):
             eng.backward_scale(3)
 
         parts = [first, lambda: eng.backward_scale(2), lambda: eng.backward_scale(1), lambda: eng.backward_scale(0),
-                 lambda: eng.optimizer_step(lr=lr, grad_scale=scale)]
+                 lambda: eng.optimizer_step(lr=lr, grad_scale=scale, **adam)]
         self.graphs = []
         for fn in parts:
             g = torch.cuda.CUDAGraph()
@@ -108,4 +108,39 @@ class GraphedStep(object):
         if dp is not None:
             dp.finish()
         g[4].replay()
+        return self.loss
+
+
+class StaticBatchStep(object):
+    """A replayable training step for a stream of different batches of one shape: the step is captured once over static
+    copies of the inputs (one hipGraph on a single GPU, the five-graph GraphedStep under data parallelism) and every call
+    copies the new batch into them first.  What a real training loop needs to run at the replay rate of bench.py instead
+    of being bound by ~2500 Python-issued launches per step.  The engine's buffers for this shape must already exist
+    (run one eager step of the shape first); lr / betas / eps / weight decay are baked into the captured launches."""
+
+    def __init__(self, engine, dp, inp, gt, lr, **adam):
+        self.inp = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
+        self.gt = gt.clone()
+        torch.cuda.synchronize()
+        if dp is None:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.loss = engine.train_step(self.inp, self.gt, lr=lr, **adam)
+            self.run = self.graph.replay
+        else:
+            self.seg = GraphedStep(engine, dp, self.inp, self.gt, lr=lr, warm=0, **adam)
+            self.loss = self.seg.loss
+            self.run = self.seg
+
+    @staticmethod
+    def signature(inp, gt, lr, adam):
+        items = tuple(sorted((k, tuple(v.shape) if isinstance(v, torch.Tensor) else v) for k, v in inp.items()))
+        return items, tuple(gt.shape), lr, tuple(sorted((k, tuple(v) if isinstance(v, (tuple, list)) else v) for k, v in adam.items()))
+
+    def __call__(self, inp, gt):
+        for k, v in inp.items():
+            if isinstance(v, torch.Tensor):
+                self.inp[k].copy_(v, non_blocking=True)
+        self.gt.copy_(gt, non_blocking=True)
+        self.run()
         return self.loss

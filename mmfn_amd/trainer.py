@@ -22,6 +22,7 @@ import torch
 
 from . import data as D
 from . import ops
+from .parallel import StaticBatchStep
 
 
 class Trainer(object):
@@ -36,9 +37,16 @@ class Trainer(object):
         self.logdir = log_dir
 
     # ------------------------------------------------------------------ one epoch of training
-    def train(self, model, dataloader_train, config, optimizer, dp=None, fused=True, log_every=50, on_log=None):
+    def train(self, model, dataloader_train, config, optimizer, dp=None, fused=True, log_every=50, on_log=None, graph=True,
+              lane_bucket=16):
+        """One epoch.  graph=True (fused path): the second batch of a given shape captures the step into hipGraphs over
+        static input buffers and every later batch of that shape only copies its inputs and replays (the first one runs
+        eagerly and sizes the buffers); lane sets are zero-padded to a multiple of `lane_bucket` lanes so that ragged
+        batches fall into few shapes (padded lanes are masked by lane_num, which leaves the result unchanged)."""
         model.train()
         eng = model._engine_for()
+        if not hasattr(self, "_static_steps"):
+            self._static_steps = {}
         total = torch.zeros(1, dtype=torch.float32, device=model._layout.device)
         window = torch.zeros_like(total)
         num_batches = 0
@@ -46,8 +54,20 @@ class Trainer(object):
             if fused:
                 g = optimizer.param_groups[0]
                 inp = args if isinstance(args, dict) else model._pack(*args)  # raw-frame batches are engine inputs already
-                loss = eng.train_step(inp, gt, lr=g["lr"], dp=dp, betas=tuple(g["betas"]), eps=g["eps"],
-                                      weight_decay=g["weight_decay"])
+                adam = dict(betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"])
+                if graph:
+                    inp = _bucket_lanes(inp, lane_bucket)
+                    sig = StaticBatchStep.signature(inp, gt, g["lr"], adam)
+                    state = self._static_steps.get(sig)
+                    if state is None:  # first batch of this shape: eager (allocates the engine's buffers for it)
+                        self._static_steps[sig] = "seen"
+                        loss = eng.train_step(inp, gt, lr=g["lr"], dp=dp, **adam)
+                    else:
+                        if state == "seen":
+                            state = self._static_steps[sig] = StaticBatchStep(eng, dp, inp, gt, g["lr"], **adam)
+                        loss = state(inp, gt)
+                else:
+                    loss = eng.train_step(inp, gt, lr=g["lr"], dp=dp, **adam)
             else:
                 if dp is not None or isinstance(args, dict):
                     raise NotImplementedError("the autograd path takes reference-format batches on one GPU; use fused=True")
@@ -127,6 +147,16 @@ class Trainer(object):
         model.load_state_dict({k[7:] if k.startswith("module.") else k: v for k, v in weights.items()})
         optimizer.load_state_dict(torch.load(os.path.join(logdir, names[1]), map_location="cpu"))
         return True
+
+
+def _bucket_lanes(inp, bucket):
+    lane = inp.get("lane")
+    if lane is None or bucket <= 1 or lane.shape[1] % bucket == 0:
+        return inp
+    pad = bucket - lane.shape[1] % bucket
+    out = dict(inp)
+    out["lane"] = torch.nn.functional.pad(lane, (0, 0, 0, 0, 0, pad))
+    return out
 
 
 def _plain_state_dict(model):

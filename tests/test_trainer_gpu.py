@@ -118,3 +118,31 @@ def test_checkpoint_files_and_resume(store, tmp_path):
     for k in s1:
         assert torch.equal(s1[k], s2[k]), k
     assert tr2.train_loss == tr.train_loss
+
+
+def test_graph_replay_epoch_equals_eager_epoch(store):
+    """Trainer.train(graph=True): static-input hipGraph replay over changing batches == eager fused steps, bit for bit
+    (dropout on: the counter RNG advances on the device inside the captured step)."""
+    from mmfn_amd import data as D
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd import model as M
+    from mmfn_amd.optim import FusedAdamW
+    from mmfn_amd.trainer import Trainer
+    from oracle import harness
+    oracle = harness.build_oracle("vec", dropout=0.1)
+    cfg = GlobalConfig()
+    loader = D.make_loader(store, batch_size=1, num_workers=0)  # 4 batches with 5 / 9 / 3 / 7 lanes -> one 16-lane bucket
+    nets = []
+    for graph in (False, True):
+        net = M.MMFN(cfg, DEV)
+        net.load_state_dict(oracle.state_dict(), strict=True)
+        tr = Trainer(DEV, None)
+        opt = FusedAdamW(net, lr=1e-4)
+        tr.train(net, loader, cfg, opt, graph=graph)
+        tr.train(net, loader, cfg, opt, graph=graph)
+        if graph:
+            assert len(tr._static_steps) == 1 and not isinstance(next(iter(tr._static_steps.values())), str)
+        nets.append((tr.train_loss, net.state_dict()))
+    assert nets[0][0] == nets[1][0]
+    for k in nets[0][1]:
+        assert torch.equal(nets[0][1][k], nets[1][1][k]), k
