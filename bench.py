@@ -145,6 +145,9 @@ def main():
     ap.add_argument("--workload", default="train", choices=["train", "image-only"],
                     help="train = full step (BASELINE configs[1]); image-only = ResNet-34 branch fwd+bwd (configs[3])")
     ap.add_argument("--n-lidar", type=int, default=16384, help="LiDAR points per sample (configs[4]: 65536)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = the parity path (headline); bf16 = bf16 MFMA operands for the Linear / Winograd GEMMs with fp32 "
+                         "accumulation, activations and master weights (BASELINE configs[2]; reported as dtype bf16)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-stream", action="store_true", help="disable encoder-branch concurrency (profiling runs)")
@@ -179,7 +182,7 @@ def main():
     from mmfn_amd.parallel import DataParallel
 
     torch.manual_seed(42)  # init_torch(): run_steps/utils.py:77-84
-    net = {"vec": MMFN, "img": MMFNImg, "rad": MMFNRad}[args.variant](GlobalConfig(), dev)
+    net = {"vec": MMFN, "img": MMFNImg, "rad": MMFNRad}[args.variant](GlobalConfig(gemm_dtype=args.dtype), dev)
     net.train()
     B = args.batch
     inp, gt = synth_inputs(B, dev, seed=42 + rank, n_lidar=args.n_lidar, variant=args.variant)
@@ -254,7 +257,7 @@ def main():
     result = {
         "metric": "image-branch fwd+bwd samples/sec" if image_only else "train samples/sec (RGB+LiDAR+vec-map fusion)", "value": round(value, 2), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": B * world, "parallelism": "dp%d" % world, "hipgraph": graph is not None,
                    "branch_streams": 1 if args.single_stream else eng.n_lanes},
@@ -276,7 +279,7 @@ def main():
         traffic, traffic_src = None, None
         import glob
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-        default_workload = (not image_only and args.variant == "vec" and B == 32 and args.n_lidar == 16384)
+        default_workload = (not image_only and args.variant == "vec" and B == 32 and args.n_lidar == 16384 and args.dtype == "f32")
         if tfiles and default_workload:  # PMC-derived HBM bytes per launch of this kernel family (tools/profile_round.sh)
             rec = json.load(open(tfiles[-1]))
             traffic, traffic_src = round(rec["hbm_bytes_per_launch"]), os.path.basename(tfiles[-1])
@@ -300,6 +303,9 @@ def main():
             "kernel_ms_per_step": round(ms / steps_p, 3),
             "whole_step_algorithmic_tflops": round(ALGO_GFLOP_PER_SAMPLE.get("image-only" if image_only else args.variant, 0) * B / ms_per_step, 2),
         }
+        if args.dtype != "f32":
+            result["roofline"]["note"] = ("bf16 mode: the GEMMs with bf16 MFMA operands are priced against the fp32 MFMA peak here "
+                                          "for comparability with the f32 run; their own dense peak is 2.5 PFLOP/s")
         if not args.no_cpu_baseline and not image_only and args.variant == "vec":
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))

@@ -85,7 +85,9 @@ enum {
   MMFN_EPI_MASK_AUX = 8,   /* v = aux[m,n] > 0 ? v : 0   (ReLU backward)                  */
   MMFN_EPI_DROPOUT = 16,   /* v = keep ? v/(1-p) : 0, counter-based RNG                   */
   MMFN_EPI_RESIDUAL = 32,  /* + res[m*ldr + n]                                            */
-  MMFN_EPI_ACCUM = 64      /* + C[m,n] (beta = 1)                                         */
+  MMFN_EPI_ACCUM = 64,     /* + C[m,n] (beta = 1)                                         */
+  MMFN_EPI_BF16_OPERANDS = 128 /* opt-in mixed precision for plain GEMM forms: A and B rounded to bf16 on the way into LDS,
+                                  bf16 MFMA, fp32 accumulate / epilogue / output (autocast-style; BASELINE configs[2]) */
 };
 
 typedef struct mmfn_gemm_desc {

@@ -43,6 +43,9 @@ class GlobalConfig(object):
     feature_num = 5
     up = down = left = right = 28
     tmp_town_for_save_opendrive = "/tmp/opendrvie_tmp"
+    # not in the reference: arithmetic of the Linear / Winograd GEMMs.  "f32" is the parity path; "bf16" rounds their operands
+    # to bf16 on the way into the MFMA units (fp32 accumulation, activations and master weights; BASELINE configs[2])
+    gemm_dtype = "f32"
 
     def __init__(self, **kwargs):
         self.train_data, self.val_towns = [], []

@@ -682,6 +682,140 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16-operand mode (MMFN_EPI_BF16_OPERANDS, plain GEMM forms): A and B stay fp32 in HBM and are rounded to bf16
+// (v_cvt_pk_bf16_f32, round to nearest even) on their way into LDS; v_mfma_f32_32x32x16_bf16 accumulates in fp32 and the
+// epilogue / outputs are fp32 as everywhere else.  16x the MFMA rate of the fp32 instruction, so the kernel is bound by the
+// fp32 operand traffic instead: 3-4x faster than the fp32 kernel on the transformer shapes (tools/experiments).
+//   tile 128x128, 4 waves (2x2 of 64x64), BK = 32: LDS rows of 32 bf16 (64 B) whose 16-byte slots are XOR-swizzled by row so
+//   the fragment ds_read_b128 is conflict-free; k-contiguous operands store 4 consecutive k per float4 directly, m-contiguous
+//   operands (dX's weights, dW's activations) load a 4(k) x 4(m) micro-tile and transpose it in registers first.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int HBK = 32;  // k-tile of the bf16 kernel
+
+__device__ __forceinline__ int hslot(int row, int slot) { return slot ^ ((row >> 2) & 3); }
+
+template <bool A_KC, bool B_KC, int BM, int BN>
+__global__ __launch_bounds__(NT) void gemm_bf16_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, const int tiles_n) {
+  const mmfn_gemm_desc d = batch_view(d_in);
+  constexpr int TM = BM / 64, TN = BN / 64;            // 32x32 accumulator tiles per wave (2x2 waves)
+  constexpr int UA = BM * 8 / NT, UB = BN * 8 / NT;    // k-contiguous staging units (row, k-quad) per thread
+  __shared__ __attribute__((aligned(16))) __bf16 sm[2][(BM + BN) * HBK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+  const int nkt = d.K / HBK;
+  const int kt_begin = blockIdx.y * kt_per_split, kt_end = min(nkt, kt_begin + kt_per_split);
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // m-contiguous staging: one 4(k) x 4(m) micro-tile per thread, (k-quad, m-quad) = (tid / (rows/4), tid % (rows/4));
+  // with a 64-row operand only the first 128 threads carry one
+  constexpr int AQ = BM / 4, BQ = BN / 4;
+  const bool a_on = A_KC || tid < AQ * 8, b_on = B_KC || tid < BQ * 8;
+  f32x4 ra[4], rb[4];
+  const float* pa[4];
+  const float* pb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int u = tid + i * NT;
+    if (A_KC) pa[i] = d.A + (size_t)min(m0 + (u >> 3), d.M - 1) * d.lda + (u & 7) * 4;
+    else pa[i] = d.A + (size_t)(((tid / AQ) & 7) * 4 + i) * d.lda + min(m0 + (tid % AQ) * 4, d.M - 4);
+    if (B_KC) pb[i] = d.B + (size_t)min(n0 + (u >> 3), d.N - 1) * d.ldb + (u & 7) * 4;
+    else pb[i] = d.B + (size_t)(((tid / BQ) & 7) * 4 + i) * d.ldb + min(n0 + (tid % BQ) * 4, d.N - 4);
+  }
+  auto load = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (A_KC ? i < UA : a_on) ra[i] = ld4(pa[i] + (A_KC ? (size_t)kt * HBK : (size_t)kt * HBK * d.lda));
+      if (B_KC ? i < UB : b_on) rb[i] = ld4(pb[i] + (B_KC ? (size_t)kt * HBK : (size_t)kt * HBK * d.ldb));
+    }
+  };
+  auto store_kc = [&](__bf16* base, const f32x4* r, int units) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i >= units) break;
+      const int u = tid + i * NT, row = u >> 3, q = u & 7;
+      bf16x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (__bf16)r[i][e];
+      *reinterpret_cast<bf16x4*>(&base[row * HBK + hslot(row, q >> 1) * 8 + (q & 1) * 4]) = v;
+    }
+  };
+  auto store_mc = [&](__bf16* base, const f32x4* r, int quads) {  // r[j] = 4 consecutive rows at k = 4*kq + j
+    const int kq = tid / quads, mq = tid % quads;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = mq * 4 + e;
+      bf16x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (__bf16)r[j][e];
+      *reinterpret_cast<bf16x4*>(&base[row * HBK + hslot(row, kq >> 1) * 8 + (kq & 1) * 4]) = v;
+    }
+  };
+  auto store = [&](int buf) {
+    if (A_KC) store_kc(sm[buf], ra, UA); else if (a_on) store_mc(sm[buf], ra, AQ);
+    if (B_KC) store_kc(sm[buf] + BM * HBK, rb, UB); else if (b_on) store_mc(sm[buf] + BM * HBK, rb, BQ);
+  };
+  if (kt_begin < kt_end) {
+    load(kt_begin);
+    store(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const bool more = kt + 1 < kt_end;
+    if (more) load(kt + 1);
+    const __bf16* As = sm[cur];
+    const __bf16* Bs = sm[cur] + BM * HBK;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int ar = wm * TM * 32 + i * 32 + l31;
+        a[i] = *reinterpret_cast<const bf16x8*>(&As[ar * HBK + hslot(ar, 2 * s2 + h) * 8]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int br = wn * TN * 32 + j * 32 + l31;
+        b[j] = *reinterpret_cast<const bf16x8*>(&Bs[br * HBK + hslot(br, 2 * s2 + h) * 8]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+  uint64_t key = 0;
+  if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
+  const bool to_slab = d.splitk > 1;
+  float* slab = to_slab ? d.workspace + (size_t)blockIdx.y * d.M * d.N : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 32 + j * 32 + l31;
+      if (col >= d.N) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (row >= d.M) continue;
+        if (to_slab) slab[(size_t)row * d.N + col] = acc[i][j][r];
+        else epilogue_store(d, key, row, col, acc[i][j][r]);
+      }
+    }
+}
+
 // Deterministic split-K combine: slabs [splitk][M][N] -> epilogue(C).  One thread per 4 consecutive
 // columns (16-byte loads), 4 independent partial sums so the slab loads pipeline.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const mmfn_gemm_desc d) {
@@ -864,6 +998,69 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
   return 0;
 }
 
+bool bf16_ok(const mmfn_gemm_desc& d) {
+  if (!(d.flags & MMFN_EPI_BF16_OPERANDS)) return false;
+  const bool a_kc = d.a_mode == MMFN_A_ROWMAJOR, a_mc = d.a_mode == MMFN_A_COLMAJOR;
+  const bool b_kc = d.b_mode == MMFN_B_NK, b_mc = d.b_mode == MMFN_B_KN;
+  if (!(a_kc || a_mc) || !(b_kc || b_mc)) return false;
+  if (d.K % HBK || (d.lda & 3) || (d.ldb & 3)) return false;
+  if ((((uintptr_t)d.A) | ((uintptr_t)d.B)) & 15) return false;
+  if (a_mc && ((d.M & 3) || d.M < 4)) return false;
+  if (b_mc && ((d.N & 3) || d.N < 4)) return false;
+  return true;
+}
+
+// Tile and split-K of the bf16 kernel: 128x128 tiles (the efficient shape) as long as they can give every CU a block, if
+// need be by splitting K (never below 8 k-tiles = 256 of K per split); 64x64 tiles only when even that leaves CUs idle
+// (short K, or batched launches, which do not split).  Then split until there are about two blocks per CU.
+void bf16_config(const mmfn_gemm_desc& d, int* bt, int* splitk) {
+  const int64_t nb = std::max(1, d.batch);
+  const int nkt = d.K / HBK;
+  const bool can_split = d.batch <= 1 && d.splitk != 1 && d.workspace != nullptr;
+  const int64_t max_sk = can_split ? std::max(1, std::min(32, nkt / 8)) : 1;
+  const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * nb;
+  *bt = (d.tile == 1 || (d.tile != 2 && big * max_sk >= 256)) ? 128 : 64;
+  const int64_t blocks = (int64_t)ceil_div(d.M, *bt) * ceil_div(d.N, *bt) * nb;
+  int sk = 1;
+  if (can_split) {
+    if (d.splitk > 1) sk = std::min(d.splitk, nkt);
+    else if (blocks < 384) sk = (int)std::max<int64_t>(1, std::min<int64_t>((512 + blocks - 1) / blocks, max_sk));
+  }
+  *splitk = sk;
+}
+
+int launch_bf16(const mmfn_gemm_desc& d, hipStream_t s) {
+  const int nkt = d.K / HBK;
+  int bt, sk;
+  bf16_config(d, &bt, &sk);
+  const int kps = ceil_div(nkt, sk), zdim = ceil_div(nkt, kps);
+  mmfn_gemm_desc dd = d;
+  dd.splitk = zdim;
+  const int tn = ceil_div(d.N, bt);
+  dim3 grid(ceil_div(d.M, bt) * tn, zdim, d.batch > 1 ? d.batch : 1);
+  const bool a_kc = d.a_mode == MMFN_A_ROWMAJOR, b_kc = d.b_mode == MMFN_B_NK;
+#define MMFN_LAUNCH_BF16(AK, BK_, T)                                                                                \
+  hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, T, T>), grid, dim3(NT), 0, s, dd, kps, tn)
+  if (bt == 128) {
+    if (a_kc && b_kc) MMFN_LAUNCH_BF16(true, true, 128);
+    else if (a_kc) MMFN_LAUNCH_BF16(true, false, 128);
+    else if (b_kc) MMFN_LAUNCH_BF16(false, true, 128);
+    else MMFN_LAUNCH_BF16(false, false, 128);
+  } else {
+    if (a_kc && b_kc) MMFN_LAUNCH_BF16(true, true, 64);
+    else if (a_kc) MMFN_LAUNCH_BF16(true, false, 64);
+    else if (b_kc) MMFN_LAUNCH_BF16(false, true, 64);
+    else MMFN_LAUNCH_BF16(false, false, 64);
+  }
+#undef MMFN_LAUNCH_BF16
+  MMFN_LAUNCH_CHECK();
+  if (zdim > 1) {
+    launch_splitk_reduce(dd, s);
+    MMFN_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 void pick_config(const mmfn_gemm_desc& d, int* tile, int* splitk) {
   // Time model per candidate tile (microseconds, constants fitted to tools/gemm_bench.py on MI355X):
   //   compute  = padded FLOPs / (95 TF/s * tile efficiency * fill), fill = min(1, blocks*sk / saturating blocks)
@@ -903,7 +1100,8 @@ extern "C" int64_t mmfn_gemm_workspace_bytes(const mmfn_gemm_desc* d) {
   float dummy;
   dd.workspace = &dummy;  // let pick_config consider split-K
   int tile, sk;
-  pick_config(dd, &tile, &sk);
+  if (bf16_ok(dd)) bf16_config(dd, &tile, &sk);
+  else pick_config(dd, &tile, &sk);
   return sk > 1 ? (int64_t)sk * d->M * d->N * (int64_t)sizeof(float) : 0;
 }
 
@@ -916,6 +1114,7 @@ extern "C" int mmfn_gemm_f32(const mmfn_gemm_desc* dp, void* stream) {
   if ((d.flags & MMFN_EPI_RESIDUAL) && !d.res) return MMFN_EINVAL;
   if ((d.flags & MMFN_EPI_MASK_AUX) && !d.aux) return MMFN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (bf16_ok(d)) return launch_bf16(d, s);
   int tile, sk;
   pick_config(d, &tile, &sk);
   const int a = d.a_mode, b = d.b_mode;

@@ -660,6 +660,17 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
+def _in_precision(fn):
+    """Run an Engine method with its plain GEMMs in the engine's arithmetic (ops.precision)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        with ops.precision(self.gemm_dtype):
+            return fn(self, *args, **kwargs)
+    return wrapped
+
+
 class Engine(object):
     """Forward / backward / optimizer step of one MMFN replica on one GPU.
 
@@ -703,6 +714,8 @@ class Engine(object):
         # gaps; captured into the hipGraph this becomes a fork/join DAG.
         self.side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         self.multi_stream = True
+        # "f32" (parity path) or "bf16": bf16 MFMA operands with fp32 accumulation for the Linear / Winograd GEMMs
+        self.gemm_dtype = getattr(cfg, "gemm_dtype", "f32")
         self.n_lanes = int(os.environ.get("MMFN_BRANCH_LANES", "3"))
         self.offload_wgrad = os.environ.get("MMFN_OFFLOAD_WGRAD", "1") == "1"
 
@@ -778,6 +791,7 @@ class Engine(object):
         return outs
 
     # ------------------------------------------------------------------ forward / backward
+    @_in_precision
     def forward(self, inp, training, gt=None):
         B = inp["target_point"].shape[0]
         ctx = self._ctx(B, training)
@@ -828,6 +842,7 @@ class Engine(object):
             if on_stage is not None:
                 on_stage(3 - s)
 
+    @_in_precision
     def backward_begin(self, dpred=None, gscale=None):
         """Head backward + gradient of the global-average-pool/sum: seeds the per-branch gradients."""
         ctx, B = self._last
@@ -837,6 +852,7 @@ class Engine(object):
         self._G = [bufs.get("G3.%d" % m, shp) for m, shp in enumerate(shapes)]
         ops.gap_sum_bwd(g_fused, self._G)
 
+    @_in_precision
     def backward_scale(self, s):
         """Backward of fusion scale s (3 = deepest): GPT_s, then ResNet stage s+1 of the three branches
         (s = 0: layer1 + stems + VectorNet).  After it returns (enqueues), backward stage 3-s is complete."""

@@ -233,3 +233,38 @@ def test_driving_session_equals_reference_pipeline(golden_dir):
     assert set(out) == {"steer", "throttle", "brake", "pred_wp", "pid"} and -1.0 <= out["steer"] <= 1.0
     with pytest.raises(ValueError):
         sess.predict(rgb[:100], pts, lanes, tp, speed)
+
+
+def test_bf16_operand_mode_tracks_the_fp32_path():
+    """GlobalConfig(gemm_dtype="bf16"): the Linear / Winograd GEMMs round their operands to bf16 (fp32 accumulation,
+    activations, master weights).  Not a parity mode - the check is that waypoints and loss stay within bf16's rounding
+    of the fp32 path and that the backward runs.  (Gradients are not compared here: this network's backward amplifies a
+    1e-6 rounding difference ~100x, see test_train_step_matches_oracle, so bf16's 2e-3 shows up as noise: cosine 0.99 on the
+    deepest stage, 0.65 on the shallow ones at batch 32)"""
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd import model as M
+    from oracle import harness
+    oracle, net32, batch, args = _setup("vec")
+    cfg16 = GlobalConfig(embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0, gemm_dtype="bf16")
+    net16 = M.MMFN(cfg16, DEV)
+    net16.load_state_dict(oracle.state_dict(), strict=True)
+    dargs = _dev_args(args)
+    gt = batch["gt_wp"].to(DEV)
+    losses, grads = [], []
+    for net in (net32, net16):
+        net.train()
+        for p in net.parameters():
+            p.grad = None
+        loss = torch.nn.functional.l1_loss(net(*dargs), gt, reduction="none").mean()
+        loss.backward()
+        losses.append(loss.item())
+        grads.append(net._layout.grads[:net._layout.tail].clone())
+    assert abs(losses[0] - losses[1]) <= 2e-2 * abs(losses[0]), losses
+    assert torch.isfinite(grads[1]).all() and grads[1].abs().max().item() > 0
+    harness.calibrate_bn(oracle, args)
+    for net in (net32, net16):
+        net.load_state_dict(oracle.state_dict(), strict=True)
+        net.eval()
+    with torch.no_grad():
+        a, b = net32(*dargs), net16(*dargs)
+    assert (a - b).abs().max().item() <= 2e-2 * max(1.0, a.abs().max().item()), (a - b).abs().max().item()

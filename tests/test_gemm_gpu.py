@@ -136,3 +136,52 @@ def test_winograd_conv_and_dgrad(cfg):
     _close(dw.permute(0, 3, 1, 2), wr.grad)
     dw_direct = ops.conv2d_wgrad(dy_nhwc, x_nhwc, tuple(w_ohwi.shape), 1, 1, tile=2)
     assert (dw - dw_direct).abs().max().item() <= 3e-5 * dw_direct.abs().max().item()
+
+
+@pytest.mark.parametrize("shape", [(384, 256, 512), (224, 160, 96), (6144, 512, 2048), (64, 2048, 6144)])
+def test_bf16_operand_gemm_forms(shape):
+    """MMFN_EPI_BF16_OPERANDS: every plain form equals the fp32 product of the bf16-rounded operands (fp32 accumulate);
+    epilogues, split-K and batching behave as in the fp32 kernel."""
+    from mmfn_amd import ops
+    dev = _dev()
+    M, N, K = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    b = torch.randn(N, generator=g)
+    rnd = lambda t: t.bfloat16().float()
+    xd, wd, dyd, bd = x.to(dev), w.to(dev), dy.to(dev), b.to(dev)
+
+    def close(got, ref):
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+
+    with ops.precision("bf16"):
+        close(ops.linear_fwd(xd, wd, bd, relu=True), torch.relu(rnd(x) @ rnd(w).t() + b))       # NT
+        close(ops.linear_dx(dyd, wd), rnd(dy) @ rnd(w))                                        # NN (n-contiguous weights)
+        close(ops.linear_dw(dyd, xd), rnd(dy).t() @ rnd(x))                                    # TN
+        close(ops.linear_dw(dyd, xd, splitk=3), rnd(dy).t() @ rnd(x))
+        res = torch.randn(M, N, generator=g)
+        close(ops.linear_fwd(xd, wd, bd, res=res.to(dev), ldr=N), rnd(x) @ rnd(w).t() + b + res)
+    # outside the context the same call is the fp32 path again; so is a contraction length that is not a multiple of 32
+    ref32 = x @ w.t() + b
+    assert (ops.linear_fwd(xd, wd, bd).cpu() - ref32).abs().max().item() <= 1e-4 * ref32.abs().max().item()
+    with ops.precision("bf16"):
+        got = ops.linear_fwd(xd[:, :K - 8].contiguous(), wd[:, :K - 8].contiguous(), bd).cpu()
+    ref = x[:, :K - 8] @ w[:, :K - 8].t() + b
+    assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def test_bf16_operand_batched_gemm():
+    from mmfn_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    V = torch.randn(36, 512, 128, generator=g)
+    U = torch.randn(36, 256, 128, generator=g)
+    out = torch.empty(36, 512, 256, device=dev)
+    with ops.precision("bf16"):
+        ops.gemm(V.to(dev), U.to(dev), out, 512, 256, 128, 128, 128, 256, ops.A_ROWMAJOR, ops.B_NK, batch=36,
+                 strideA=512 * 128, strideB=256 * 128, strideC=512 * 256)
+    ref = torch.einsum("tmk,tnk->tmn", V.bfloat16().float(), U.bfloat16().float())
+    assert (out.cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()

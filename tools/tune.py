@@ -19,12 +19,13 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/gfx950.json"
     dev = torch.device("cuda:0")
     jobs = [("vec", 32, 16384, False), ("img", 32, 16384, False), ("rad", 16, 65536, False), ("vec", 128, 16384, True)]
+    dtype = os.environ.get("TUNE_DTYPE", "f32")  # "bf16": tune the bf16-operand kernels' (tile, split-K) as well
     if os.environ.get("TUNE_JOBS"):
         jobs = jobs[:int(os.environ["TUNE_JOBS"])]
     for variant, B, n_lidar, image_only in jobs:
         t0 = time.time()
         torch.manual_seed(42)
-        net = {"vec": MMFN, "img": MMFNImg, "rad": MMFNRad}[variant](GlobalConfig(), dev)
+        net = {"vec": MMFN, "img": MMFNImg, "rad": MMFNRad}[variant](GlobalConfig(gemm_dtype=dtype), dev)
         net.train()
         inp, gt = bench.synth_inputs(B, dev, seed=42, n_lidar=n_lidar, variant=variant)
         eng = net._engine_for()
