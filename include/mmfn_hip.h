@@ -86,8 +86,10 @@ enum {
   MMFN_EPI_DROPOUT = 16,   /* v = keep ? v/(1-p) : 0, counter-based RNG                   */
   MMFN_EPI_RESIDUAL = 32,  /* + res[m*ldr + n]                                            */
   MMFN_EPI_ACCUM = 64,     /* + C[m,n] (beta = 1)                                         */
-  MMFN_EPI_BF16_OPERANDS = 128 /* opt-in mixed precision for plain GEMM forms: A and B rounded to bf16 on the way into LDS,
+  MMFN_EPI_BF16_OPERANDS = 128, /* opt-in mixed precision for plain GEMM forms: A and B rounded to bf16 on the way into LDS,
                                   bf16 MFMA, fp32 accumulate / epilogue / output (autocast-style; BASELINE configs[2]) */
+  MMFN_EPI_BF16X3 = 256    /* fp32 arithmetic on the bf16 MFMA pipe (plain GEMM forms): each operand element split exactly
+                              into three bf16 terms, six cross products accumulated in fp32: product error < 2^-22 relative */
 };
 
 typedef struct mmfn_gemm_desc {

@@ -696,12 +696,18 @@ constexpr int HBK = 32;  // k-tile of the bf16 kernel
 
 __device__ __forceinline__ int hslot(int row, int slot) { return slot ^ ((row >> 2) & 3); }
 
-template <bool A_KC, bool B_KC, int BM, int BN>
+// TERMS = 1: plain bf16 operands.  TERMS = 3 (MMFN_EPI_BF16X3): fp32 emulation - every operand element is split exactly into
+// three bf16 terms x = hi + mid + lo (8 + 8 + 8 significand bits) kept as three LDS planes, and each product is formed from the
+// six leading cross terms hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid (each exact in the fp32 accumulator; the dropped
+// mid*lo, lo*mid, lo*lo are below 2^-24 relative), i.e. fp32-accurate at 16/6 = 2.7x the fp32 MFMA rate.
+template <bool A_KC, bool B_KC, int BM, int BN, int TERMS>
 __global__ __launch_bounds__(NT) void gemm_bf16_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, const int tiles_n) {
   const mmfn_gemm_desc d = batch_view(d_in);
   constexpr int TM = BM / 64, TN = BN / 64;            // 32x32 accumulator tiles per wave (2x2 waves)
   constexpr int UA = BM * 8 / NT, UB = BN * 8 / NT;    // k-contiguous staging units (row, k-quad) per thread
-  __shared__ __attribute__((aligned(16))) __bf16 sm[2][(BM + BN) * HBK];
+  constexpr int NBUF = TERMS == 1 ? 2 : 1;             // three planes: single LDS stage (48 KB), two barriers per k-tile
+  constexpr int PLANE = (BM + BN) * HBK;
+  __shared__ __attribute__((aligned(16))) __bf16 sm[NBUF][TERMS * PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
@@ -737,15 +743,30 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(const mmfn_gemm_desc d_in
       if (B_KC ? i < UB : b_on) rb[i] = ld4(pb[i] + (B_KC ? (size_t)kt * HBK : (size_t)kt * HBK * d.ldb));
     }
   };
+  auto put = [&](__bf16* base, int off, const float* x) {  // 4 consecutive k of one row -> 1 or 3 bf16x4 planes
+    bf16x4 hi, mid, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = (__bf16)x[e];
+      if (TERMS == 3) {
+        const float r1 = x[e] - (float)hi[e];
+        mid[e] = (__bf16)r1;
+        lo[e] = (__bf16)(r1 - (float)mid[e]);
+      }
+    }
+    *reinterpret_cast<bf16x4*>(&base[off]) = hi;
+    if (TERMS == 3) {
+      *reinterpret_cast<bf16x4*>(&base[PLANE + off]) = mid;
+      *reinterpret_cast<bf16x4*>(&base[2 * PLANE + off]) = lo;
+    }
+  };
   auto store_kc = [&](__bf16* base, const f32x4* r, int units) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i >= units) break;
       const int u = tid + i * NT, row = u >> 3, q = u & 7;
-      bf16x4 v;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (__bf16)r[i][e];
-      *reinterpret_cast<bf16x4*>(&base[row * HBK + hslot(row, q >> 1) * 8 + (q & 1) * 4]) = v;
+      const float x[4] = {r[i][0], r[i][1], r[i][2], r[i][3]};
+      put(base, row * HBK + hslot(row, q >> 1) * 8 + (q & 1) * 4, x);
     }
   };
   auto store_mc = [&](__bf16* base, const f32x4* r, int quads) {  // r[j] = 4 consecutive rows at k = 4*kq + j
@@ -753,10 +774,8 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(const mmfn_gemm_desc d_in
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int row = mq * 4 + e;
-      bf16x4 v;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (__bf16)r[j][e];
-      *reinterpret_cast<bf16x4*>(&base[row * HBK + hslot(row, kq >> 1) * 8 + (kq & 1) * 4]) = v;
+      const float x[4] = {r[0][e], r[1][e], r[2][e], r[3][e]};
+      put(base, row * HBK + hslot(row, kq >> 1) * 8 + (kq & 1) * 4, x);
     }
   };
   auto store = [&](int buf) {
@@ -776,25 +795,43 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(const mmfn_gemm_desc d_in
     const __bf16* Bs = sm[cur] + BM * HBK;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-      bf16x8 a[TM], b[TN];
+      bf16x8 a[TERMS][TM], b[TERMS][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int ar = wm * TM * 32 + i * 32 + l31;
-        a[i] = *reinterpret_cast<const bf16x8*>(&As[ar * HBK + hslot(ar, 2 * s2 + h) * 8]);
+      for (int p = 0; p < TERMS; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int ar = wm * TM * 32 + i * 32 + l31;
+          a[p][i] = *reinterpret_cast<const bf16x8*>(&As[p * PLANE + ar * HBK + hslot(ar, 2 * s2 + h) * 8]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int br = wn * TN * 32 + j * 32 + l31;
+          b[p][j] = *reinterpret_cast<const bf16x8*>(&Bs[p * PLANE + br * HBK + hslot(br, 2 * s2 + h) * 8]);
+        }
       }
+      // term loop outermost: consecutive MFMAs go to different accumulators (a dependent MFMA would wait out the full
+      // latency of its predecessor); smallest cross terms first
+      constexpr int NTERM = TERMS == 3 ? 6 : 1;
+      constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int br = wn * TN * 32 + j * 32 + l31;
-        b[j] = *reinterpret_cast<const bf16x8*>(&Bs[br * HBK + hslot(br, 2 * s2 + h) * 8]);
+      for (int t = 0; t < NTERM; ++t) {
+        const int pa_ = TERMS == 3 ? TA[t] : 0, pb_ = TERMS == 3 ? TB[t] : 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[pa_][i], b[pb_][j], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (more) store(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    if (NBUF == 2) {
+      if (more) store(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    } else {
+      __syncthreads();  // every wave is done reading the stage before it is overwritten
+      if (more) store(0);
+      __syncthreads();
+    }
   }
   uint64_t key = 0;
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
@@ -999,7 +1036,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
 }
 
 bool bf16_ok(const mmfn_gemm_desc& d) {
-  if (!(d.flags & MMFN_EPI_BF16_OPERANDS)) return false;
+  if (!(d.flags & (MMFN_EPI_BF16_OPERANDS | MMFN_EPI_BF16X3))) return false;
   const bool a_kc = d.a_mode == MMFN_A_ROWMAJOR, a_mc = d.a_mode == MMFN_A_COLMAJOR;
   const bool b_kc = d.b_mode == MMFN_B_NK, b_mc = d.b_mode == MMFN_B_KN;
   if (!(a_kc || a_mc) || !(b_kc || b_mc)) return false;
@@ -1039,18 +1076,22 @@ int launch_bf16(const mmfn_gemm_desc& d, hipStream_t s) {
   const int tn = ceil_div(d.N, bt);
   dim3 grid(ceil_div(d.M, bt) * tn, zdim, d.batch > 1 ? d.batch : 1);
   const bool a_kc = d.a_mode == MMFN_A_ROWMAJOR, b_kc = d.b_mode == MMFN_B_NK;
+  const bool x3 = (d.flags & MMFN_EPI_BF16X3) != 0;
 #define MMFN_LAUNCH_BF16(AK, BK_, T)                                                                                \
-  hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, T, T>), grid, dim3(NT), 0, s, dd, kps, tn)
+  {                                                                                                                 \
+    if (x3) hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, T, T, 3>), grid, dim3(NT), 0, s, dd, kps, tn);             \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<AK, BK_, T, T, 1>), grid, dim3(NT), 0, s, dd, kps, tn);                \
+  }
   if (bt == 128) {
-    if (a_kc && b_kc) MMFN_LAUNCH_BF16(true, true, 128);
-    else if (a_kc) MMFN_LAUNCH_BF16(true, false, 128);
-    else if (b_kc) MMFN_LAUNCH_BF16(false, true, 128);
-    else MMFN_LAUNCH_BF16(false, false, 128);
+    if (a_kc && b_kc) MMFN_LAUNCH_BF16(true, true, 128)
+    else if (a_kc) MMFN_LAUNCH_BF16(true, false, 128)
+    else if (b_kc) MMFN_LAUNCH_BF16(false, true, 128)
+    else MMFN_LAUNCH_BF16(false, false, 128)
   } else {
-    if (a_kc && b_kc) MMFN_LAUNCH_BF16(true, true, 64);
-    else if (a_kc) MMFN_LAUNCH_BF16(true, false, 64);
-    else if (b_kc) MMFN_LAUNCH_BF16(false, true, 64);
-    else MMFN_LAUNCH_BF16(false, false, 64);
+    if (a_kc && b_kc) MMFN_LAUNCH_BF16(true, true, 64)
+    else if (a_kc) MMFN_LAUNCH_BF16(true, false, 64)
+    else if (b_kc) MMFN_LAUNCH_BF16(false, true, 64)
+    else MMFN_LAUNCH_BF16(false, false, 64)
   }
 #undef MMFN_LAUNCH_BF16
   MMFN_LAUNCH_CHECK();
