@@ -143,6 +143,5 @@ def test_graph_replay_epoch_equals_eager_epoch(store):
         if graph:
             assert len(tr._static_steps) == 1 and not isinstance(next(iter(tr._static_steps.values())), str)
         nets.append((tr.train_loss, net.state_dict()))
-    assert nets[0][0] == nets[1][0]
-    for k in nets[0][1]:
-        assert torch.equal(nets[0][1][k], nets[1][1][k]), k
+    worst = max(((nets[0][1][k].double() - nets[1][1][k].double()).abs().max().item(), k) for k in nets[0][1])
+    assert nets[0][0] == nets[1][0] and worst[0] == 0.0, (nets[0][0], nets[1][0], worst)
