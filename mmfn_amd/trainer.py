@@ -64,8 +64,15 @@ class Trainer(object):
                         loss = eng.train_step(inp, gt, lr=g["lr"], dp=dp, **adam)
                     else:
                         if state == "seen":
-                            state = self._static_steps[sig] = StaticBatchStep(eng, dp, inp, gt, g["lr"], **adam)
-                        loss = state(inp, gt)
+                            try:
+                                state = StaticBatchStep(eng, dp, inp, gt, g["lr"], **adam)
+                            except RuntimeError as exc:  # a failed capture must not take the run down: this shape stays eager
+                                import warnings
+                                warnings.warn("hipGraph capture of the training step failed (%s); continuing with eager launches" % exc)
+                                torch.cuda.synchronize()
+                                state = "eager"
+                            self._static_steps[sig] = state
+                        loss = eng.train_step(inp, gt, lr=g["lr"], dp=dp, **adam) if state == "eager" else state(inp, gt)
                 else:
                     loss = eng.train_step(inp, gt, lr=g["lr"], dp=dp, **adam)
             else:
