@@ -364,7 +364,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d_in,
   uint64_t key = 0;
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
   const bool to_slab = d.splitk > 1;
-  float* slab = to_slab ? d.workspace + (size_t)blockIdx.y * d.M * d.N : nullptr;
+  float* slab = to_slab ? d.workspace + ((size_t)blockIdx.y * max(1, d_in.batch) + (d_in.batch > 1 ? blockIdx.z : 0)) * d.M * d.N : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
   uint64_t key = 0;
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
   const bool to_slab = d.splitk > 1;
-  float* slab = to_slab ? d.workspace + (size_t)blockIdx.y * d.M * d.N : nullptr;
+  float* slab = to_slab ? d.workspace + ((size_t)blockIdx.y * max(1, d_in.batch) + (d_in.batch > 1 ? blockIdx.z : 0)) * d.M * d.N : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(const mmfn_gemm_desc d_in
   uint64_t key = 0;
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
   const bool to_slab = d.splitk > 1;
-  float* slab = to_slab ? d.workspace + (size_t)blockIdx.y * d.M * d.N : nullptr;
+  float* slab = to_slab ? d.workspace + ((size_t)blockIdx.y * max(1, d_in.batch) + (d_in.batch > 1 ? blockIdx.z : 0)) * d.M * d.N : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -927,7 +927,18 @@ __global__ __launch_bounds__(1024) void splitk_reduce_deep_kernel(const mmfn_gem
   }
 }
 
-void launch_splitk_reduce(const mmfn_gemm_desc& dd, hipStream_t s) {
+// Batched launches may split K too when the batch's outputs are packed back to back (strideC == M*N, ldc == N) and the
+// epilogue has no per-batch operand: the slabs are then [split][batch][M][N] and the combine kernel sees one (batch*M) x N matrix.
+bool batch_can_split(const mmfn_gemm_desc& d) {
+  return d.batch > 1 && d.strideC == (int64_t)d.M * d.N && d.ldc == d.N && !(d.flags & (MMFN_EPI_RESIDUAL | MMFN_EPI_MASK_AUX | MMFN_EPI_ACCUM));
+}
+
+void launch_splitk_reduce(const mmfn_gemm_desc& dd_in, hipStream_t s) {
+  mmfn_gemm_desc dd = dd_in;
+  if (dd.batch > 1) {  // (only reached when batch_can_split)
+    dd.M *= dd.batch;
+    dd.batch = 1;
+  }
   const size_t total = (size_t)dd.M * dd.N;
   if (dd.splitk >= 32 && total <= ((size_t)1 << 20)) {
     hipLaunchKernelGGL(splitk_reduce_deep_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, s, dd);
@@ -1053,7 +1064,7 @@ bool bf16_ok(const mmfn_gemm_desc& d) {
 void bf16_config(const mmfn_gemm_desc& d, int* bt, int* splitk) {
   const int64_t nb = std::max(1, d.batch);
   const int nkt = d.K / HBK;
-  const bool can_split = d.batch <= 1 && d.splitk != 1 && d.workspace != nullptr;
+  const bool can_split = (d.batch <= 1 || batch_can_split(d)) && d.splitk != 1 && d.workspace != nullptr;
   const int64_t max_sk = can_split ? std::max(1, std::min(32, nkt / 8)) : 1;
   const int64_t big = (int64_t)ceil_div(d.M, 128) * ceil_div(d.N, 128) * nb;
   *bt = (d.tile == 1 || (d.tile != 2 && big * max_sk >= 256)) ? 128 : 64;
@@ -1108,14 +1119,14 @@ void pick_config(const mmfn_gemm_desc& d, int* tile, int* splitk) {
   //   split-K  = slab write + slab read at ~3 TB/s + one extra launch (~3 us)
   // and the split factor is the smallest one that saturates the chip (capped so slabs stay small).
   const int nkt = ceil_div(d.K, BK);
-  const bool can_split = d.workspace != nullptr && d.splitk != 1 && d.batch <= 1;
+  const bool can_split = d.workspace != nullptr && d.splitk != 1 && (d.batch <= 1 || batch_can_split(d));
   int best = -1, best_sk = 1;
   double best_t = 0.0;
   for (int i = 0; i < 4; ++i) {
     const TileCand& c = kTiles[i];
     if (d.tile >= 1 && d.tile <= 4 && d.tile != c.id) continue;
     const int64_t tm = ceil_div(d.M, c.bm), tn = ceil_div(d.N, c.bn);
-    const int64_t blocks = tm * tn;
+    const int64_t blocks = tm * tn * std::max(1, d.batch);
     // outputs of only a handful of tiles (first-layer weight gradients, K = B*H*W ~ 1e5..1e6) may split deeper
     const int sk_cap = (int)std::max<int64_t>(48, std::min<int64_t>(512, 1024 / blocks));
     const int sk_max = can_split ? std::min(sk_cap, std::max(1, nkt / 8)) : 1;
@@ -1143,7 +1154,7 @@ extern "C" int64_t mmfn_gemm_workspace_bytes(const mmfn_gemm_desc* d) {
   int tile, sk;
   if (bf16_ok(dd)) bf16_config(dd, &tile, &sk);
   else pick_config(dd, &tile, &sk);
-  return sk > 1 ? (int64_t)sk * d->M * d->N * (int64_t)sizeof(float) : 0;
+  return sk > 1 ? (int64_t)sk * std::max(1, d->batch) * d->M * d->N * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int mmfn_gemm_f32(const mmfn_gemm_desc* dp, void* stream) {

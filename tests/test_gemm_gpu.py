@@ -185,3 +185,18 @@ def test_bf16_operand_batched_gemm():
                  strideA=512 * 128, strideB=256 * 128, strideC=512 * 256)
     ref = torch.einsum("tmk,tnk->tmn", V.bfloat16().float(), U.bfloat16().float())
     assert (out.cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_batched_gemm_split_k():
+    """Packed batched GEMMs (the Winograd-domain weight gradient: 36 x [Co x Ci x tiles]) may split K."""
+    from mmfn_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    dM = torch.randn(36, 512, 128, generator=g)   # [t][tiles][Co]
+    V = torch.randn(36, 512, 64, generator=g)     # [t][tiles][Ci]
+    ref = torch.einsum("tkm,tkn->tmn", dM, V)
+    for sk in (1, 4):
+        out = torch.empty(36, 128, 64, device=dev)
+        ops.gemm(dM.to(dev), V.to(dev), out, 128, 64, 512, 128, 64, 64, ops.A_COLMAJOR, ops.B_KN, batch=36,
+                 strideA=512 * 128, strideB=512 * 64, strideC=128 * 64, tile=2, splitk=sk)
+        assert (out.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), sk
