@@ -42,7 +42,8 @@ class Trainer(object):
         """One epoch.  graph=True (fused path): the second batch of a given shape captures the step into hipGraphs over
         static input buffers and every later batch of that shape only copies its inputs and replays (the first one runs
         eagerly and sizes the buffers); lane sets are zero-padded to a multiple of `lane_bucket` lanes so that ragged
-        batches fall into few shapes (padded lanes are masked by lane_num, which leaves the result unchanged)."""
+        batches fall into few shapes (padded lanes are masked by lane_num: outputs are unchanged, parameter gradients to
+        the last ulp of their row sums)."""
         model.train()
         eng = model._engine_for()
         if not hasattr(self, "_static_steps"):
@@ -55,8 +56,8 @@ class Trainer(object):
                 g = optimizer.param_groups[0]
                 inp = args if isinstance(args, dict) else model._pack(*args)  # raw-frame batches are engine inputs already
                 adam = dict(betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"])
+                inp = _bucket_lanes(inp, lane_bucket)  # in both modes, so that eager and replayed steps are bit-identical
                 if graph:
-                    inp = _bucket_lanes(inp, lane_bucket)
                     sig = StaticBatchStep.signature(inp, gt, g["lr"], adam)
                     state = self._static_steps.get(sig)
                     if state is None:  # first batch of this shape: eager (allocates the engine's buffers for it)
