@@ -102,37 +102,94 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(batch=8, steps=10, warmup=1, budget_s=25.0):
-    """The oracle's train step (fwd + L1 + bwd + AdamW, fp32) on the host cores."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_train_rate(batch, warmup, steps, threads):
+    """Median step time of the oracle's train step (zero-grad + fwd + L1 + bwd + AdamW, fp32, dropout 0.1 active)."""
     from oracle import fixtures, harness
-    threads = usable_cores()
-    torch.set_num_threads(threads)
     model = harness.build_oracle("vec", dropout=0.1)
     b = fixtures.synthetic_batch(batch, "vec", seed=42, lanes=64)
     args = harness.forward_args(b, "vec")
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
     model.train()
-
-    def step():
+    times = []
+    for i in range(warmup + steps):
+        t0 = time.perf_counter()
         for p in model.parameters():
             p.grad = None
         loss = harness.l1_waypoint_loss(model(*args), b["gt_wp"])
         loss.backward()
         opt.step()
+        if i >= warmup:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    return batch / times[len(times) // 2], times[len(times) // 2]
 
-    for _ in range(warmup):
-        step()
-    t0 = time.time()
-    done = 0
-    for _ in range(steps):
-        step()
-        done += 1
-        if time.time() - t0 > budget_s:
-            break
-    steps = done
-    dt = (time.time() - t0) / steps
-    return {"value": round(batch / dt, 3), "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": "%d train steps of the CPU oracle at batch %d (vec, fp32, %d torch threads)" % (steps, batch, threads)}
+
+def cpu_baseline(big_batch=32, small_batch=2, warmup=2, steps=5):
+    """the reference's CPU PyTorch path (here: the oracle, its validated restatement) timed on this
+    box's host cores - same step as the GPU (fwd + L1 + bwd + AdamW, fp32), all usable cores, B=2 (BASELINE configs[0]) and
+    the per-GPU batch (32), median of `steps` after `warmup` warm-ups, anomaly mode off.  `value` is the batch-32 figure
+    (the like-for-like comparison with the GPU line); the batch-2 figure rides along."""
+    threads = usable_cores()
+    torch.set_num_threads(threads)
+    v2, t2 = _cpu_train_rate(small_batch, warmup, steps, threads)
+    v32, t32 = _cpu_train_rate(big_batch, warmup, steps, threads)
+    return {"value": round(v32, 3), "unit": "samples/s", "cores": threads, "kind": "port", "cpu": cpu_model(),
+            "value_batch2": round(v2, 3),
+            "sample": "oracle train step (vec, fp32, %d torch threads), median of %d steps after %d warm-ups: batch %d %.2f s/step, "
+                      "batch %d %.2f s/step" % (threads, steps, warmup, big_batch, t32, small_batch, t2)}
+
+
+def oracle_batch_from_inputs(inp, variant):
+    """Device-resident engine inputs (synth_inputs) -> the CPU batch dict oracle.harness.forward_args takes."""
+    B = inp["target_point"].shape[0]
+    cpu = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
+    return {"rgb_u8": cpu["rgb_u8"], "lidar_pts": cpu["lidar_pts"], "target_point": cpu["target_point"], "velocity": cpu["velocity"],
+            "lane": cpu.get("lane", torch.zeros(B, 1, 10, 5)), "lane_num": cpu.get("lane_num", torch.ones(B)).long(),
+            "map_u8": cpu.get("map", torch.zeros(B, 3, 256, 256)), "radar": cpu.get("radar", torch.zeros(B, 81, 5)),
+            "radar_adj": cpu.get("radar_adj", torch.zeros(B, 81, 81))}
+
+
+def loss_vs_oracle(net, eng, inp, gt, variant):
+    """Waypoint L1 loss of the HIP path vs the CPU oracle on THE BENCHED BATCH with the current weights (train-mode BatchNorm,
+    dropout switched off on both sides because the reference's RNG stream cannot be reproduced).  Outside the timed region;
+    BatchNorm running statistics are restored afterwards."""
+    from oracle import harness
+    L = net._layout
+    cfg = eng.cfg
+    saved_p = (cfg.embd_pdrop, cfg.attn_pdrop, cfg.resid_pdrop)
+    saved_buf = (L.buffers_flat.clone(), L.counters_flat.clone())
+    rad_p = None if eng.rad is None else eng.rad.p
+    cfg.embd_pdrop = cfg.attn_pdrop = cfg.resid_pdrop = 0.0
+    if eng.rad is not None:
+        eng.rad.p = 0.0
+    try:
+        _, loss = eng.forward(inp, True, gt)
+        hip = float(loss.item())
+    finally:
+        cfg.embd_pdrop, cfg.attn_pdrop, cfg.resid_pdrop = saved_p
+        if eng.rad is not None:
+            eng.rad.p = rad_p
+        L.buffers_flat.copy_(saved_buf[0])
+        L.counters_flat.copy_(saved_buf[1])
+    oracle = harness.build_oracle(variant, dropout=0.0)
+    oracle.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
+    batch = oracle_batch_from_inputs(inp, variant)
+    torch.set_num_threads(usable_cores())
+    oracle.train()
+    with torch.no_grad():
+        ref = float(harness.l1_waypoint_loss(oracle(*harness.forward_args(batch, variant)), gt.cpu()).item())
+    return {"hip": round(hip, 7), "oracle": round(ref, 7), "abs_diff": float("%.3g" % abs(hip - ref)), "tolerance": 1e-4,
+            "note": "benched batch, current weights, train-mode BatchNorm, dropout off on both sides"}
 
 
 def main():
@@ -150,6 +207,7 @@ def main():
                          "accumulation, activations and master weights (BASELINE configs[2]; reported as dtype bf16)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-oracle-check", action="store_true", help="skip the loss_vs_oracle block (one CPU oracle forward)")
     ap.add_argument("--single-stream", action="store_true", help="disable encoder-branch concurrency (profiling runs)")
     ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps for the roofline block")
     args = ap.parse_args()
@@ -245,6 +303,20 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
+    comm = None
+    if dp is not None:
+        # exposed communication: time the compute stream waits for the gradient all-reduces at the end of the backward
+        # (what the overlap does not hide), over a few extra steps outside the timed region; max over ranks
+        dp.measure_exposed = True
+        for _ in range(3):
+            runner()
+        ex = torch.tensor([dp.exposed_ms() or 0.0], device=dev, dtype=torch.float64)
+        dp.measure_exposed = False
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        nbytes = 4 * sum(e - b for chunks in dp.buckets for b, e in chunks)
+        comm = {"backend": dist.get_backend(), "library": "RCCL over xGMI" if dist.get_backend() == "nccl" else dist.get_backend(),
+                "ranks": dist.get_world_size(), "allreduce_bytes_per_step": nbytes, "buckets": sum(len(c) for c in dp.buckets),
+                "exposed_ms_per_step": round(float(ex.item()), 3)}
     loss_val = None if image_only else float(eng._bufs_for(B).get("head.loss", (1,)).item())
     workload = ("full MMFN %s (ResNet34 img + ResNet18 LiDAR-BEV + %s -> 4 GPT fusion -> GRU), train step fwd+L1+bwd+AdamW, "
                 "batch %d/GPU, 400x300x3 u8 RGB + %d-pt LiDAR + %s"
@@ -263,6 +335,8 @@ def main():
                    "branch_streams": 1 if args.single_stream else eng.n_lanes},
         "loss": None if loss_val is None else round(loss_val, 6),
     }
+    if comm is not None:
+        result["comm"] = comm
     if rank == 0:
         # ---- roofline of the dominant kernel family (fp32 MFMA GEMM / implicit conv)
         prof = ops.GemmProfiler()
@@ -306,6 +380,8 @@ def main():
         if args.dtype != "f32":
             result["roofline"]["note"] = ("bf16 mode: the GEMMs with bf16 MFMA operands are priced against the fp32 MFMA peak here "
                                           "for comparability with the f32 run; their own dense peak is 2.5 PFLOP/s")
+        if not image_only and args.dtype == "f32" and not args.no_oracle_check:
+            result["loss_vs_oracle"] = loss_vs_oracle(net, eng, inp, gt, args.variant)
         if not args.no_cpu_baseline and not image_only and args.variant == "vec":
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))

@@ -213,6 +213,12 @@ int mmfn_gru_head_bwd_f32(const float* pred, const float* gt, const float* dpred
 int mmfn_step_advance(int64_t* step, void* stream);
 int mmfn_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, const int64_t* step, float grad_scale, void* stream);
+/* torch.optim.AdamW with param_groups (the reference's decay / no-decay split, model_vec.py:179-209) and hyper-parameters
+ * in DEVICE memory, so a learning-rate schedule does not invalidate a captured hipGraph.  hyper: [n_groups][8] floats
+ * {lr, beta1, beta2, eps, weight_decay, grad_scale, 0, 0}; group_of: one group id per 4 consecutive parameters (tensors
+ * of the flat layout are 16-byte aligned), NULL = all group 0; n must be a multiple of 4; n_groups <= 16. */
+int mmfn_adamw_groups_f32(float* p, const float* g, float* m, float* v, int64_t n, const uint8_t* group_of, const float* hyper,
+                          int n_groups, const int64_t* step, void* stream);
 
 /* ---- sensor ingest (dataloader.py:271-308, model_vec.py:33-44,368-381) ------------------------- */
 int mmfn_ingest_rgb_u8(const uint8_t* in, float* out, int B, int H, int W, int crop, void* stream);

@@ -716,6 +716,9 @@ class Engine(object):
         self.multi_stream = True
         # "f32" (parity path) or "bf16": bf16 MFMA operands with fp32 accumulation for the Linear / Winograd GEMMs
         self.gemm_dtype = getattr(cfg, "gemm_dtype", "f32")
+        self.opt_group_of = None
+        self.opt_hyper = torch.zeros(16, 8, dtype=torch.float32, device=dev)
+        self._hyper_host = None
         self.n_lanes = int(os.environ.get("MMFN_BRANCH_LANES", "3"))
         self.offload_wgrad = os.environ.get("MMFN_OFFLOAD_WGRAD", "1") == "1"
 
@@ -893,11 +896,44 @@ class Engine(object):
 
         self._branches([img_tail, lid_tail, map_tail])
 
-    def optimizer_step(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+    # ------------------------------------------------------------------ optimizer
+    def set_param_groups(self, group_of):
+        """group_of: uint8 device tensor with one optimizer-group id per 4 consecutive floats of the flat buffer
+        (optim.FusedAdamW builds it from torch-style param_groups), or None = one group."""
+        self.opt_group_of = group_of
+
+    def set_hyper(self, rows):
+        """rows: [(lr, beta1, beta2, eps, weight_decay, grad_scale), ...] one per optimizer group.  They live in a small
+        device table read by the AdamW kernel, so a learning-rate schedule changes the table (one tiny host-to-device copy,
+        outside any captured graph) instead of invalidating captured hipGraphs."""
+        rows = tuple(tuple(float(x) for x in r) for r in rows)
+        if rows == self._hyper_host:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("optimizer hyper-parameters changed inside a hipGraph capture; call Engine.set_hyper() before it")
+        if len(rows) > 16:
+            raise ValueError("at most 16 optimizer groups")
+        host = torch.zeros(16, 8, dtype=torch.float32)
+        for i, r in enumerate(rows):
+            host[i, :6] = torch.tensor(r, dtype=torch.float32)
+        self.opt_hyper.copy_(host.to(self.device, non_blocking=False))
+        self._hyper_host = rows
+
+    @staticmethod
+    def hyper_rows(lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0, groups=None):
+        if groups is None:
+            groups = [(lr, betas[0], betas[1], eps, weight_decay)]
+        return [tuple(r[:5]) + (grad_scale,) for r in groups]
+
+    def optimizer_step(self, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0, groups=None):
+        """torch.optim.AdamW step over the trained range of the flat buffer.  `groups`: per-group
+        (lr, beta1, beta2, eps, weight_decay) rows (FusedAdamW.hyper_rows()); default one group from the scalars."""
         L = self.layout
+        groups = self.hyper_rows(lr, betas, eps, weight_decay, grad_scale, groups)
+        self.set_hyper(groups)
         ops.step_advance(self.step_count)
-        ops.adamw(L.params, L.grads, L.exp_avg, L.exp_avg_sq, self.step_count, lr, betas[0], betas[1], eps, weight_decay,
-                  grad_scale, n=L.tail)
+        ops.adamw_groups(L.params, L.grads, L.exp_avg, L.exp_avg_sq, self.step_count, self.opt_hyper, len(groups),
+                         group_of=self.opt_group_of if len(groups) > 1 else None, n=L.tail)
 
     def train_step(self, inp, gt, lr=1e-4, dp=None, **adam):
         """zero-grad (implicit: every gradient is overwritten) + forward + L1 + backward + AdamW

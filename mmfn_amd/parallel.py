@@ -33,6 +33,10 @@ class DataParallel(object):
                 b += n
             self.buckets.append(chunks)
         self.pending = []
+        # exposed-communication probe: when enabled, finish() brackets its waits with events on the compute stream; the
+        # elapsed time between them is what the collectives did NOT hide behind the backward (bench.py --gpus N reports it)
+        self.measure_exposed = False
+        self.exposed = []
 
     def broadcast_parameters(self, src=0):
         L = self.layout
@@ -56,9 +60,25 @@ class DataParallel(object):
 
     def finish(self):
         """Make the compute stream wait for all outstanding reductions (before the optimizer)."""
+        probe = self.measure_exposed and self.layout.device.type == "cuda"
+        if probe:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for w in self.pending:
             w.wait()
         self.pending = []
+        if probe:
+            e1.record()
+            self.exposed.append((e0, e1))
+
+    def exposed_ms(self):
+        """Mean milliseconds per step the compute stream sat waiting for gradient reductions (needs measure_exposed)."""
+        if not self.exposed:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.exposed]
+        self.exposed = []
+        return sum(ms) / len(ms)
 
 
 class GraphedStep(object):
@@ -79,6 +99,8 @@ class GraphedStep(object):
             eng.train_step(inp, gt, lr=lr, dp=dp, **adam)
         torch.cuda.synchronize()
         scale = 1.0 / (dp.world if dp is not None else 1)
+        self.scale = scale
+        eng.set_hyper(eng.hyper_rows(lr=lr, grad_scale=scale, **adam))  # the captured AdamW reads them from device memory
 
         def first():
             from . import ops
@@ -99,6 +121,10 @@ class GraphedStep(object):
             self.graphs.append(g)
         self.loss = eng._bufs_for(inp["target_point"].shape[0]).get("head.loss", (1,))
 
+    def set_hyper(self, lr, **adam):
+        """New learning rate / Adam hyper-parameters for the following replays (no re-capture)."""
+        self.engine.set_hyper(self.engine.hyper_rows(lr=lr, grad_scale=self.scale, **adam))
+
     def __call__(self):
         g, dp = self.graphs, self.dp
         for i in range(4):
@@ -116,11 +142,15 @@ class StaticBatchStep(object):
     copies of the inputs (one hipGraph on a single GPU, the five-graph GraphedStep under data parallelism) and every call
     copies the new batch into them first.  What a real training loop needs to run at the replay rate of bench.py instead
     of being bound by ~2500 Python-issued launches per step.  The engine's buffers for this shape must already exist
-    (run one eager step of the shape first); lr / betas / eps / weight decay are baked into the captured launches."""
+    (run one eager step of the shape first).  lr / betas / eps / weight decay (per optimizer group) are NOT baked into the
+    capture: the AdamW kernel reads them from a device table that __call__ refreshes when they change."""
 
     def __init__(self, engine, dp, inp, gt, lr, **adam):
+        self.engine = engine
         self.inp = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
         self.gt = gt.clone()
+        self.scale = 1.0 / (dp.world if dp is not None else 1)
+        engine.set_hyper(engine.hyper_rows(lr=lr, grad_scale=self.scale, **adam))
         torch.cuda.synchronize()
         if dp is None:
             self.graph = torch.cuda.CUDAGraph()
@@ -133,11 +163,14 @@ class StaticBatchStep(object):
             self.run = self.seg
 
     @staticmethod
-    def signature(inp, gt, lr, adam):
+    def signature(inp, gt):
+        """Shapes only: hyper-parameters live in device memory and are not part of a capture's identity."""
         items = tuple(sorted((k, tuple(v.shape) if isinstance(v, torch.Tensor) else v) for k, v in inp.items()))
-        return items, tuple(gt.shape), lr, tuple(sorted((k, tuple(v) if isinstance(v, (tuple, list)) else v) for k, v in adam.items()))
+        return items, tuple(gt.shape)
 
-    def __call__(self, inp, gt):
+    def __call__(self, inp, gt, lr=None, **adam):
+        if lr is not None:
+            self.engine.set_hyper(self.engine.hyper_rows(lr=lr, grad_scale=self.scale, **adam))
         for k, v in inp.items():
             if isinstance(v, torch.Tensor):
                 self.inp[k].copy_(v, non_blocking=True)

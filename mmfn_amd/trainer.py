@@ -35,6 +35,7 @@ class Trainer(object):
         self.bestval = 1e10
         self.device = device
         self.logdir = log_dir
+        self.max_captured_shapes = 12  # ragged batches (lane buckets, LiDAR sizes) multiply the shapes: bound the captures
 
     # ------------------------------------------------------------------ one epoch of training
     def train(self, model, dataloader_train, config, optimizer, dp=None, fused=True, log_every=50, on_log=None, graph=True,
@@ -47,35 +48,41 @@ class Trainer(object):
         model.train()
         eng = model._engine_for()
         if not hasattr(self, "_static_steps"):
-            self._static_steps = {}
+            self._static_steps = {}      # input-shape signature -> "seen" | "eager" | StaticBatchStep, in LRU order
+            self._retired_steps = []
         total = torch.zeros(1, dtype=torch.float32, device=model._layout.device)
         window = torch.zeros_like(total)
         num_batches = 0
         for args, gt in D.DevicePrefetcher(dataloader_train, self.device, config, variant=model.variant):
             if fused:
-                g = optimizer.param_groups[0]
                 inp = args if isinstance(args, dict) else model._pack(*args)  # raw-frame batches are engine inputs already
-                adam = dict(betas=tuple(g["betas"]), eps=g["eps"], weight_decay=g["weight_decay"])
+                # per-group (lr, beta1, beta2, eps, weight_decay): read every step, so an LR scheduler just works - they go
+                # to the device table the AdamW kernel reads, captured graphs stay valid
+                adam = dict(groups=_hyper_rows(optimizer))
+                lr = optimizer.param_groups[0]["lr"]
                 inp = _bucket_lanes(inp, lane_bucket)  # in both modes, so that eager and replayed steps are bit-identical
                 if graph:
-                    sig = StaticBatchStep.signature(inp, gt, g["lr"], adam)
-                    state = self._static_steps.get(sig)
+                    sig = StaticBatchStep.signature(inp, gt)
+                    state = self._static_steps.pop(sig, None)
                     if state is None:  # first batch of this shape: eager (allocates the engine's buffers for it)
-                        self._static_steps[sig] = "seen"
-                        loss = eng.train_step(inp, gt, lr=g["lr"], dp=dp, **adam)
+                        state = "seen"
+                        loss = eng.train_step(inp, gt, lr=lr, dp=dp, **adam)
                     else:
                         if state == "seen":
                             try:
-                                state = StaticBatchStep(eng, dp, inp, gt, g["lr"], **adam)
+                                state = StaticBatchStep(eng, dp, inp, gt, lr, **adam)
                             except RuntimeError as exc:  # a failed capture must not take the run down: this shape stays eager
                                 import warnings
                                 warnings.warn("hipGraph capture of the training step failed (%s); continuing with eager launches" % exc)
                                 torch.cuda.synchronize()
                                 state = "eager"
-                            self._static_steps[sig] = state
-                        loss = eng.train_step(inp, gt, lr=g["lr"], dp=dp, **adam) if state == "eager" else state(inp, gt)
+                        loss = eng.train_step(inp, gt, lr=lr, dp=dp, **adam) if state == "eager" else state(inp, gt, lr=lr, **adam)
+                    self._static_steps[sig] = state  # re-inserted last: the dict is the LRU order
+                    while len(self._static_steps) > self.max_captured_shapes:
+                        old_sig = next(iter(self._static_steps))
+                        self._retired_steps.append(self._static_steps.pop(old_sig))  # graphs are kept alive, never replayed again
                 else:
-                    loss = eng.train_step(inp, gt, lr=g["lr"], dp=dp, **adam)
+                    loss = eng.train_step(inp, gt, lr=lr, dp=dp, **adam)
             else:
                 if dp is not None or isinstance(args, dict):
                     raise NotImplementedError("the autograd path takes reference-format batches on one GPU; use fused=True")
@@ -127,13 +134,19 @@ class Trainer(object):
             self.bestval_epoch = self.cur_epoch
         weights = _plain_state_dict(model)
         opt_state = optimizer.state_dict()
+        # every file goes to a temporary name first and is renamed into place; recent.log is written LAST, so a crash
+        # mid-save leaves the previous consistent (model, optimizer, log) triple behind, never a mixed one
         if best:
-            torch.save(weights, os.path.join(logdir, "best_model.pth"))
-            torch.save(opt_state, os.path.join(logdir, "best_optim.pth"))
-        torch.save(weights, os.path.join(logdir, "model.pth"))
-        torch.save(opt_state, os.path.join(logdir, "recent_optim.pth"))
-        with open(os.path.join(logdir, "recent.log"), "w") as f:
+            _atomic_save(weights, os.path.join(logdir, "best_model.pth"))
+            _atomic_save(opt_state, os.path.join(logdir, "best_optim.pth"))
+        _atomic_save(weights, os.path.join(logdir, "model.pth"))
+        _atomic_save(opt_state, os.path.join(logdir, "recent_optim.pth"))
+        tmp = os.path.join(logdir, "recent.log.tmp")
+        with open(tmp, "w") as f:
             f.write(json.dumps(self._log_table()))
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, os.path.join(logdir, "recent.log"))
         return best
 
     def resume(self, model, optimizer, logdir=None, which="best"):
@@ -151,6 +164,9 @@ class Trainer(object):
         self.train_loss = table["train_loss"]
         self.val_loss = table["val_loss"]
         names = ("best_model.pth", "best_optim.pth") if which == "best" else ("model.pth", "recent_optim.pth")
+        if not all(os.path.isfile(os.path.join(logdir, n)) for n in names):
+            # no validation set / no improvement yet: save() never wrote the best_* pair - continue from the recent one
+            names = ("model.pth", "recent_optim.pth")
         weights = torch.load(os.path.join(logdir, names[0]), map_location="cpu")
         model.load_state_dict({k[7:] if k.startswith("module.") else k: v for k, v in weights.items()})
         optimizer.load_state_dict(torch.load(os.path.join(logdir, names[1]), map_location="cpu"))
@@ -167,6 +183,40 @@ def _bucket_lanes(inp, bucket):
     return out
 
 
+def _atomic_save(obj, path):
+    tmp = path + ".tmp"
+    torch.save(obj, tmp)
+    os.replace(tmp, path)
+
+
+def _hyper_rows(optimizer):
+    if hasattr(optimizer, "hyper_rows"):
+        return optimizer.hyper_rows()
+    return [(g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"]) for g in optimizer.param_groups]
+
+
+def sync_resume_state(trainer, optimizer, dist, src=0):
+    """After rank `src` resumed from disk: every rank takes its epoch / iteration counters, loss history and the
+    optimizer hyper-parameters (lr, betas, eps, weight decay per group).  Without this the ranks would iterate different
+    epoch ranges (and deadlock in the gradient all-reduce when rank 0 leaves the loop first), seed their samplers
+    differently and step with different learning rates.  Weights / moments / step counter travel separately
+    (DataParallel.broadcast_parameters)."""
+    payload = [None]
+    if dist.get_rank() == src:
+        payload[0] = {"table": trainer._log_table(),
+                      "groups": [{k: g[k] for k in ("lr", "betas", "eps", "weight_decay")} for g in optimizer.param_groups]}
+    dist.broadcast_object_list(payload, src=src)
+    st = payload[0]
+    t = st["table"]
+    trainer.cur_epoch, trainer.cur_iter = t["epoch"], t["iter"]
+    trainer.bestval, trainer.bestval_epoch = t["bestval"], t["bestval_epoch"]
+    trainer.train_loss, trainer.val_loss = list(t["train_loss"]), list(t["val_loss"])
+    if len(st["groups"]) != len(optimizer.param_groups):
+        raise ValueError("rank %d has %d optimizer groups, rank %d has %d" % (dist.get_rank(), len(optimizer.param_groups), src, len(st["groups"])))
+    for g, new in zip(optimizer.param_groups, st["groups"]):
+        g["lr"], g["betas"], g["eps"], g["weight_decay"] = new["lr"], tuple(new["betas"]), new["eps"], new["weight_decay"]
+
+
 def _plain_state_dict(model):
     return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
@@ -179,7 +229,8 @@ def fit(model, optimizer, train_loader, val_loader, config, logdir, epochs, val_
     if rank == 0:
         trainer.resume(model, optimizer)
     if dp is not None:
-        dp.broadcast_parameters()
+        dp.broadcast_parameters()                       # weights, BN buffers, Adam moments, step counter, RNG
+        sync_resume_state(trainer, optimizer, dp.dist)  # epoch / iteration counters, loss history, lr & co
     for epoch in range(trainer.cur_epoch, epochs):
         sampler = getattr(train_loader, "sampler", None)
         if hasattr(sampler, "set_epoch"):

@@ -87,6 +87,7 @@ def test_train_step_matches_oracle(variant, golden_dir):
     import copy
     from oracle import harness
     oracle, net, batch, args = _setup(variant)
+    init_sd = {k: v.detach().clone() for k, v in oracle.state_dict().items()}
     o64 = copy.deepcopy(oracle).double()
     _, loss64, g64 = harness.train_step(o64, _to64(args), batch["gt_wp"].double())
     pred_ref, loss_ref, grads_ref = harness.train_step(oracle, args, batch["gt_wp"])
@@ -123,19 +124,71 @@ def test_train_step_matches_oracle(variant, golden_dir):
     # accurate summation order in the attention kernels) moves p95 between ~3.5 and ~6 on this batch, and other seeds
     # give 4..17 for every kernel generation tried (tools/grad_ratio.py); the per-tensor bound above is the hard check
     assert ratios[int(len(ratios) * 0.95)] <= 8.0, "95th percentile gradient error ratio %g" % ratios[int(len(ratios) * 0.95)]
-    # optimizer: torch AdamW on the views == what the reference loop does
+    # ---- the reference-generated vectors (tests/golden, oracle/make_golden.py): per-parameter gradient norms / first
+    # elements and the stage taps localise a drift to a layer.  The golden gradients are the
+    # fp32 reference's, so they carry that run's own fp32 error e_cpu (measured above against fp64) on top of ours.
+    names = [str(n) for n in g["param_names"]]
+    params = dict(net.named_parameters())
+    bad = []
+    for i, name in enumerate(names):
+        p = params[name]
+        if bool(g["grad_none"][i]):
+            assert p.grad is None, name
+            continue
+        t = g64[name]
+        n = t.norm().item()
+        e_cpu = (grads_ref[name].double() - t).norm().item()
+        tol = 13.0 * e_cpu + 2e-4 * n + 1e-8 * gmax
+        gn = p.grad.detach().double().norm().item()
+        head = p.grad.detach().flatten()[:8].cpu().double().numpy()
+        m = head.size
+        if abs(gn - float(g["grad_norm"][i])) > tol or np.abs(head - g["grad_head"][i][:m].astype(np.float64)).max() > tol:
+            bad.append((name, gn, float(g["grad_norm"][i]), tol))
+    assert not bad, "gradient vs reference-generated golden vectors (name, |hip|, |golden|, tol): %s" % bad[:8]
+    eng = net._engine_for()
+    taps = {"fused": eng.taps["fused"]}
+    for s_ in range(4):  # image tokens of GPT s: [B, 64, C] rows == the reference's NCHW [B, C, 8, 8] image output
+        taps["gpt%d_img" % (s_ + 1)] = eng.taps["gpt%d" % (s_ + 1)][:, :64].permute(0, 2, 1)
+    if variant != "img":
+        taps["vectornet"] = eng.taps["stage1"][2].permute(0, 3, 1, 2)  # NHWC map features -> "b n d a"
+    for k, v in taps.items():
+        v = v.contiguous().double().cpu()
+        ref_abs = float(g["tap_%s_abs" % k])
+        assert abs(v.sum().item() - float(g["tap_%s_sum" % k])) <= 2e-5 * ref_abs + 1e-6, k
+        assert abs(v.abs().sum().item() - ref_abs) <= 2e-5 * ref_abs + 1e-6, k
+        hd = g["tap_%s_head" % k].astype(np.float64)
+        assert np.abs(v.flatten()[:16].numpy() - hd).max() <= 1e-4 * max(1.0, np.abs(hd).max()), k
+    # ---- optimizer: torch AdamW on the views == what the reference loop does.  The first Adam step moves every weight
+    # by lr * g / (|g| + eps) ~ +-lr, so a meaningful check is elementwise on the UPDATE, restricted to the elements whose
+    # gradient sign fp32 arithmetic determines at all (|g| well above the fp32 oracle's own error against fp64).
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
     opt = torch.optim.AdamW(net.parameters(), lr=1e-4)
     opt.step()
-    ref_sd = oracle.state_dict()
+    ref_sd = oracle.state_dict()   # the oracle after ITS AdamW step (harness.train_step)
     got_sd = net.state_dict()
+    checked = total = 0
     for k, v in ref_sd.items():
         if v.dtype != torch.float32:
             assert int(got_sd[k].item()) == int(v.item()), k
             continue
-        d = (got_sd[k].cpu() - v).abs().max().item()
-        # one Adam step moves every weight by <= lr (sign-like update): noise-level gradients may flip
-        tol = 1e-3 * max(1.0, v.abs().max().item()) if "running" in k else 2.1e-4  # batch-2 variances: fp32 noise through 30 layers
-        assert d <= tol, (k, d)
+        if "running" in k:  # batch-2 variances: fp32 noise through 30 layers
+            d = (got_sd[k].cpu() - v).abs().max().item()
+            assert d <= 1e-3 * max(1.0, v.abs().max().item()), (k, d)
+            continue
+        if g64.get(k) is None:
+            assert torch.equal(got_sd[k].cpu(), before[k].cpu()), k   # no gradient -> untouched (torch semantics)
+            continue
+        t = g64[k]
+        sure = t.abs() > 10.0 * (grads_ref[k].double() - t).abs() + 1e-7 * gmax
+        upd_hip = (got_sd[k].cpu().double() - before[k].cpu().double())
+        # oracle's update, reconstructed from its post-step weights and the closed-form initial fill
+        upd_ref = (v.double() - init_sd[k].double())
+        total += t.numel()
+        checked += int(sure.sum())
+        if sure.any():
+            d = (upd_hip - upd_ref)[sure].abs().max().item()
+            assert d <= 2e-6, (k, d)   # lr = 1e-4: a wrong sign is 2e-4, a missing update 1e-4
+    assert checked >= 0.5 * total, (checked, total)
 
 
 def test_fused_train_step_equals_autograd_path():

@@ -112,3 +112,39 @@ def test_abi_library_exports_every_declared_symbol():
     handle = _lib.lib()
     assert handle.mmfn_abi_version() == 1
     assert set(_lib._SIGNATURES) == set(declared)
+
+
+def test_decay_groups_follow_the_reference_rule():
+    """configure_optimizers == GPT.configure_optimizers (model_vec.py:179-209) on the GPT sub-modules, extended to the whole
+    model: Linear / Conv2d weights decay; biases, LayerNorm / BatchNorm weights and pos_emb do not."""
+    import torch.nn as nn
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd.model import MMFNRad
+    from mmfn_amd.optim import FusedAdamW, configure_optimizers
+    m = MMFNRad(GlobalConfig(), "cpu")
+    groups = configure_optimizers(m)
+    name_of = {id(p): n for n, p in m.named_parameters()}
+    decay = {name_of[id(p)] for p in groups[0]["params"]}
+    no_decay = {name_of[id(p)] for p in groups[1]["params"]}
+    assert groups[0]["weight_decay"] == 0.01 and groups[1]["weight_decay"] == 0.0
+    assert decay | no_decay == set(name_of.values()) and not decay & no_decay
+    # the reference's rule, restated per module type
+    for mn, mod in m.named_modules():
+        for pn, _ in mod.named_parameters(recurse=False):
+            full = "%s.%s" % (mn, pn) if mn else pn
+            if pn.endswith("bias") or isinstance(mod, (nn.LayerNorm, nn.BatchNorm2d)) or pn == "pos_emb":
+                assert full in no_decay, full
+            elif pn.endswith("weight") and isinstance(mod, (nn.Linear, nn.Conv2d)):
+                assert full in decay, full
+    assert "encoder.transformer1.pos_emb" in no_decay and "decoder.bias_ih" in no_decay and "decoder.weight_hh" in decay
+    assert "encoder.radar_encoder.attention_0.W" in decay
+    opt = FusedAdamW(m, lr=1e-4, param_groups=groups)   # group-id map builds without a GPU
+    gid = opt._group_of
+    L = m._layout
+    off, n = L.offsets["encoder.transformer1.pos_emb"]
+    assert gid.numel() == L.total // 4 and int(gid[off // 4]) == 1 and int(gid[(off + n - 1) // 4]) == 1
+    off, n = L.offsets["encoder.transformer4.blocks.0.mlp.0.weight"]
+    assert int(gid[off // 4]) == 0
+    import pytest
+    with pytest.raises(ValueError):
+        FusedAdamW(m, param_groups=[{"params": groups[0]["params"]}])   # must cover every parameter

@@ -103,3 +103,46 @@ def test_stage_order_of_real_model():
     assert r[3][0] <= L.offsets["encoder.vectornet_encoder.generator.3.weight"][0] < r[3][1]
     sizes = [(e - b) * 4 / 2 ** 20 for b, e in r]
     assert sizes[0] > sum(sizes[1:])  # the first bucket (scale 4) is the largest -> most overlap
+
+
+def _resume_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mmfn_amd.trainer import Trainer, sync_resume_state
+
+    class _Opt(object):
+        def __init__(self):
+            self.param_groups = [dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, params=[]),
+                                 dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, params=[])]
+
+    tr, opt = Trainer("cpu", None), _Opt()
+    if rank == 0:  # what Trainer.resume() restored on rank 0 only
+        tr.cur_epoch, tr.cur_iter, tr.bestval, tr.bestval_epoch = 7, 1234, 0.25, 5
+        tr.train_loss, tr.val_loss = [3.0, 2.0], [2.5]
+        opt.param_groups[0].update(lr=2.5e-5, betas=(0.8, 0.99))
+        opt.param_groups[1].update(lr=5e-5)
+    sync_resume_state(tr, opt, dist)
+    got = (tr.cur_epoch, tr.cur_iter, tr.bestval, tr.bestval_epoch, tr.train_loss, tr.val_loss,
+           opt.param_groups[0]["lr"], opt.param_groups[0]["betas"], opt.param_groups[1]["lr"], opt.param_groups[1]["weight_decay"])
+    # every rank now iterates the same epoch range
+    out.put((rank, got, list(range(tr.cur_epoch, 9))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_resume_state_reaches_every_rank_gloo():
+    """after a rank-0 resume the other ranks must take its epoch counter and learning rate, otherwise
+    they iterate different epoch ranges and deadlock in the gradient all-reduce."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_resume_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2] == [7, 8]
+    assert res[1][1][:4] == (7, 1234, 0.25, 5) and res[1][1][6] == 2.5e-5 and res[1][1][7] == (0.8, 0.99)
