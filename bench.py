@@ -31,7 +31,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_
 ALGO_GFLOP_PER_SAMPLE = {"vec": 106.6, "img": 112.4, "rad": 117.7, "image-only": 28.4}
 
 
-def synth_inputs(B, device, seed, lanes=64, n_lidar=16384, variant="vec"):
+def synth_inputs(B, device, seed, lanes=64, n_lidar=16384, variant="vec", lane_format="10x5"):
     g = torch.Generator().manual_seed(seed)
     rgb = torch.randint(0, 256, (B, 300, 400, 3), generator=g, dtype=torch.uint8)
     pts = torch.empty(B, n_lidar, 4)
@@ -44,6 +44,10 @@ def synth_inputs(B, device, seed, lanes=64, n_lidar=16384, variant="vec"):
     lane[..., 2:5] = torch.randint(0, 2, (B, lanes, 10, 3), generator=g).float()
     lane_num = torch.randint(1, lanes + 1, (B,), generator=g)
     lane_num[0] = lanes
+    if lane_format == "19x8":  # north_star's perf-only variant: polylines already vectorised, 19 vectors x 8 features
+        lane = torch.zeros(B, lanes, 19, 8)
+        lane[..., 0:4] = torch.randn(B, lanes, 19, 4, generator=g) * 8.0
+        lane[..., 4:8] = torch.randint(0, 2, (B, lanes, 19, 4), generator=g).float()
     for i in range(B):
         lane[i, int(lane_num[i]):] = 0.0
     inp = {
@@ -181,7 +185,7 @@ def loss_vs_oracle(net, eng, inp, gt, variant):
             eng.rad.p = rad_p
         L.buffers_flat.copy_(saved_buf[0])
         L.counters_flat.copy_(saved_buf[1])
-    oracle = harness.build_oracle(variant, dropout=0.0)
+    oracle = harness.build_oracle(variant, dropout=0.0, lane_channels=getattr(eng.cfg, "lane_channels", 7))
     oracle.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()}, strict=True)
     batch = oracle_batch_from_inputs(inp, variant)
     torch.set_num_threads(usable_cores())
@@ -202,6 +206,9 @@ def main():
     ap.add_argument("--workload", default="train", choices=["train", "image-only"],
                     help="train = full step (BASELINE configs[1]); image-only = ResNet-34 branch fwd+bwd (configs[3])")
     ap.add_argument("--n-lidar", type=int, default=16384, help="LiDAR points per sample (configs[4]: 65536)")
+    ap.add_argument("--lane-format", default="10x5", choices=["10x5", "19x8"],
+                    help="10x5 = the reference's lane nodes (parity format, default); 19x8 = north_star's perf-only pre-vectorised "
+                         "polylines [B,64,19,8] (VectorNet with lane_channels=8; no reference checkpoint has this shape)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = the parity path (headline); bf16 = bf16 MFMA operands for the Linear / Winograd GEMMs with fp32 "
                          "accumulation, activations and master weights (BASELINE configs[2]; reported as dtype bf16)")
@@ -240,10 +247,10 @@ def main():
     from mmfn_amd.parallel import DataParallel
 
     torch.manual_seed(42)  # init_torch(): run_steps/utils.py:77-84
-    net = {"vec": MMFN, "img": MMFNImg, "rad": MMFNRad}[args.variant](GlobalConfig(gemm_dtype=args.dtype), dev)
+    net = {"vec": MMFN, "img": MMFNImg, "rad": MMFNRad}[args.variant](GlobalConfig(gemm_dtype=args.dtype, lane_channels=8 if args.lane_format == "19x8" else 7), dev)
     net.train()
     B = args.batch
-    inp, gt = synth_inputs(B, dev, seed=42 + rank, n_lidar=args.n_lidar, variant=args.variant)
+    inp, gt = synth_inputs(B, dev, seed=42 + rank, n_lidar=args.n_lidar, variant=args.variant, lane_format=args.lane_format)
     dp = DataParallel(net, dist) if world > 1 else None
     if dp is not None:
         dp.broadcast_parameters()
@@ -321,7 +328,7 @@ def main():
     workload = ("full MMFN %s (ResNet34 img + ResNet18 LiDAR-BEV + %s -> 4 GPT fusion -> GRU), train step fwd+L1+bwd+AdamW, "
                 "batch %d/GPU, 400x300x3 u8 RGB + %d-pt LiDAR + %s"
                 % (args.variant, {"vec": "VectorNet", "img": "ResNet34 raster map", "rad": "VectorNet + radar GAT"}[args.variant], B,
-                   args.n_lidar, "256x256x3 raster map" if args.variant == "img" else "64x10x5 lanes"
+                   args.n_lidar, "256x256x3 raster map" if args.variant == "img" else ("64x19x8 pre-vectorised polylines" if args.lane_format == "19x8" else "64x10x5 lanes")
                    + (" + 81x5 radar" if args.variant == "rad" else "")))
     if image_only:
         workload = "ResNet-34 camera branch alone, fwd+bwd (no optimizer), batch %d, 400x300x3 u8 RGB" % B
@@ -353,7 +360,8 @@ def main():
         traffic, traffic_src = None, None
         import glob
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-        default_workload = (not image_only and args.variant == "vec" and B == 32 and args.n_lidar == 16384 and args.dtype == "f32")
+        default_workload = (not image_only and args.variant == "vec" and B == 32 and args.n_lidar == 16384 and args.dtype == "f32"
+                            and args.lane_format == "10x5")
         if tfiles and default_workload:  # PMC-derived HBM bytes per launch of this kernel family (tools/profile_round.sh)
             rec = json.load(open(tfiles[-1]))
             traffic, traffic_src = round(rec["hbm_bytes_per_launch"]), os.path.basename(tfiles[-1])

@@ -43,6 +43,9 @@ class GlobalConfig(object):
     feature_num = 5
     up = down = left = right = 28
     tmp_town_for_save_opendrive = "/tmp/opendrvie_tmp"
+    # Subgraph input width.  7 is the reference (model_vec.py:434: vectors built from [.., 10, 5] lane nodes); 8 selects the
+    # PERF-ONLY pre-vectorised polyline input [B, L, 19, 8] named by BASELINE.json's north_star
+    lane_channels = 7
     # not in the reference: arithmetic of the Linear / Winograd GEMMs.  "f32" is the parity path; "bf16" rounds their operands
     # to bf16 on the way into the MFMA units (fp32 accumulation, activations and master weights; BASELINE configs[2])
     gemm_dtype = "f32"

@@ -11,23 +11,12 @@
 // K/V/Q fragments stream straight from L2 (the whole qkv of a sample is 1.2 MB).  The backward
 // runs two such passes (query-owned: dQ; key-owned: dK, dV) that recompute P from the saved
 // row log-sum-exp instead of storing it; dropout masks are regenerated from the counter RNG.
+#include <stdlib.h>
+
 #include "common.h"
+#include "attention_args.h"
 
 namespace {
-
-struct AttnArgs {
-  const float* q; const float* k; const float* v;  // row stride ld, head h at column h*HS
-  float* o;                                         // [B*T, ldo]
-  float* lse;                                       // [B, NH, T]
-  const float* dO;                                  // backward: grad of o (ldo)
-  float* delta;                                     // [B, NH, T]  sum_j P_j dP_j
-  float* dq; float* dk; float* dv;                  // row stride ldg
-  const int* kv_len;                                // optional [B]: keys >= kv_len[b] are masked
-  const uint64_t* rng_state;
-  int B, T, NH, ld, ldo, ldg;
-  float scale, drop_p;
-  uint32_t rng_stream;
-};
 
 __device__ __forceinline__ int rowmap(int r) { return (r & 3) + 8 * (r >> 2); }
 __device__ __forceinline__ f32x4 ld4g(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -114,6 +103,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
   const int q = qt * 32 + l31;
   const bool qvalid = q < T;
   const int kvlen = a.kv_len ? min(T, a.kv_len[b]) : T;
+  const bool nokeys = kvlen <= 0;
   const size_t rowbase = (size_t)b * T;
   const float* Qp = a.q + (rowbase + min(q, T - 1)) * a.ld + hd * HS + 4 * h;
   f32x4 qf[NC];
@@ -154,7 +144,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = (ktb + kt) * 32 + rowmap(r) + 4 * h;
-      const float v = key < kvlen ? s[kt][r] * a.scale : -INFINITY;
+      // kv_len == 0 (a sample without lanes): the reference's masked_fill(-1e9) + softmax degrades to UNIFORM attention
+      // over all T keys (model_vec.py:315-317) and stays finite; -inf everywhere would give 0/0
+      const float v = nokeys ? (key < T ? 0.f : -INFINITY) : (key < kvlen ? s[kt][r] * a.scale : -INFINITY);
       s[kt][r] = v;
       mx = fmaxf(mx, v);
     }
@@ -252,6 +244,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
   const bool qvalid = q < T;
   const int qc = min(q, T - 1);
   const int kvlen = a.kv_len ? min(T, a.kv_len[b]) : T;
+  const bool nokeys = kvlen <= 0;  // uniform attention whose scores are constants: P = 1/T, dS = 0 (see attn_fwd_kernel)
   const size_t rowbase = (size_t)b * T;
   stage_rows<HS>(sm_q, a.q + rowbase * a.ld + hd * HS, a.ld, qt * 32, T, threadIdx.x);
   stage_rows<HS>(sm_do, a.dO + rowbase * a.ldo + hd * HS, a.ldo, qt * 32, T, threadIdx.x);
@@ -303,7 +296,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = (ktb + kt) * 32 + rowmap(r) + 4 * h;
-        const float p = key < kvlen ? expf(st[r] * a.scale - lse) : 0.f;
+        const float p = nokeys ? (key < T ? expf(-lse) : 0.f) : (key < kvlen ? expf(st[r] * a.scale - lse) : 0.f);
         float dpv = dp[r];
         if (drop) dpv *= mmfn_dropout_scale(key64, pbase + (uint64_t)key, a.drop_p, inv_keep);
         ds[kt][r] = p;
@@ -326,7 +319,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
   for (int kt = 0; kt < NK2; ++kt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ds[kt][r] = ds[kt][r] * (dpt[kt][r] - delta) * a.scale;
+    for (int r = 0; r < 16; ++r) ds[kt][r] = nokeys ? 0.f : ds[kt][r] * (dpt[kt][r] - delta) * a.scale;
   const bool dok = ND * l31 < HS;
   f32x16 dq[ND];
 #pragma unroll
@@ -383,7 +376,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
   const int key = kt0 * 32 + l31;
   const bool kvalid = key < T;
   const int kvlen = a.kv_len ? min(T, a.kv_len[b]) : T;
-  const bool kin = key < kvlen;
+  const bool nokeys = kvlen <= 0;
+  const bool kin = nokeys ? kvalid : key < kvlen;
   const size_t rowbase = (size_t)b * T;
   stage_rows<HS>(sm_kf, a.k + rowbase * a.ld + hd * HS, a.ld, kt0 * 32, T, threadIdx.x);
   stage_rows<HS>(sm_vf, a.v + rowbase * a.ld + hd * HS, a.ld, kt0 * 32, T, threadIdx.x);
@@ -455,11 +449,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
         const int qrow = qt * 32 + rowmap(r) + 4 * h;
         const bool valid = qrow < T;
         const int qc = min(qrow, T - 1);
-        const float p = (valid && kin) ? expf(st[r] * a.scale - lsev[g & 1][rr]) : 0.f;
+        const float p = (valid && kin) ? expf((nokeys ? 0.f : st[r] * a.scale) - lsev[g & 1][rr]) : 0.f;
         float msc = 1.f;
         if (drop) msc = mmfn_dropout_scale(key64, (statbase + qc) * (uint64_t)T + (uint64_t)key, a.drop_p, inv_keep);
         const float pd = p * msc;
-        const float dsv = p * (dp[r] * msc - dlt[g & 1][rr]) * a.scale;
+        const float dsv = nokeys ? 0.f : p * (dp[r] * msc - dlt[g & 1][rr]) * a.scale;
 #pragma unroll
         for (int dt = 0; dt < ND; ++dt) {
           dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(pd, a1[g & 1][rr][dt], dv[dt], 0, 0, 0);
@@ -499,9 +493,20 @@ int dispatch_nkt(int which, const AttnArgs& a, hipStream_t s) {
   return MMFN_EINVAL;
 }
 
+// MMFN_ATTN_TILE_KERNELS=1 forces the one-tile-per-block kernels of this file for every shape (A/B runs, tests)
+bool tile_kernels_only() {
+  static const bool v = [] { const char* e = getenv("MMFN_ATTN_TILE_KERNELS"); return e && e[0] == '1'; }();
+  return v;
+}
+
 int dispatch(int which, int hs, const AttnArgs& a, hipStream_t s) {
   if (a.B <= 0 || a.T <= 0 || a.T > 256 || a.NH <= 0) return MMFN_EINVAL;
   if ((a.ld & 3) || (a.ldo & 3) || ((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.v & 15)) return MMFN_EINVAL;
+  if (!tile_kernels_only() && !(a.ldg & 3)) {
+    // T = 64 / 128 / 192 (the fusion transformers: 192 tokens): one workgroup per (sample, head, half), attention_wg.hip
+    const int rc = mmfn_attn_wg_launch(which, hs, a, s);
+    if (rc >= 0) return rc;
+  }
   switch (hs) {
     case 16: return dispatch_nkt<16>(which, a, s);
     case 32: return dispatch_nkt<32>(which, a, s);

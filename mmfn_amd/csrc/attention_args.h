@@ -1,0 +1,22 @@
+// Argument block shared by the attention kernels (attention.hip: one 32-query tile per block, any T <= 256;
+// attention_wg.hip: one (sample, head, half) per workgroup for T a multiple of 64).
+#pragma once
+#include "common.h"
+
+struct AttnArgs {
+  const float* q; const float* k; const float* v;  // row stride ld, head h at column h*HS
+  float* o;                                         // [B*T, ldo]
+  float* lse;                                       // [B, NH, T]
+  const float* dO;                                  // backward: grad of o (ldo)
+  float* delta;                                     // [B, NH, T]  sum_j P_j dP_j
+  float* dq; float* dk; float* dv;                  // row stride ldg
+  const int* kv_len;                                // optional [B]: keys >= kv_len[b] are masked
+  const uint64_t* rng_state;
+  int B, T, NH, ld, ldo, ldg;
+  float scale, drop_p;
+  uint32_t rng_stream;
+};
+
+// attention_wg.hip.  which: 0 forward, 1 backward dQ (+delta), 2 backward dK/dV.  Returns -1 when the shape is not
+// covered by the workgroup-per-half kernels (the caller then uses the tile kernels of attention.hip).
+int mmfn_attn_wg_launch(int which, int hs, const AttnArgs& a, hipStream_t s);

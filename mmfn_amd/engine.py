@@ -366,13 +366,20 @@ class VectorNet(object):
         self.heads = mod.L2L.heads
 
     def fwd(self, ctx, lane, lane_num):
-        """lane [B,L,n,5] f32, lane_num int32 [B]  ->  map features NHWC [B,64,64,64]."""
+        """lane [B,L,n,5] f32 nodes (reference format) or pre-vectorised polylines [B,L,V,lane_channels] (perf-only
+        64x19x8 variant, config.lane_channels = 8), lane_num int32 [B]  ->  map features NHWC [B,64,64,64]."""
         bufs, nm = ctx.bufs, self.name
-        B, L, n, _ = lane.shape
-        V = n - 1
-        R = B * L
-        vec = ops.lane_to_vector(lane, bufs.get(nm + ".vec", (R * V, 7)))
-        x = vec
+        B, L, n, F = lane.shape
+        cin = self.sub[0][0].w.shape[1]
+        if F == 5 and cin == 7:
+            V = n - 1
+            R = B * L
+            x = ops.lane_to_vector(lane, bufs.get(nm + ".vec", (R * V, 7)))
+        elif F == cin:
+            V, R = n, B * L
+            x = lane.view(R * V, cin)
+        else:
+            raise ValueError("lane tensor [..., %d, %d] does not fit a VectorNet with lane_channels=%d" % (n, F, cin))
         self.sub_saved = []
         for i, (lin, ln) in enumerate(self.sub):
             pre = bufs.get("%s.sub%d.pre" % (nm, i), (R * V, 64))

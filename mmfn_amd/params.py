@@ -155,7 +155,7 @@ def encoder_params(cfg, variant):
     e.lidar_encoder = Bag()
     e.lidar_encoder._model = resnet_trunk((2, 2, 2, 2), 2)
     if variant in ("vec", "rad"):
-        e.vectornet_encoder = vectornet_params()
+        e.vectornet_encoder = vectornet_params(lane_channels=getattr(cfg, "lane_channels", 7))
     if variant == "rad":
         e.radar_encoder = gat_params(5, cfg.hidden, cfg.attn_pdrop, cfg.alpha, cfg.nb_heads)
     n_modal = cfg.n_views + 2

@@ -30,6 +30,7 @@ class OracleConfig(object):
     alpha = 0.2
     lane_node_num = 10
     feature_num = 5
+    lane_channels = 7   # 8 = perf-only pre-vectorised [B, L, 19, 8] polylines (see oracle/model.py _VectornetEncoder)
 
     def __init__(self, **kwargs):
         for k, v in kwargs.items():

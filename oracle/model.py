@@ -217,6 +217,7 @@ class _MaskSelfAttention(nn.Module):
 class _VectornetEncoder(nn.Module):
     def __init__(self, lane_channels=7, hidden=64, layers=3, pos_dim=64, heads=2, fusion_dim=128):
         super().__init__()
+        self.lane_channels = lane_channels
         self.lane_subgraph = _Subgraph(lane_channels, hidden, layers)
         self.pos_emb = nn.Sequential(nn.Linear(2, pos_dim), nn.LayerNorm(pos_dim), nn.GELU(),
                                      nn.Linear(pos_dim, pos_dim))
@@ -238,7 +239,11 @@ class _VectornetEncoder(nn.Module):
         b = lane.shape[0]
         # the reference casts to float32; following the weights' dtype keeps that for fp32 models and
         # lets the same code run as an fp64 ground truth in the gradient-conditioning tests
-        tok = self.lane_subgraph(self.lane_to_vector(lane).to(self.L2L.to_qkv.weight.dtype))
+        # PERF-ONLY input variant (BASELINE.json north_star "64x19x8 polyline tensors"): lanes that
+        # arrive already vectorised [B, L, 19, lane_channels=8] skip the node->vector conversion.  Not a reference format:
+        # the reference hard-codes lane_channels=7 (model_vec.py:434) and always converts [.., 10, 5] nodes.
+        vec = lane if (lane.shape[-1] == self.lane_channels and self.lane_channels != 5) else self.lane_to_vector(lane)
+        tok = self.lane_subgraph(vec.to(self.L2L.to_qkv.weight.dtype))
         counts = lane_num.reshape(b).to(torch.int64)
         mask = (torch.arange(max_lane, device=lane.device)[None, :] < counts[:, None]).float()[:, None, :]
         tok = self.L2L(tok, mask)
@@ -302,7 +307,7 @@ class _Encoder(nn.Module):
         self.img_map_encoder = _ImageBranch(True)
         self.lidar_encoder = _LidarBranch()
         if variant in ("vec", "rad"):
-            self.vectornet_encoder = _VectornetEncoder()
+            self.vectornet_encoder = _VectornetEncoder(lane_channels=getattr(cfg, "lane_channels", 7))
         if variant == "rad":
             self.radar_encoder = _SpGAT(5, cfg.hidden, cfg.attn_pdrop, cfg.alpha, cfg.nb_heads)
         n_modal = cfg.n_views + 2

@@ -99,3 +99,35 @@ def test_radar_lists_of_any_length_feed_the_rad_model():
         ref = oracle(*args2)
         got = net(*_dev(args2)).cpu()
     assert (got - ref).abs().max().item() <= 1e-4
+
+
+def test_prevectorised_19x8_polylines_match_the_oracle():
+    """north_star's perf-only lane input: [B, 64, 19, 8] pre-vectorised polylines (GlobalConfig(lane_channels=8)) skip the
+    node->vector kernel; forward, loss and VectorNet gradients against the oracle built with the same lane_channels."""
+    import bench
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd.model import MMFN
+    from oracle import harness
+    torch.set_num_threads(bench.usable_cores())
+    B = 3
+    oracle = harness.build_oracle("vec", dropout=0.0, lane_channels=8)
+    net = MMFN(GlobalConfig(embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0, lane_channels=8), DEV)
+    net.load_state_dict(oracle.state_dict(), strict=True)
+    assert tuple(net.state_dict()["encoder.vectornet_encoder.lane_subgraph.layers.mlp_0.mlp.0.weight"].shape) == (64, 8)
+    inp, gt = bench.synth_inputs(B, torch.device(DEV), seed=5, lanes=64, n_lidar=4096, lane_format="19x8")
+    assert tuple(inp["lane"].shape) == (B, 64, 19, 8)
+    args = harness.forward_args(bench.oracle_batch_from_inputs(inp, "vec"), "vec")
+    pred_ref, loss_ref, grads_ref = harness.train_step(oracle, args, gt.cpu())
+    net.train()
+    eng = net._engine_for()
+    pred, loss = eng.forward(inp, True, gt)
+    eng.backward()
+    net._layout.attach_grads()
+    assert (pred.cpu() - pred_ref).abs().max().item() <= 1e-4 and abs(loss.item() - loss_ref.item()) <= 1e-4
+    vn = {n: g for n, g in grads_ref.items() if "vectornet_encoder" in n and g is not None}
+    floor = 1e-3 * max(g.norm().item() for g in vn.values())   # tiny-gradient tensors (LayerNorm gains) sit in fp32 noise
+    for name, p in net.named_parameters():
+        if "vectornet_encoder.lane_subgraph" in name or "vectornet_encoder.generator.3" in name:
+            ref = grads_ref[name]
+            err = (p.grad.cpu() - ref).norm().item()
+            assert err <= 5e-2 * ref.norm().item() + floor, (name, err, ref.norm().item(), floor)

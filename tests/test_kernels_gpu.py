@@ -181,7 +181,7 @@ def test_gap_and_transpose():
 
 # ------------------------------------------------------------------ attention
 @pytest.mark.parametrize("T,NH,HS", [(192, 4, 16), (192, 4, 32), (192, 4, 64), (192, 4, 128), (256, 4, 128),
-                                     (64, 2, 64), (9, 2, 64), (50, 2, 64)])
+                                     (128, 2, 64), (128, 4, 128), (64, 2, 64), (64, 3, 32), (9, 2, 64), (50, 2, 64)])
 @pytest.mark.parametrize("masked", [False, True])
 def test_attention(T, NH, HS, masked):
     from mmfn_amd import ops
@@ -212,6 +212,39 @@ def test_attention(T, NH, HS, masked):
     ops.attention_bwd(qd, qd[:, C:], qd[:, 2 * C:], 3 * C, o, dO.to(DEV).view(B * T, C), C, lse, delta, dqkv, dqkv[:, C:],
                       dqkv[:, 2 * C:], 3 * C, B, T, NH, HS, scale, kv_len=kvd)
     _close(dqkv.view(B, T, 3 * C), qr.grad, 5e-5, "attn bwd")
+
+
+@pytest.mark.parametrize("T", [48, 64])   # 48: tile kernels (attention.hip); 64: workgroup-per-half kernels (attention_wg.hip)
+def test_attention_sample_without_keys_is_uniform_and_finite(T):
+    """kv_len[b] == 0 (a sample with zero lanes): the reference's masked_fill(-1e9) + softmax gives uniform attention over
+    the padded keys and a zero score gradient (model_vec.py:315-317); the kernels must do the same instead of 0/0 = NaN."""
+    from mmfn_amd import ops
+    B, NH, HS = 3, 2, 64
+    C = NH * HS
+    g = _g(77)
+    qkv = torch.randn(B, T, 3 * C, generator=g)
+    dO = torch.randn(B, T, C, generator=g)
+    scale = HS ** -0.5
+    kv_len = torch.tensor([0, 5, 0], dtype=torch.int32)
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = (t.view(B, T, NH, HS).transpose(1, 2) for t in qr.chunk(3, dim=-1))
+    keep = (torch.arange(T)[None, :] < kv_len[:, None]).view(B, 1, 1, T)
+    att = ((q @ k.transpose(-1, -2)) * scale).masked_fill(~keep, -1e9)
+    o_ref = (torch.softmax(att, -1) @ v).transpose(1, 2).reshape(B, T, C)
+    o_ref.backward(dO)
+    qd = qkv.to(DEV).view(B * T, 3 * C)
+    o = torch.empty(B * T, C, device=DEV)
+    lse = torch.empty(B, NH, T, device=DEV)
+    ops.attention_fwd(qd, qd[:, C:], qd[:, 2 * C:], 3 * C, o, C, lse, B, T, NH, HS, scale, kv_len=kv_len.to(DEV))
+    assert torch.isfinite(o).all()
+    _close(o.view(B, T, C), o_ref, 2e-5, "attn fwd, empty key set")
+    dqkv = torch.zeros(B * T, 3 * C, device=DEV)
+    delta = torch.empty(B, NH, T, device=DEV)
+    ops.attention_bwd(qd, qd[:, C:], qd[:, 2 * C:], 3 * C, o, dO.to(DEV).view(B * T, C), C, lse, delta, dqkv, dqkv[:, C:],
+                      dqkv[:, 2 * C:], 3 * C, B, T, NH, HS, scale, kv_len=kv_len.to(DEV))
+    assert torch.isfinite(dqkv).all()
+    _close(dqkv.view(B, T, 3 * C), qr.grad, 5e-5, "attn bwd, empty key set")
+    assert dqkv.view(B, T, 3 * C)[0, :, :2 * C].abs().max().item() == 0.0   # constant scores: no gradient to q, k
 
 
 def test_attention_dropout_consistency():

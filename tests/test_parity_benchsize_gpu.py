@@ -5,9 +5,11 @@
   configs[3]  ResNet-34 camera branch alone, batch 128          against a torch fp32 ResNet-34 (oracle/model.py)
 
 The oracle (plain PyTorch fp32 on the host cores) needs ~5-20 s per step at these sizes.  north_star bar: waypoint L1
-loss within 1e-4 of the reference CPU path on identical batches; waypoints within 1e-4.  At these batch sizes BatchNorm
-statistics are well conditioned, so gradients are compared directly with the fp32 oracle (per-tensor relative error and
-cosine), which also checks every (tile, split-K) entry of the tuning table that only the large shapes select."""
+loss within 1e-4 of the reference CPU path on identical batches; waypoints within 1e-4.  Gradients: two fp32 evaluations
+of this graph (85 train-mode BatchNorms in the backward) differ by ~1e-2 relative per tensor even at batch 32, so - as in
+tests/test_e2e_gpu.py - the HIP gradient is judged against an fp64 oracle with the fp32 oracle's own error on the same
+tensor as the yardstick.  This also exercises every (tile, split-K) entry of the tuning table that only the large shapes
+select."""
 import os
 
 import numpy as np
@@ -48,31 +50,64 @@ def _raw_inputs(batch, variant):
     return inp
 
 
-def _grad_report(net, grads_ref):
-    """Per-parameter relative error / cosine of the HIP gradient against the fp32 oracle's."""
+def _to64(a):
+    if torch.is_tensor(a):
+        return a.double() if a.is_floating_point() else a
+    if isinstance(a, (list, tuple)):
+        return type(a)(_to64(x) for x in a)
+    return a
+
+
+def _grad_report(hip_grads, g32, g64):
+    """Per-parameter error of the HIP gradient and of the fp32 oracle's gradient, both against an fp64 evaluation of the
+    same graph: (|hip - f64| / |f64|, |cpu32 - f64| / |f64|, cosine(hip, f64), name)."""
     rows = []
-    gmax = max(t.norm().item() for t in grads_ref.values() if t is not None)
-    for name, p in net.named_parameters():
-        t = grads_ref[name]
+    gmax = max(t.norm().item() for t in g64.values() if t is not None)
+    for name, t in g64.items():
+        a = hip_grads[name]
         if t is None:
-            assert p.grad is None, name
+            assert a is None, name
             continue
-        assert p.grad is not None, name
-        a = p.grad.detach().cpu().double().flatten()
-        b = t.double().flatten()
+        assert a is not None, name
+        a = a.detach().cpu().double().flatten()
+        b = t.flatten()
         n = b.norm().item()
         if n <= 1e-7 * gmax:   # exactly-zero / noise-level tensors (pos_emb.0.weight: zero input)
             assert a.norm().item() <= 1e-5 * gmax, name
             continue
-        rel = (a - b).norm().item() / n
-        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
-        rows.append((rel, cos, name))
+        c = g32[name].double().flatten()
+        rows.append(((a - b).norm().item() / n, (c - b).norm().item() / n, float(torch.dot(a, b) / (a.norm() * b.norm())), name))
     return rows
 
 
+def _judge_gradients(rows, tag):
+    """Both the HIP path and the CPU oracle are fp32 evaluations of a graph whose backward amplifies rounding (85 train-mode
+    BatchNorms): the yardstick for the HIP error is the fp32 oracle's OWN error against fp64 on the same tensor."""
+    rel_hip = sorted(r[0] for r in rows)
+    rel_cpu = sorted(r[1] for r in rows)
+    ratios = sorted(r[0] / max(r[1], 1e-9) for r in rows)
+    worst = max(rows)
+    print("[%s] gradient error vs fp64: HIP median %.2e p95 %.2e max %.2e (%s) | CPU fp32 oracle median %.2e p95 %.2e max %.2e | "
+          "ratio HIP/CPU median %.2f p95 %.2f | min cosine %.6f"
+          % (tag, rel_hip[len(rows) // 2], rel_hip[int(len(rows) * 0.95)], worst[0], worst[3], rel_cpu[len(rows) // 2],
+             rel_cpu[int(len(rows) * 0.95)], rel_cpu[-1], ratios[len(rows) // 2], ratios[int(len(rows) * 0.95)], min(r[2] for r in rows)))
+    assert ratios[len(rows) // 2] <= 2.5, "median HIP / CPU-fp32 gradient error ratio %g" % ratios[len(rows) // 2]
+    assert ratios[int(len(rows) * 0.95)] <= 8.0, "p95 HIP / CPU-fp32 gradient error ratio %g" % ratios[int(len(rows) * 0.95)]
+    # per tensor: 12x the fp32 oracle's error on that tensor, or on a typical tensor where the oracle happened to land
+    # unusually close to fp64 (the error ratio is long-tailed in both directions).  No cosine bound: with this closed-form
+    # weight fill some tensors' fp32 gradients - the oracle's included - point opposite to the fp64 ones (cosine -0.99999).
+    med_cpu = rel_cpu[len(rows) // 2]
+    bad = [r for r in rows if r[0] > 12.0 * max(r[1], med_cpu) + 2e-4]
+    assert not bad, "per-tensor bound (|hip-f64|, |cpu32-f64|, cos, name): %s" % bad[:6]
+
+
 def _check_train_step(variant, B, n_lidar):
+    import copy
     from oracle import harness
     oracle, net, batch, args = _build(variant, B, n_lidar)
+    o64 = copy.deepcopy(oracle).double()
+    _, loss64, g64 = harness.train_step(o64, _to64(args), batch["gt_wp"].double())
+    del o64
     pred_ref, loss_ref, grads_ref = harness.train_step(oracle, args, batch["gt_wp"])
     net.train()
     eng = net._engine_for()
@@ -84,38 +119,35 @@ def _check_train_step(variant, B, n_lidar):
     torch.cuda.synchronize()
     wp_err = (pred.cpu() - pred_ref).abs().max().item()
     loss_err = abs(loss.item() - loss_ref.item())
-    rows = _grad_report(net, grads_ref)
-    rows.sort(reverse=True)
-    rels = sorted(r[0] for r in rows)
-    print("\n[%s B=%d N=%d] loss hip %.7f oracle %.7f |diff| %.2e; waypoint max err %.2e; grad rel err median %.2e p95 %.2e max %.2e (%s); min cos %.6f"
-          % (variant, B, n_lidar, loss.item(), loss_ref.item(), loss_err, wp_err, rels[len(rels) // 2], rels[int(len(rels) * 0.95)],
-             rows[0][0], rows[0][2], min(r[1] for r in rows)))
+    print("\n[%s B=%d N=%d] loss hip %.7f oracle fp32 %.7f fp64 %.7f |hip-fp32| %.2e; waypoint max err %.2e"
+          % (variant, B, n_lidar, loss.item(), loss_ref.item(), loss64.item(), loss_err, wp_err))
     assert loss_err <= 1e-4, (loss.item(), loss_ref.item())          # north_star: within 1e-4 fp32
+    assert abs(loss.item() - loss64.item()) <= 1e-4
     assert wp_err <= 1e-4 * max(1.0, pred_ref.abs().max().item()), wp_err
-    # gradients vs the fp32 oracle: both sides are fp32 evaluations of a graph whose backward amplifies rounding
-    # (85 train-mode BatchNorms), so the bound is statistical + a hard per-tensor cap
-    assert rels[len(rels) // 2] <= 2e-3, "median relative gradient error %g" % rels[len(rels) // 2]
-    assert rels[int(len(rels) * 0.95)] <= 2e-2, "p95 relative gradient error %g" % rels[int(len(rels) * 0.95)]
-    assert rows[0][0] <= 0.25 and min(r[1] for r in rows) >= 0.97, rows[:5]
-    # one fused AdamW step from these gradients == torch.optim.AdamW on the oracle (elements with a determined sign)
+    hip_grads = {n: p.grad for n, p in net.named_parameters()}
+    _judge_gradients(_grad_report(hip_grads, grads_ref, g64), "%s B=%d" % (variant, B))
+    # one fused AdamW step from these gradients == torch.optim.AdamW on the oracle, on the elements whose gradient sign both
+    # fp32 evaluations determine
     init = {k: v.detach().clone() for k, v in net.named_parameters()}
+    hip_g = {k: v.grad.detach().cpu().double() for k, v in net.named_parameters() if v.grad is not None}
     eng.optimizer_step(lr=1e-4)
     torch.cuda.synchronize()
     ref_sd = oracle.state_dict()
     checked = total = 0
+    gmax = max(t.norm().item() for t in g64.values() if t is not None)
     for name, p in net.named_parameters():
-        t = grads_ref[name]
+        t = g64[name]
         if t is None:
             continue
-        sure = t.abs() > 1e-3 * t.abs().max()
+        sure = t.abs() > 10.0 * torch.maximum((grads_ref[name].double() - t).abs(), (hip_g[name] - t).abs()) + 1e-7 * gmax
         upd = (p.detach().cpu().double() - init[name].cpu().double())
         upd_ref = ref_sd[name].double() - init[name].cpu().double()
         total += t.numel()
         checked += int(sure.sum())
         if sure.any():
-            frac_bad = ((upd - upd_ref)[sure].abs() > 2e-6).double().mean().item()
-            assert frac_bad <= 2e-3, (name, frac_bad)
-    assert checked > 0.2 * total
+            d = (upd - upd_ref)[sure].abs().max().item()
+            assert d <= 2e-6, (name, d)   # lr 1e-4: a wrong sign is 2e-4, a missing update 1e-4
+    assert checked > 0.3 * total, (checked, total)
     # BatchNorm running statistics after the step (momentum 0.1, unbiased variance)
     got_sd = net.state_dict()
     for k, v in ref_sd.items():
@@ -169,33 +201,33 @@ def test_image_branch_batch128_matches_torch_resnet34():
     pooled = step()
     net._layout.attach_grads()
     torch.cuda.synchronize()
-    # torch fp32 reference: same crop, normalisation, trunk, global average pool, loss = mean(pooled)
-    trunk = oracle.encoder.image_encoder.features
-    trunk.train()
+    # torch reference: same crop, normalisation, trunk, global average pool, loss = mean(pooled) - in fp32 (the oracle) and
+    # in fp64 (the yardstick for both fp32 evaluations)
+    import copy
     x = torch.from_numpy(np.stack([preprocess.crop_chw(im) for im in rgb.numpy()]).copy()).float()
     x = normalize_imagenet(x)
-    f = trunk.stem(x)
-    for li in range(1, 5):
-        f = getattr(trunk, "layer%d" % li)(f)
-    ref_pooled = f.mean((2, 3))
-    ref_pooled.mean().backward()
-    err = (pooled.cpu() - ref_pooled.detach()).abs().max().item()
-    assert err <= 1e-4 * max(1.0, ref_pooled.abs().max().item()), err
-    ref_grads = {"encoder.image_encoder.features." + k: p.grad for k, p in trunk.named_parameters()}
-    rows = []
-    gmax = max(t.norm().item() for t in ref_grads.values() if t is not None)
+
+    def run(trunk, x):
+        trunk.train()
+        for p in trunk.parameters():
+            p.grad = None
+        f = trunk.stem(x)
+        for li in range(1, 5):
+            f = getattr(trunk, "layer%d" % li)(f)
+        pooled = f.mean((2, 3))
+        pooled.mean().backward()
+        return pooled.detach(), {"encoder.image_encoder.features." + k: p.grad for k, p in trunk.named_parameters()}
+
+    trunk = oracle.encoder.image_encoder.features
+    t64 = copy.deepcopy(trunk).double()
+    pooled64, g64 = run(t64, x.double())
+    ref_pooled, g32 = run(trunk, x)
+    err = (pooled.cpu().double() - pooled64).abs().max().item()
+    err_cpu = (ref_pooled.double() - pooled64).abs().max().item()
+    print("\n[image-only B=128] pooled max err vs fp64: HIP %.2e, CPU fp32 oracle %.2e" % (err, err_cpu))
+    # 36 convolutions + train-mode BatchNorms deep: the fp32 oracle itself is this far from fp64
+    assert err <= max(4.0 * err_cpu, 1e-4 * max(1.0, pooled64.abs().max().item())), (err, err_cpu)
     params = dict(net.named_parameters())
-    for name, t in ref_grads.items():
-        if t is None:   # fc of the torchvision trunk is unused (model_vec.py:24)
-            continue
-        a = params[name].grad.detach().cpu().double().flatten()
-        b = t.double().flatten()
-        if b.norm().item() <= 1e-7 * gmax:
-            continue
-        rows.append(((a - b).norm().item() / b.norm().item(), float(torch.dot(a, b) / (a.norm() * b.norm())), name))
-    rows.sort(reverse=True)
-    rels = sorted(r[0] for r in rows)
-    print("\n[image-only B=128] pooled max err %.2e; grad rel err median %.2e p95 %.2e max %.2e (%s)"
-          % (err, rels[len(rels) // 2], rels[int(len(rels) * 0.95)], rows[0][0], rows[0][2]))
+    rows = _grad_report({k: params[k].grad for k in g64}, g32, g64)
     assert len(rows) >= 100
-    assert rels[len(rels) // 2] <= 2e-3 and rels[int(len(rels) * 0.95)] <= 2e-2 and rows[0][0] <= 0.25, rows[:5]
+    _judge_gradients(rows, "image-only B=128")

@@ -119,7 +119,8 @@ def main():
     init = {k: v.detach().clone() for k, v in oracle.named_parameters()}
     torch.optim.AdamW(oracle.parameters(), lr=1e-4).step()
     for name, (m32, m64) in means.items():
-        sure = m64.abs() > 10.0 * (m32 - m64).abs() + 1e-7 * gmax
+        ghip = named[name].grad.detach().cpu().double() / world
+        sure = m64.abs() > 10.0 * torch.maximum((m32 - m64).abs(), (ghip - m64).abs()) + 1e-7 * gmax
         upd_ref = ref_params[name].detach().double() - init[name].double()
         upd_hip = named[name].detach().cpu().double() - init[name].double()
         total += m64.numel(); checked += int(sure.sum())
