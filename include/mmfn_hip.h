@@ -51,6 +51,10 @@ int mmfn_wino_output_stats_f32(const float* Mt, float* y, double* partials, int*
 /* weight gradient in the F(4x4,3x3) domain: dw = G^T [ sum_tiles (A dY A^T) . (B^T x B) ] G
  *   dMt[36][tiles][Co] = A dy A^T per 4x4 patch;  dU[t] = dMt[t]^T . V[t] (batched GEMM);  dw[Co][3][3][Ci] = G^T dU G */
 int mmfn_wino_outgrad_f32(const float* dy, float* dMt, int B, int H, int W, int C, void* stream);
+/* Data gradient of the same convolution as the ADJOINT of its forward Winograd pipeline: dV [36][tiles][Ci] (= dM . U, one
+ * 36-batch GEMM over the forward's own transformed filter) -> dx = overlap-add of B dV B^T over the tiles' 6x6 input patches
+ * (+ res).  H = W in {8, 16, 32}; replaces cuDNN's backward-data for the BasicBlock 3x3 convolutions (model_vec.py:539-593). */
+int mmfn_wino_input_adjoint_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, void* stream);
 int mmfn_wino_wgrad_out_f32(const float* dU, float* dw, int Co, int Ci, void* stream);
 /* y = a*x + b*y (b == 0 ignores the old y) */
 int mmfn_axpby_f32(float* y, const float* x, float a, float b, int64_t n, void* stream);
@@ -156,6 +160,13 @@ int mmfn_layernorm_fwd_f32(const float* x, const float* weight, const float* bia
 int mmfn_layernorm_bwd_f32(const float* g, const float* x, const float* weight, const float* bias, const float* mean,
                            const float* rstd, const float* dres, float* dx, float* dweight, float* dbias, int M, int C,
                            int act, void* workspace, void* stream);
+/* Same, plus an optional second output dx_dropped = dx * keep_scale(row * C + col) for the dropout that the forward applied
+ * in the epilogue of the following residual branch's last GEMM (counter RNG: same state / stream / index), so the backward
+ * needs no separate dropout pass over dx (model_vec.py:107-108,130-131: resid_drop).  dx_dropped NULL = plain. */
+int mmfn_layernorm_bwd_drop_f32(const float* g, const float* x, const float* weight, const float* bias, const float* mean,
+                                const float* rstd, const float* dres, float* dx, float* dweight, float* dbias, int M, int C,
+                                int act, float* dx_dropped, float drop_p, const uint64_t* rng_state, uint32_t rng_stream,
+                                void* workspace, void* stream);
 /* out[c] = sum_r in[r*ld + c]   (bias gradients) */
 int64_t mmfn_colsum_workspace_bytes(int64_t M, int C);
 int mmfn_colsum_f32(const float* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream);
@@ -198,6 +209,9 @@ int mmfn_attention_bwd_f32(const float* q, const float* k, const float* v, int l
                            const float* lse, float* delta, float* dq, float* dk, float* dv, int ldg, int B, int T, int NH,
                            int HS, float scale, const int32_t* kv_len, float drop_p, const uint64_t* rng_state,
                            uint32_t rng_stream, void* stream);
+/* Development aid (MMFN_ATTN_DEBUG=1): copies 32 s_memtime stamps (waves 0 and 7 of workgroup 0, phase boundaries of the
+ * last workgroup-form forward launch) to HOST memory; MMFN_EINVAL when the instrumentation is off. */
+int mmfn_attn_debug_read(int64_t* out32);
 
 /* ---- waypoint head: GRUCell x steps + Linear(64,2) + L1 loss (model_vec.py:666-680, phase2:104) ---- */
 int64_t mmfn_gru_head_part_floats(void);

@@ -151,12 +151,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
       mx = fmaxf(mx, v);
     }
   mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const float msafe = mx > -INFINITY ? mx : 0.f;
   float sum = 0.f;
 #pragma unroll
   for (int kt = 0; kt < NK2; ++kt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = s[kt][r] > -INFINITY ? expf(s[kt][r] - mx) : 0.f;  // a half may be fully masked
+      const float e = mmfn_exp(s[kt][r] - msafe);  // branch-free; masked keys and fully masked halves give exp(-inf) = 0
       s[kt][r] = e;
       sum += e;
     }
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
   {
     const float mo = sm_ml[w ^ 1][0][l31], lo = sm_ml[w ^ 1][1][l31];
     const float m = fmaxf(mx, mo);
-    const float fw = mx > -INFINITY ? expf(mx - m) : 0.f;
-    const float fo = mo > -INFINITY ? expf(mo - m) : 0.f;
+    const float fw = mmfn_exp(mx - m);
+    const float fo = mmfn_exp(mo - m);
     const float l = sum * fw + lo * fo;
     if (w == 0 && qvalid && h == 0 && a.lse) a.lse[((size_t)b * a.NH + hd) * T + q] = m + logf(l);
     pscale = fw / l;
@@ -296,7 +297,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = (ktb + kt) * 32 + rowmap(r) + 4 * h;
-        const float p = nokeys ? (key < T ? expf(-lse) : 0.f) : (key < kvlen ? expf(st[r] * a.scale - lse) : 0.f);
+        const float ex = mmfn_exp((nokeys ? 0.f : st[r] * a.scale) - lse);
+        const float p = (nokeys ? key < T : key < kvlen) ? ex : 0.f;
         float dpv = dp[r];
         if (drop) dpv *= mmfn_dropout_scale(key64, pbase + (uint64_t)key, a.drop_p, inv_keep);
         ds[kt][r] = p;
@@ -449,7 +451,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
         const int qrow = qt * 32 + rowmap(r) + 4 * h;
         const bool valid = qrow < T;
         const int qc = min(qrow, T - 1);
-        const float p = (valid && kin) ? expf((nokeys ? 0.f : st[r] * a.scale) - lsev[g & 1][rr]) : 0.f;
+        const float ex = mmfn_exp((nokeys ? 0.f : st[r] * a.scale) - lsev[g & 1][rr]);
+        const float p = (valid && kin) ? ex : 0.f;
         float msc = 1.f;
         if (drop) msc = mmfn_dropout_scale(key64, (statbase + qc) * (uint64_t)T + (uint64_t)key, a.drop_p, inv_keep);
         const float pd = p * msc;

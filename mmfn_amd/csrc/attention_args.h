@@ -15,6 +15,7 @@ struct AttnArgs {
   int B, T, NH, ld, ldo, ldg;
   float scale, drop_p;
   uint32_t rng_stream;
+  long long* dbg;                                   // MMFN_ATTN_DEBUG=1 (dev only): phase time stamps of workgroup 0
 };
 
 // attention_wg.hip.  which: 0 forward, 1 backward dQ (+delta), 2 backward dK/dV.  Returns -1 when the shape is not

@@ -10,18 +10,23 @@
 //   * 16x16 tiles give the granularity that divides: a workgroup owns T/2 queries (forward, dQ pass) or T/2 keys (dK/dV
 //     pass) against all T of the other side; wave (g, s) takes the 16*NT x 16*NT sub-block of group g (2 per half) and
 //     contraction slice s (4 per T), NT = T/64 - exactly 1/8 of the workgroup's MFMAs each, in every phase;
-//   * operands go L2 -> registers directly, 16 B per lane, prefetched one 16-column chunk ahead: each wave reads its
-//     rows once, a K / V row is read by 4 waves per (sample, head) instead of 12;
+//   * operands are staged through LDS by the whole workgroup (16-byte coalesced row loads, one copy per workgroup):
+//     with L2 -> register operand loads every wave re-read the rows its seven siblings also need (580 KB per workgroup
+//     at head size 128 against 240 KB of distinct data) and the CU's vector-memory path, not the matrix pipe, set the
+//     pace (51 cycles per MFMA measured where the instruction needs 32); the MFMA phases now read LDS only;
 //   * the S^T / dP^T accumulator tile IS the A operand of the second product (accumulator row 4*(lane>>4)+r <-> k slot
 //     lane>>4, step r), so probabilities never leave registers;
 //   * the four slices meet through LDS three times: row max, row sum (delta in the backward), and the partial output
 //     tiles - each wave finishes the quarter of the head dimension it owns, so the merge is balanced as well and the
 //     result leaves as 64..128-byte contiguous runs per row.
+#include <stdlib.h>
+
 #include "attention_args.h"
 
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int NTHR = 512;   // 8 waves: two per SIMD
 
 template <int HS, int NT>
 struct Shape {
@@ -33,7 +38,7 @@ struct Shape {
   static constexpr int NFOREIGN = NDT - W;            // tiles a wave hands to other owners (owners), NDT for non-owners
   // merge buffer: [group 2][slice 4][tile slot NDT][row tile NT][reg 4][lane 64] floats; owners never write their own
   static constexpr int SLOTS = NDT >= 4 ? NDT - W : NDT;
-  static constexpr int MERGE_FLOATS = 2 * 4 * SLOTS * NT * 4 * 64;
+  static constexpr int MERGE_FLOATS_PER_GROUP = 4 * SLOTS * NT * 4 * 64;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -43,70 +48,131 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 template <int W>
 __device__ __forceinline__ int dcol(int n, int j) { return (j / W) * 16 * W + n * W + (j % W); }
 
-// acc[p][x][y] += sum_d A_p[16x + l15][d] * B_p[16y + l15][d] over the HS columns of this head, NP products at once.
-// Lane (l15, l4) loads the float4 at columns 16c + 4*l4 of its row: element e feeds MFMA step e, whose four k slots are
-// then the columns {16c + 4*slot + e}: a permutation of the chunk's columns, the same one on both operands.
-template <int HS, int NT, int NP>
-__device__ __forceinline__ void product_phase(const float* const* Abase, const size_t* lda, const float* const* Bbase,
-                                              const size_t* ldb, int l15, int l4, f32x4 (*acc)[NT][NT]) {
-  constexpr int NC = HS / 16;
-  f32x4 fa[2][NP][NT], fb[2][NP][NT];
-  auto load = [&](int c, int buf) {
+// ---- operand staging.  An operand matrix in LDS is [rows][HS] with row pitch HS + 4 floats: the 16-byte fragment
+// reads of 16 consecutive rows then fall into 16 distinct bank quads.
+template <int HS>
+struct Pitch { static constexpr int P = HS + 4; };
+
+// Cooperative copy of NROWS rows x NCOLS columns (columns col0 .. col0 + NCOLS of an HS-wide operand, global row stride
+// ld) into LDS: issue() puts every thread's 16-byte pieces in flight into registers, commit() writes them to LDS - the
+// caller places work (MFMAs, softmax, a barrier) in between.
+template <int HS, int NROWS, int NCOLS, int NTHR>
+struct Stager {
+  static constexpr int Q = NCOLS / 4;
+  static constexpr int UNITS = NROWS * Q;
+  static constexpr int PER = (UNITS + NTHR - 1) / NTHR;
+  f32x4 r[PER];
+  __device__ __forceinline__ void issue(const float* src, size_t ld, int tid, int col0 = 0) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * NTHR;
+      if (UNITS % NTHR == 0 || u < UNITS) r[i] = ld4(src + (size_t)(u / Q) * ld + col0 + 4 * (u % Q));
+    }
+  }
+  __device__ __forceinline__ void commit(float* dst, int tid, int col0 = 0) const {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        fa[buf][p][t] = ld4(Abase[p] + (size_t)(16 * t + l15) * lda[p] + 16 * c + 4 * l4);
-        fb[buf][p][t] = ld4(Bbase[p] + (size_t)(16 * t + l15) * ldb[p] + 16 * c + 4 * l4);
-      }
-  };
-  load(0, 0);
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * NTHR;
+      if (UNITS % NTHR == 0 || u < UNITS)
+        *reinterpret_cast<f32x4*>(dst + (u / Q) * Pitch<HS>::P + col0 + 4 * (u % Q)) = r[i];
+    }
+  }
+};
+
+// Column groups of the first products: the operands arrive in NS groups of HS / NS columns; group g+1 is in flight
+// (global -> registers) while the MFMAs of group g run, so only the first group's latency is exposed.  (Cold operands
+// stream at HBM speed: 150 KB per workgroup x 256 workgroups at head size 128 is ~6 us that used to precede any MFMA.)
+template <int HS>
+struct Groups {
+  static constexpr int NS = HS >= 128 ? 4 : (HS >= 64 ? 2 : 1);
+  static constexpr int COLS = HS / NS;
+};
+
+// acc[x][y] += sum_d A[16x + l15][d] * B[16y + l15][d] over columns [col0, col0 + NCOLS) of this head; A, B point at the
+// first row of this wave's tiles inside staged LDS matrices.  Lane (l15, l4) reads the float4 at columns 16c + 4*l4 of its
+// row: element e feeds MFMA step e, whose four k slots are then the columns {16c + 4*slot + e}: a permutation of the
+// chunk's columns, the same one on both operands.
+template <int HS, int NT, int NCOLS>
+__device__ __forceinline__ void product_phase(const float* A, const float* B, int col0, int l15, int l4, f32x4 (*acc)[NT]) {
+  constexpr int NC = NCOLS / 16, P = Pitch<HS>::P;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    if (c + 1 < NC) load(c + 1, (c + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
+    f32x4 fa[NT], fb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      fa[t] = *reinterpret_cast<const f32x4*>(A + (16 * t + l15) * P + col0 + 16 * c + 4 * l4);
+      fb[t] = *reinterpret_cast<const f32x4*>(B + (16 * t + l15) * P + col0 + 16 * c + 4 * l4);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-      for (int p = 0; p < NP; ++p)
+      for (int x = 0; x < NT; ++x)
 #pragma unroll
-        for (int x = 0; x < NT; ++x)
+        for (int y = 0; y < NT; ++y) acc[x][y] = mfma16(fa[x][e], fb[y][e], acc[x][y]);
+  }
+}
+
+// A chain of N first products, each over a (full T-row, half T/2-row) operand pair that arrives in column groups:
+//   src(i) -> (pointer / stride of the full operand, of the half operand) of product i;  prod(i, col0) runs its MFMAs;
+//   tail() is called right before the last group's MFMAs (the caller issues the next phase's loads there).
+// Every group is one barrier.  With NS >= 2 the group being written (columns of group g+1) was last read NS groups ago, one
+// or more barriers back; with NS == 1 the only group is overwritten, so a barrier separates its last reader from the write.
+template <int HS, int NT, int NPROD, typename Src, typename Prod, typename Tail>
+__device__ __forceinline__ void product_chain(float* sFull, float* sHalf, int tid, Src&& src, Prod&& prod, Tail&& tail) {
+  constexpr int T = 64 * NT, NS = Groups<HS>::NS, COLS = Groups<HS>::COLS, N = NPROD * NS;
+  Stager<HS, T, COLS, NTHR> stF;
+  Stager<HS, T / 2, COLS, NTHR> stH;
+  const float* pf; const float* ph; size_t lf, lh;
+  src(0, pf, lf, ph, lh);
+  stF.issue(pf, lf, tid, 0);
+  stH.issue(ph, lh, tid, 0);
+  stF.commit(sFull, tid, 0);
+  stH.commit(sHalf, tid, 0);
+  __syncthreads();
 #pragma unroll
-          for (int y = 0; y < NT; ++y) acc[p][x][y] = mfma16(fa[c & 1][p][x][e], fb[c & 1][p][y][e], acc[p][x][y]);
+  for (int i = 0; i < N; ++i) {
+    const int col0 = (i % NS) * COLS;
+    if (i + 1 < N) {
+      src((i + 1) / NS, pf, lf, ph, lh);
+      stF.issue(pf, lf, tid, ((i + 1) % NS) * COLS);
+      stH.issue(ph, lh, tid, ((i + 1) % NS) * COLS);
+    } else {
+      tail();
+    }
+    prod(i / NS, col0);
+    if (i + 1 < N) {
+      if (NS == 1) __syncthreads();
+      stF.commit(sFull, tid, ((i + 1) % NS) * COLS);
+      stH.commit(sHalf, tid, ((i + 1) % NS) * COLS);
+      __syncthreads();
+    }
   }
 }
 
 // out[y][j] += sum over this wave's contraction rows r of P[r][row 16y + ..] * R[r][dcol(.., j)]:  P is the accumulator
-// of product_phase ([x = contraction tile][y = output-row tile]), R rows start at `rows` with stride ld.
+// of product_phase ([x = contraction tile][y = output-row tile]), R the staged LDS matrix at the wave's first row.
 template <int HS, int NT>
-__device__ __forceinline__ void second_phase(const f32x4 (*P)[NT], const float* rows, size_t ld, int l15, int l4,
-                                             f32x4 (*out)[HS / 16]) {
+__device__ __forceinline__ void second_phase(const f32x4 (*Pm)[NT], const float* rows, int l15, int l4, f32x4 (*out)[HS / 16]) {
   using S = Shape<HS, NT>;
-  constexpr int NDT = S::NDT, W = S::W, NG = NDT / W;
-  float rv[2][NDT];
-  auto load = [&](int step, int buf) {
-    const int x = step >> 2, e = step & 3;
-    const float* p = rows + (size_t)(16 * x + 4 * l4 + e) * ld + l15 * W;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      if (W == 2) {
-        const f32x2 t = *reinterpret_cast<const f32x2*>(p + 32 * g);
-        rv[buf][2 * g] = t[0]; rv[buf][2 * g + 1] = t[1];
-      } else {
-        rv[buf][g] = p[16 * g];
-      }
-    }
-  };
-  load(0, 0);
+  constexpr int NDT = S::NDT, W = S::W, NGR = NDT / W, P = Pitch<HS>::P;
 #pragma unroll
   for (int step = 0; step < 4 * NT; ++step) {
-    if (step + 1 < 4 * NT) load(step + 1, (step + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
     const int x = step >> 2, e = step & 3;
+    const float* p = rows + (16 * x + 4 * l4 + e) * P + l15 * W;
+    float rv[NDT];
+#pragma unroll
+    for (int g = 0; g < NGR; ++g) {
+      if (W == 2) {
+        const f32x2 t = *reinterpret_cast<const f32x2*>(p + 32 * g);
+        rv[2 * g] = t[0]; rv[2 * g + 1] = t[1];
+      } else {
+        rv[g] = p[16 * g];
+      }
+    }
 #pragma unroll
     for (int y = 0; y < NT; ++y)
 #pragma unroll
-      for (int j = 0; j < NDT; ++j) out[y][j] = mfma16(P[x][y][e], rv[step & 1][j], out[y][j]);
+      for (int j = 0; j < NDT; ++j) out[y][j] = mfma16(Pm[x][y][e], rv[j], out[y][j]);
   }
 }
 
@@ -118,8 +184,9 @@ __device__ __forceinline__ void merge_store(const f32x4 (*acc)[HS / 16], float* 
                                             int l4, float* dst, size_t ldd) {
   using S = Shape<HS, NT>;
   constexpr int NDT = S::NDT, W = S::W, NOWN = S::NOWN, SLOTS = S::SLOTS;
-  auto slab = [&](int src, int slot, int y, int r) {
-    return sm + ((((size_t)(grp * 4 + src) * SLOTS + slot) * NT + y) * 4 + r) * 64 + lane;
+  // one 16-byte unit per (tile, row tile, lane): the four accumulator rows of a lane sit together, lane-linear across the wave
+  auto slab = [&](int src, int slot, int y) {
+    return reinterpret_cast<f32x4*>(sm) + (((size_t)(grp * 4 + src) * SLOTS + slot) * NT + y) * 64 + lane;
   };
   const bool owner = slice < NOWN;
   // slot of tile j in slice src's parking area: its own tiles are skipped when it is an owner of a full (NDT >= 4) head
@@ -130,44 +197,43 @@ __device__ __forceinline__ void merge_store(const f32x4 (*acc)[HS / 16], float* 
     if (!mine) {
       const int sl = slot_of(slice, j);
 #pragma unroll
-      for (int y = 0; y < NT; ++y)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) *slab(slice, sl, y, r) = acc[y][j][r];
+      for (int y = 0; y < NT; ++y) *slab(slice, sl, y) = acc[y][j];
     }
   }
   __syncthreads();
   if (owner) {
 #pragma unroll
-    for (int y = 0; y < NT; ++y)
+    for (int y = 0; y < NT; ++y) {
+      f32x4 t[W];
+#pragma unroll
+      for (int jj = 0; jj < W; ++jj) {
+        const int j = slice * W + jj;   // NDT < 4: W == 1 and slice < NDT, so j = slice
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        bool first = true;
+#pragma unroll
+        for (int src = 0; src < 4; ++src) {   // slice order, own copy taken from registers at its place in the order
+          f32x4 part;
+          if (src == slice) {
+            // j depends on slice (wave-uniform): select acc[y][j] with an unrolled compare so register indices stay static
+            part = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jc = 0; jc < NDT; ++jc)
+              if (jc == j) part = acc[y][jc];
+          } else {
+            part = *slab(src, slot_of(src, j), y);
+          }
+          v = first ? part : v + part;
+          first = false;
+        }
+        t[jj] = v;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float t[W];
-#pragma unroll
-        for (int jj = 0; jj < W; ++jj) {
-          const int j = slice * W + jj;   // NDT < 4: W == 1 and slice < NDT, so j = slice
-          float v = 0.f;
-          bool first = true;
-#pragma unroll
-          for (int src = 0; src < 4; ++src) {   // slice order, own copy taken from registers at its place in the order
-            float part;
-            if (src == slice) {
-              // select acc[y][j][r] with a compile-time-indexable form: j depends on slice (wave-uniform) -> unrolled compare
-              part = 0.f;
-#pragma unroll
-              for (int jc = 0; jc < NDT; ++jc)
-                if (jc == j) part = acc[y][jc][r];
-            } else {
-              part = *slab(src, slot_of(src, j), y, r);
-            }
-            v = first ? part : v + part;
-            first = false;
-          }
-          t[jj] = v;
-        }
         float* p = dst + (size_t)(16 * y + 4 * l4 + r) * ldd + slice * 16 * W + l15 * W;
-        if (W == 2) *reinterpret_cast<f32x2*>(p) = f32x2{t[0], t[1]};
-        else p[0] = t[0];
+        if (W == 2) *reinterpret_cast<f32x2*>(p) = f32x2{t[0][r], t[1][r]};
+        else p[0] = t[0][r];
       }
+    }
   }
 }
 
@@ -180,15 +246,35 @@ __device__ __forceinline__ float quad_sum(float v) {
   return v + __shfl_xor(v, 32, 64);
 }
 
+// LDS plan of a workgroup (8 waves, 512 threads), in floats.  The operand area holds, at different times, two staged
+// operand matrices for the products (T + T/2 rows), one T-row matrix for the second product, and the merge parking area.
+template <int HS, int NT>
+struct Lds {
+  using S = Shape<HS, NT>;
+  static constexpr int T = 64 * NT, P = Pitch<HS>::P;
+  static constexpr int FULL = T * P, HALF = (T / 2) * P;   // an operand with all T rows / with this workgroup's half
+  static constexpr int OPERANDS = FULL + HALF;
+  static constexpr int MERGE = 2 * S::MERGE_FLOATS_PER_GROUP;
+  static constexpr int AREA = OPERANDS > MERGE ? OPERANDS : MERGE;
+};
+
+// dev instrumentation: s_memtime stamps of waves 0 and 7 of workgroup (0,0,0) at the phase boundaries
+__device__ __forceinline__ void stamp(const AttnArgs& a, int idx) {
+  if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0 &&
+      ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 7))
+    a.dbg[((threadIdx.x >> 6) ? 16 : 0) + idx] = (long long)__builtin_amdgcn_s_memtime();
+}
+
 // ---------------------------------------------------------------------------------------------------------- forward
 template <int HS, int NT>
-__global__ __launch_bounds__(512) void attn_wg_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
   using S = Shape<HS, NT>;
-  constexpr int NDT = S::NDT, G = S::G, T = 64 * NT;
-  __shared__ float sm_merge[S::MERGE_FLOATS];
-  __shared__ float sm_stat[2][2][4][G];   // [max | sum][query group][key slice][query]
+  using L = Lds<HS, NT>;
+  constexpr int NDT = S::NDT, G = S::G, T = 64 * NT, P = L::P;
+  __shared__ __attribute__((aligned(16))) float sm[L::AREA];
+  __shared__ float sm_stat[2][2][4][G];   // [slice max | slice sum][query group][key slice][query]
   const int half = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int qg = w >> 2, ks = w & 3;
   const size_t rowbase = (size_t)b * T;
   const int q0 = half * 2 * G + qg * G;   // first query of this wave's group
@@ -196,19 +282,27 @@ __global__ __launch_bounds__(512) void attn_wg_fwd_kernel(const AttnArgs a) {
   const int kvlen = a.kv_len ? min(T, a.kv_len[b]) : T;
   const bool nokeys = kvlen <= 0;
   const size_t ld = a.ld;
-  f32x4 s[1][NT][NT];   // S^T: [key tile][query tile], acc row = key 4*l4 + r, lane column = query l15
+  float* sK = sm;               // [T][P]
+  float* sQ = sm + L::FULL;     // [T/2][P]: the queries of this half
+  stamp(a, 0);
+  f32x4 s[NT][NT];   // S^T: [key tile][query tile], acc row = key 4*l4 + r, lane column = query l15
 #pragma unroll
   for (int x = 0; x < NT; ++x)
 #pragma unroll
-    for (int y = 0; y < NT; ++y) s[0][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
-  {
-    const float* A[1] = {a.k + (rowbase + k0) * ld + hd * HS};
-    const float* Bq[1] = {a.q + (rowbase + q0) * ld + hd * HS};
-    const size_t l1[1] = {ld};
-    product_phase<HS, NT, 1>(A, l1, Bq, l1, l15, l4, s);
-  }
-  // ---- softmax over keys: local (12 values per query) -> quad -> the four key slices through LDS
-  float mx[NT], sum[NT];
+    for (int y = 0; y < NT; ++y) s[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+  Stager<HS, T, HS, NTHR> stV;   // V goes into flight under the last MFMAs of the first product, lands in LDS (over K / Q)
+  product_chain<HS, NT, 1>(
+      sK, sQ, tid,
+      [&](int, const float*& pf, size_t& lf, const float*& ph, size_t& lh) {
+        pf = a.k + rowbase * ld + hd * HS; lf = ld;
+        ph = a.q + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
+      },
+      [&](int, int col0) { product_phase<HS, NT, Groups<HS>::COLS>(sK + k0 * P, sQ + qg * G * P, col0, l15, l4, s); },
+      [&]() { stV.issue(a.v + rowbase * ld + hd * HS, ld, tid); });
+  stamp(a, 2);
+  // ---- softmax over keys, flash-style across the four key slices: every slice normalises by its OWN row maximum, the
+  // (max, sum) pairs meet in LDS once, then each slice rescales by exp(m_slice - m) / l
+  float mx[NT];
 #pragma unroll
   for (int y = 0; y < NT; ++y) {
     float m = -INFINITY;
@@ -218,33 +312,27 @@ __global__ __launch_bounds__(512) void attn_wg_fwd_kernel(const AttnArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int key = k0 + 16 * x + 4 * l4 + r;
         // kv_len == 0: the reference's masked_fill(-1e9) + softmax is uniform attention over all keys (model_vec.py:315-317)
-        const float v = nokeys ? 0.f : (key < kvlen ? s[0][x][y][r] * a.scale : -INFINITY);
-        s[0][x][y][r] = v;
+        const float v = nokeys ? 0.f : (key < kvlen ? s[x][y][r] * a.scale : -INFINITY);
+        s[x][y][r] = v;
         m = fmaxf(m, v);
       }
-    mx[y] = quad_max(m);
-    if (l4 == 0) sm_stat[0][qg][ks][16 * y + l15] = mx[y];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int y = 0; y < NT; ++y) {
-    float m = sm_stat[0][qg][0][16 * y + l15];
-#pragma unroll
-    for (int o = 1; o < 4; ++o) m = fmaxf(m, sm_stat[0][qg][o][16 * y + l15]);
-    mx[y] = m;   // finite: at least one key of the row is unmasked (kv_len >= 1 or the uniform case)
+    m = quad_max(m);
+    const float msafe = m > -INFINITY ? m : 0.f;   // a fully masked slice: every exponent is exp(-inf - 0) = 0
     float t = 0.f;
 #pragma unroll
     for (int x = 0; x < NT; ++x)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = s[0][x][y][r] > -INFINITY ? expf(s[0][x][y][r] - m) : 0.f;
-        s[0][x][y][r] = e;
+        const float e = mmfn_exp(s[x][y][r] - msafe);   // masked keys: exp(-inf) = 0
+        s[x][y][r] = e;
         t += e;
       }
-    sum[y] = quad_sum(t);
-    if (l4 == 0) sm_stat[1][qg][ks][16 * y + l15] = sum[y];
+    mx[y] = m;
+    t = quad_sum(t);
+    if (l4 == 0) { sm_stat[0][qg][ks][16 * y + l15] = m; sm_stat[1][qg][ks][16 * y + l15] = t; }
   }
-  __syncthreads();
+  __syncthreads();   // statistics visible; K / Q no longer read
+  stV.commit(sm, tid);
   const bool drop = a.drop_p > 0.f;
   uint64_t key64 = 0;
   float inv_keep = 1.f;
@@ -252,39 +340,52 @@ __global__ __launch_bounds__(512) void attn_wg_fwd_kernel(const AttnArgs a) {
 #pragma unroll
   for (int y = 0; y < NT; ++y) {
     const int qi = 16 * y + l15;
-    const float l = (sm_stat[1][qg][0][qi] + sm_stat[1][qg][1][qi]) + (sm_stat[1][qg][2][qi] + sm_stat[1][qg][3][qi]);
+    float m = sm_stat[0][qg][0][qi];
+#pragma unroll
+    for (int o = 1; o < 4; ++o) m = fmaxf(m, sm_stat[0][qg][o][qi]);   // finite: some key of the row is unmasked
+    float l = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {   // slice order: every slice computes the same l bit for bit
+      l += sm_stat[1][qg][o][qi] * mmfn_exp(sm_stat[0][qg][o][qi] - m);   // masked slice: sum 0 * exp(-inf) = 0
+    }
     const int q = q0 + qi;
-    if (ks == 0 && l4 == 0 && a.lse) a.lse[((size_t)b * a.NH + hd) * T + q] = mx[y] + logf(l);
-    const float inv = 1.0f / l;
+    if (ks == 0 && l4 == 0 && a.lse) a.lse[((size_t)b * a.NH + hd) * T + q] = m + logf(l);
+    const float fac = mmfn_exp(mx[y] - m) / l;
     const uint64_t pbase = (((uint64_t)b * a.NH + hd) * T + q) * (uint64_t)T;
 #pragma unroll
     for (int x = 0; x < NT; ++x)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float p = s[0][x][y][r] * inv;
+        float p = s[x][y][r] * fac;
         if (drop) p *= mmfn_dropout_scale(key64, pbase + (uint64_t)(k0 + 16 * x + 4 * l4 + r), a.drop_p, inv_keep);
-        s[0][x][y][r] = p;
+        s[x][y][r] = p;
       }
   }
+  __syncthreads();   // V staged
+  stamp(a, 3);
   // ---- O = P . V over this wave's key slice, then the four slices are summed
   f32x4 o[NT][NDT];
 #pragma unroll
   for (int y = 0; y < NT; ++y)
 #pragma unroll
     for (int j = 0; j < NDT; ++j) o[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  second_phase<HS, NT>(s[0], a.v + (rowbase + k0) * ld + hd * HS, ld, l15, l4, o);
-  merge_store<HS, NT>(o, sm_merge, qg, ks, lane, l15, l4, a.o + (rowbase + q0) * a.ldo + hd * HS, a.ldo);
+  second_phase<HS, NT>(s, sm + k0 * P, l15, l4, o);
+  stamp(a, 4);
+  __syncthreads();   // V no longer read: the area becomes the merge parking space
+  merge_store<HS, NT>(o, sm, qg, ks, lane, l15, l4, a.o + (rowbase + q0) * a.ldo + hd * HS, a.ldo);
+  stamp(a, 5);
 }
 
 // ---------------------------------------------------------------------------------------- backward, query-owned: dQ, delta
 template <int HS, int NT>
-__global__ __launch_bounds__(512) void attn_wg_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
   using S = Shape<HS, NT>;
-  constexpr int NDT = S::NDT, G = S::G, T = 64 * NT;
-  __shared__ float sm_merge[S::MERGE_FLOATS];
+  using L = Lds<HS, NT>;
+  constexpr int NDT = S::NDT, G = S::G, T = 64 * NT, P = L::P;
+  __shared__ __attribute__((aligned(16))) float sm[L::AREA];
   __shared__ float sm_stat[2][2][4][G];   // [sum P dP | sum P][query group][key slice][query]
   const int half = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int qg = w >> 2, ks = w & 3;
   const size_t rowbase = (size_t)b * T;
   const int q0 = half * 2 * G + qg * G;
@@ -292,6 +393,12 @@ __global__ __launch_bounds__(512) void attn_wg_dq_kernel(const AttnArgs a) {
   const int kvlen = a.kv_len ? min(T, a.kv_len[b]) : T;
   const bool nokeys = kvlen <= 0;   // constant scores: P = 1/T, dS = 0
   const size_t ld = a.ld;
+  const size_t statbase = ((size_t)b * a.NH + hd) * T;
+  float* sA = sm;               // [T][P]: K, then V, then K again
+  float* sB = sm + L::FULL;     // [T/2][P]: Q, then dO of this half
+  float lse_y[NT];   // issued before the products: used right after them
+#pragma unroll
+  for (int y = 0; y < NT; ++y) lse_y[y] = a.lse[statbase + q0 + 16 * y + l15];
   f32x4 acc[2][NT][NT];   // [0] S^T = K Q^T, [1] dP^T = V dO^T
 #pragma unroll
   for (int p = 0; p < 2; ++p)
@@ -299,21 +406,30 @@ __global__ __launch_bounds__(512) void attn_wg_dq_kernel(const AttnArgs a) {
     for (int x = 0; x < NT; ++x)
 #pragma unroll
       for (int y = 0; y < NT; ++y) acc[p][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
-  {
-    const float* A[2] = {a.k + (rowbase + k0) * ld + hd * HS, a.v + (rowbase + k0) * ld + hd * HS};
-    const float* Bq[2] = {a.q + (rowbase + q0) * ld + hd * HS, a.dO + (rowbase + q0) * a.ldo + hd * HS};
-    const size_t la[2] = {ld, ld}, lb[2] = {ld, (size_t)a.ldo};
-    product_phase<HS, NT, 2>(A, la, Bq, lb, l15, l4, acc);
-  }
+  Stager<HS, T, HS, NTHR> stK;   // K again, for dQ = dS K: in flight under the last MFMAs, committed once V is no longer read
+  product_chain<HS, NT, 2>(
+      sA, sB, tid,
+      [&](int i, const float*& pf, size_t& lf, const float*& ph, size_t& lh) {
+        if (i == 0) {
+          pf = a.k + rowbase * ld + hd * HS; lf = ld;
+          ph = a.q + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
+        } else {
+          pf = a.v + rowbase * ld + hd * HS; lf = ld;
+          ph = a.dO + (rowbase + half * 2 * G) * a.ldo + hd * HS; lh = a.ldo;
+        }
+      },
+      [&](int i, int col0) { product_phase<HS, NT, Groups<HS>::COLS>(sA + k0 * P, sB + qg * G * P, col0, l15, l4, acc[i]); },
+      [&]() { stK.issue(a.k + rowbase * ld + hd * HS, ld, tid); });
+  __syncthreads();
+  stK.commit(sA, tid);
   const bool drop = a.drop_p > 0.f;
   uint64_t key64 = 0;
   float inv_keep = 1.f;
   if (drop) { key64 = mmfn_rng_key(a.rng_state, a.rng_stream); inv_keep = 1.0f / (1.0f - a.drop_p); }
-  const size_t statbase = ((size_t)b * a.NH + hd) * T;
 #pragma unroll
   for (int y = 0; y < NT; ++y) {
     const int q = q0 + 16 * y + l15;
-    const float lse = a.lse[statbase + q];
+    const float lse = lse_y[y];
     const uint64_t pbase = (statbase + q) * (uint64_t)T;
     float dl = 0.f, ps = 0.f;
 #pragma unroll
@@ -321,7 +437,8 @@ __global__ __launch_bounds__(512) void attn_wg_dq_kernel(const AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = k0 + 16 * x + 4 * l4 + r;
-        const float p = nokeys ? expf(-lse) : (key < kvlen ? expf(acc[0][x][y][r] * a.scale - lse) : 0.f);
+        const float ex = mmfn_exp((nokeys ? 0.f : acc[0][x][y][r] * a.scale) - lse);
+        const float p = (nokeys || key < kvlen) ? ex : 0.f;
         float dpv = acc[1][x][y][r];
         if (drop) dpv *= mmfn_dropout_scale(key64, pbase + (uint64_t)key, a.drop_p, inv_keep);
         acc[0][x][y][r] = p;
@@ -333,7 +450,7 @@ __global__ __launch_bounds__(512) void attn_wg_dq_kernel(const AttnArgs a) {
     ps = quad_sum(ps);
     if (l4 == 0) { sm_stat[0][qg][ks][16 * y + l15] = dl; sm_stat[1][qg][ks][16 * y + l15] = ps; }
   }
-  __syncthreads();
+  __syncthreads();   // statistics visible, K staged
 #pragma unroll
   for (int y = 0; y < NT; ++y) {
     const int qi = 16 * y + l15;
@@ -354,18 +471,21 @@ __global__ __launch_bounds__(512) void attn_wg_dq_kernel(const AttnArgs a) {
   for (int y = 0; y < NT; ++y)
 #pragma unroll
     for (int j = 0; j < NDT; ++j) dq[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  second_phase<HS, NT>(acc[0], a.k + (rowbase + k0) * ld + hd * HS, ld, l15, l4, dq);
-  merge_store<HS, NT>(dq, sm_merge, qg, ks, lane, l15, l4, a.dq + (rowbase + q0) * a.ldg + hd * HS, a.ldg);
+  second_phase<HS, NT>(acc[0], sA + k0 * P, l15, l4, dq);
+  __syncthreads();
+  merge_store<HS, NT>(dq, sm, qg, ks, lane, l15, l4, a.dq + (rowbase + q0) * a.ldg + hd * HS, a.ldg);
 }
 
 // ------------------------------------------------------------------------------------------ backward, key-owned: dK, dV
 template <int HS, int NT>
-__global__ __launch_bounds__(512) void attn_wg_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
   using S = Shape<HS, NT>;
-  constexpr int NDT = S::NDT, G = S::G, T = 64 * NT;
-  __shared__ float sm_merge[S::MERGE_FLOATS];
+  using L = Lds<HS, NT>;
+  constexpr int NDT = S::NDT, G = S::G, T = 64 * NT, P = L::P;
+  __shared__ __attribute__((aligned(16))) float sm[L::AREA];
+  __shared__ float sm_rows[8][2][G];   // per wave: log-sum-exp and delta of its G queries
   const int half = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int kg = w >> 2, qs = w & 3;
   const size_t rowbase = (size_t)b * T;
   const int k0 = half * 2 * G + kg * G;   // first key of this wave's group
@@ -373,6 +493,15 @@ __global__ __launch_bounds__(512) void attn_wg_dkv_kernel(const AttnArgs a) {
   const int kvlen = a.kv_len ? min(T, a.kv_len[b]) : T;
   const bool nokeys = kvlen <= 0;
   const size_t ld = a.ld;
+  const size_t statbase = ((size_t)b * a.NH + hd) * T;
+  float* sA = sm;               // [T][P]: Q, then dO (kept for dV), then Q again
+  float* sB = sm + L::FULL;     // [T/2][P]: K, then V of this half
+  // the wave's G per-query statistics go to a wave-private LDS strip now (one coalesced load each), and are picked up
+  // after the products: no register cost, no global-load latency between the phases
+  if (lane < G) {
+    sm_rows[w][0][lane] = a.lse[statbase + q0 + lane];
+    sm_rows[w][1][lane] = a.delta[statbase + q0 + lane];
+  }
   f32x4 acc[2][NT][NT];   // [0] S = Q K^T, [1] dP = dO V^T: [query tile][key tile], acc row = query 4*l4 + r, column = key
 #pragma unroll
   for (int p = 0; p < 2; ++p)
@@ -380,28 +509,37 @@ __global__ __launch_bounds__(512) void attn_wg_dkv_kernel(const AttnArgs a) {
     for (int x = 0; x < NT; ++x)
 #pragma unroll
       for (int y = 0; y < NT; ++y) acc[p][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
-  {
-    const float* A[2] = {a.q + (rowbase + q0) * ld + hd * HS, a.dO + (rowbase + q0) * a.ldo + hd * HS};
-    const float* Bk[2] = {a.k + (rowbase + k0) * ld + hd * HS, a.v + (rowbase + k0) * ld + hd * HS};
-    const size_t la[2] = {ld, (size_t)a.ldo}, lb[2] = {ld, ld};
-    product_phase<HS, NT, 2>(A, la, Bk, lb, l15, l4, acc);
-  }
+  Stager<HS, T, HS, NTHR> stA;   // Q again (for dK): issued before the dV product, committed after the dV merge
+  product_chain<HS, NT, 2>(
+      sA, sB, tid,
+      [&](int i, const float*& pf, size_t& lf, const float*& ph, size_t& lh) {
+        if (i == 0) {
+          pf = a.q + rowbase * ld + hd * HS; lf = ld;
+          ph = a.k + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
+        } else {
+          pf = a.dO + rowbase * a.ldo + hd * HS; lf = a.ldo;
+          ph = a.v + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
+        }
+      },
+      [&](int i, int col0) { product_phase<HS, NT, Groups<HS>::COLS>(sA + q0 * P, sB + kg * G * P, col0, l15, l4, acc[i]); },
+      [&]() {});
   const bool drop = a.drop_p > 0.f;
   uint64_t key64 = 0;
   float inv_keep = 1.f;
   if (drop) { key64 = mmfn_rng_key(a.rng_state, a.rng_stream); inv_keep = 1.0f / (1.0f - a.drop_p); }
-  const size_t statbase = ((size_t)b * a.NH + hd) * T;
 #pragma unroll
   for (int x = 0; x < NT; ++x)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int q = q0 + 16 * x + 4 * l4 + r;
-      const float lse = a.lse[statbase + q], dlt = a.delta[statbase + q];
+      const int qi = 16 * x + 4 * l4 + r;
+      const int q = q0 + qi;
+      const float lse = sm_rows[w][0][qi], dlt = sm_rows[w][1][qi];   // written by this wave (same lanes < G): in order
 #pragma unroll
       for (int y = 0; y < NT; ++y) {
         const int key = k0 + 16 * y + l15;
         const bool kin = nokeys || key < kvlen;
-        const float p = kin ? expf((nokeys ? 0.f : acc[0][x][y][r] * a.scale) - lse) : 0.f;
+        const float ex = mmfn_exp((nokeys ? 0.f : acc[0][x][y][r] * a.scale) - lse);
+        const float p = kin ? ex : 0.f;
         float msc = 1.f;
         if (drop) msc = mmfn_dropout_scale(key64, (statbase + q) * (uint64_t)T + (uint64_t)key, a.drop_p, inv_keep);
         acc[0][x][y][r] = p * msc;                                                           // dV = (P o mask)^T dO
@@ -413,23 +551,40 @@ __global__ __launch_bounds__(512) void attn_wg_dkv_kernel(const AttnArgs a) {
   for (int y = 0; y < NT; ++y)
 #pragma unroll
     for (int j = 0; j < NDT; ++j) g[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  second_phase<HS, NT>(acc[0], a.dO + (rowbase + q0) * a.ldo + hd * HS, a.ldo, l15, l4, g);
-  merge_store<HS, NT>(g, sm_merge, kg, qs, lane, l15, l4, a.dv + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
+  stA.issue(a.q + rowbase * ld + hd * HS, ld, tid);          // Q again (for dK), in flight under the dV product
+  second_phase<HS, NT>(acc[0], sA + q0 * P, l15, l4, g);     // dO is still staged
+  __syncthreads();
+  merge_store<HS, NT>(g, sm, kg, qs, lane, l15, l4, a.dv + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
+  __syncthreads();   // every owner has read the dV copies before the area is reused
+  stA.commit(sA, tid);
+  __syncthreads();
 #pragma unroll
   for (int y = 0; y < NT; ++y)
 #pragma unroll
     for (int j = 0; j < NDT; ++j) g[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  second_phase<HS, NT>(acc[1], a.q + (rowbase + q0) * ld + hd * HS, ld, l15, l4, g);
-  __syncthreads();   // every owner has read the dV copies before the parking area is reused
-  merge_store<HS, NT>(g, sm_merge, kg, qs, lane, l15, l4, a.dk + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
+  second_phase<HS, NT>(acc[1], sA + q0 * P, l15, l4, g);
+  __syncthreads();
+  merge_store<HS, NT>(g, sm, kg, qs, lane, l15, l4, a.dk + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
+}
+
+long long* debug_buffer() {   // dev only (MMFN_ATTN_DEBUG=1): allocated once, outside any capture
+  static long long* buf = [] {
+    const char* e = getenv("MMFN_ATTN_DEBUG");
+    long long* p = nullptr;
+    if (e && e[0] == '1' && hipMalloc(&p, 64 * sizeof(long long)) != hipSuccess) p = nullptr;
+    return p;
+  }();
+  return buf;
 }
 
 template <int HS, int NT>
-int launch(int which, const AttnArgs& a, hipStream_t s) {
+int launch(int which, const AttnArgs& a_in, hipStream_t s) {
+  AttnArgs a = a_in;
+  a.dbg = which == 0 ? debug_buffer() : nullptr;
   dim3 grid(2, a.NH, a.B);
-  if (which == 0) hipLaunchKernelGGL((attn_wg_fwd_kernel<HS, NT>), grid, dim3(512), 0, s, a);
-  else if (which == 1) hipLaunchKernelGGL((attn_wg_dq_kernel<HS, NT>), grid, dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((attn_wg_dkv_kernel<HS, NT>), grid, dim3(512), 0, s, a);
+  if (which == 0) hipLaunchKernelGGL((attn_wg_fwd_kernel<HS, NT>), grid, dim3(NTHR), 0, s, a);
+  else if (which == 1) hipLaunchKernelGGL((attn_wg_dq_kernel<HS, NT>), grid, dim3(NTHR), 0, s, a);
+  else hipLaunchKernelGGL((attn_wg_dkv_kernel<HS, NT>), grid, dim3(NTHR), 0, s, a);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
@@ -445,6 +600,12 @@ int by_tokens(int which, const AttnArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int mmfn_attn_debug_read(int64_t* out64) {   // dev only: copies the 32 stamps to host memory
+  long long* p = debug_buffer();
+  if (!p) return MMFN_EINVAL;
+  return (int)hipMemcpy(out64, p, 32 * sizeof(long long), hipMemcpyDeviceToHost);
+}
 
 int mmfn_attn_wg_launch(int which, int hs, const AttnArgs& a, hipStream_t s) {
   switch (hs) {

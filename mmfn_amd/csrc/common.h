@@ -37,6 +37,21 @@ __device__ __forceinline__ float mmfn_dropout_scale(uint64_t key, uint64_t idx, 
   return u >= p ? inv_keep : 0.0f;
 }
 
+// exp(x) for the softmax kernels: branch-free, ~1-2 ulp.  expf() compiles to a call-like sequence with range branches;
+// wrapped in a per-element mask it becomes 36 divergent blocks per lane (~65 instructions each: 12 k cycles of a 35 k-cycle
+// attention kernel).  Here: x * log2(e) with the rounding error of the product (and of the constant) carried into a
+// first-order correction, then one v_exp_f32.  exp(-inf) = 0, no NaN for finite or -inf input.
+__device__ __forceinline__ float mmfn_exp(float x) {
+  const float kHi = 1.44269502162933349609375f;   // float(log2 e)
+  const float kLo = 1.925963033500347e-08f;       // log2 e - kHi
+  const float t = x * kHi;
+  float r = fmaf(x, kHi, -t);                     // exact remainder of the rounded product
+  r = fmaf(x, kLo, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  // x = -inf: t = -inf, the fmaf above is -inf - (-inf) = NaN, so take the correction only where t is finite
+  return t > -3.0e38f ? fmaf(e, r * 0.693147180559945f, e) : 0.0f;
+}
+
 __device__ __forceinline__ float mmfn_gelu(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

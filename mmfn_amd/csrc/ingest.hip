@@ -84,10 +84,16 @@ __global__ __launch_bounds__(NT) void ingest_rgb_u8_vec_kernel(const uint8_t* __
 
 // VEC: points are 16-byte records (stride 4 floats, 16-byte aligned): one float4 load per point
 template <bool VEC>
-__global__ __launch_bounds__(SPLAT_NT) void lidar_splat_kernel(const float* __restrict__ pts, int N, int stride_f,
+__global__ __launch_bounds__(SPLAT_NT) void lidar_splat_kernel(const float* __restrict__ pts, int nbatch, int N, int stride_f,
                                                                float* __restrict__ out /* [B,256,256,2] */, int flip_y) {
   __shared__ int hist[2][BAND][BINS];
-  const int band = blockIdx.x, b = blockIdx.y;
+  // XCD-aware block order: workgroup L runs on XCD L % 8 (each XCD has its own L2), so the 16 band blocks of one sample
+  // are given ids that agree mod 8 - the sample's points are then fetched from HBM by ONE L2 and the other 15 blocks hit it
+  // (with bands spread over all XCDs every L2 fetched every sample: 8x the traffic, rocprofv3 FETCH_SIZE)
+  const int L = blockIdx.x;
+  const int b = (L & 7) + 8 * (L / (8 * (BINS / BAND)));
+  const int band = (L >> 3) % (BINS / BAND);
+  if (b >= nbatch) return;
   for (int i = threadIdx.x; i < 2 * BAND * BINS; i += SPLAT_NT) (&hist[0][0][0])[i] = 0;
   __syncthreads();
   const float* P = pts + (size_t)b * N * stride_f;
@@ -174,12 +180,13 @@ extern "C" int mmfn_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, 
 
 extern "C" int mmfn_lidar_splat_f32(const float* pts, int B, int N, int stride_floats, float* out, int flip_y, void* stream) {
   if (stride_floats < 3 || N < 0) return MMFN_EINVAL;
+  if (B <= 0) return 0;
+  const dim3 grid(8 * (BINS / BAND) * ceil_div(B, 8));
   if (stride_floats == 4 && (uintptr_t)pts % 16 == 0)
-    hipLaunchKernelGGL(lidar_splat_kernel<true>, dim3(BINS / BAND, B), dim3(SPLAT_NT), 0, (hipStream_t)stream, pts, N, stride_floats,
-                       out, flip_y);
+    hipLaunchKernelGGL(lidar_splat_kernel<true>, grid, dim3(SPLAT_NT), 0, (hipStream_t)stream, pts, B, N, stride_floats, out, flip_y);
   else
-    hipLaunchKernelGGL(lidar_splat_kernel<false>, dim3(BINS / BAND, B), dim3(SPLAT_NT), 0, (hipStream_t)stream, pts, N,
-                       stride_floats, out, flip_y);
+    hipLaunchKernelGGL(lidar_splat_kernel<false>, grid, dim3(SPLAT_NT), 0, (hipStream_t)stream, pts, B, N, stride_floats, out,
+                       flip_y);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

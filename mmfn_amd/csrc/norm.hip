@@ -254,9 +254,15 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ dres, float* __restrict__ dx,
                                                            float* __restrict__ partials /* [grid][2][C] */, int M,
-                                                           int act, int rows_per_block) {
+                                                           int act, int rows_per_block, float* __restrict__ dxd, float drop_p,
+                                                           const uint64_t* __restrict__ rng_state, uint32_t rng_stream) {
   typedef float vec __attribute__((ext_vector_type(VW)));
   constexpr int C = 64 * VW * NCH;
+  // optional second output dxd = dx * dropout keep-scale(row * C + col): the gradient entering the residual branch whose
+  // forward applied that dropout in a GEMM epilogue (same counter RNG index) - saves a separate elementwise pass
+  uint64_t dkey = 0;
+  float inv_keep = 1.f;
+  if (dxd) { dkey = mmfn_rng_key(rng_state, rng_stream); inv_keep = 1.0f / (1.0f - drop_p); }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   vec dw[NCH], db[NCH], wv[NCH], bv[NCH];
 #pragma unroll
@@ -306,6 +312,12 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restri
       for (int j = 0; j < VW; ++j) o[j] = rs * (a[i][j] - c1 - xh[i][j] * c2);
       if (dres) o += *reinterpret_cast<const vec*>(dres + off);
       *reinterpret_cast<vec*>(dx + off) = o;
+      if (dxd) {
+        vec od;
+#pragma unroll
+        for (int j = 0; j < VW; ++j) od[j] = o[j] * mmfn_dropout_scale(dkey, (uint64_t)off + j, drop_p, inv_keep);
+        *reinterpret_cast<vec*>(dxd + off) = od;
+      }
     }
   }
   __shared__ float red[2][NT / 64][C];
@@ -451,14 +463,23 @@ extern "C" int mmfn_layernorm_fwd_f32(const float* x, const float* weight, const
 extern "C" int mmfn_layernorm_bwd_f32(const float* g, const float* x, const float* weight, const float* bias,
                                       const float* mean, const float* rstd, const float* dres, float* dx, float* dweight,
                                       float* dbias, int M, int C, int act, void* workspace, void* stream) {
+  return mmfn_layernorm_bwd_drop_f32(g, x, weight, bias, mean, rstd, dres, dx, dweight, dbias, M, C, act, nullptr, 0.f, nullptr, 0,
+                                     workspace, stream);
+}
+
+extern "C" int mmfn_layernorm_bwd_drop_f32(const float* g, const float* x, const float* weight, const float* bias,
+                                           const float* mean, const float* rstd, const float* dres, float* dx, float* dweight,
+                                           float* dbias, int M, int C, int act, float* dx_dropped, float drop_p,
+                                           const uint64_t* rng_state, uint32_t rng_stream, void* workspace, void* stream) {
   if (M <= 0 || !workspace) return MMFN_EINVAL;
+  if (dx_dropped && (!rng_state || drop_p <= 0.f || drop_p >= 1.f)) return MMFN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int rpb = std::max(8, ceil_div(M, 768));
   const int nblk = ceil_div(M, rpb);
   float* partials = (float*)workspace;
 #define MMFN_LN_BWD(VW, NCH) \
   hipLaunchKernelGGL((layernorm_bwd_kernel<VW, NCH>), dim3(nblk), dim3(NT), 0, s, g, x, weight, bias, mean, rstd, dres, dx, \
-                     partials, M, act, rpb)
+                     partials, M, act, rpb, dx_dropped, drop_p, rng_state, rng_stream)
   switch (C) {
     case 64: MMFN_LN_BWD(1, 1); break;
     case 128: MMFN_LN_BWD(2, 1); break;

@@ -285,6 +285,81 @@ __global__ __launch_bounds__(NT) void wino4_outgrad_kernel(const float* __restri
   }
 }
 
+// ---- data gradient in the F(4x4,3x3) domain: the ADJOINT of the forward pipeline instead of a second convolution with
+// the flipped filter.  With dM = A dY A^T (wino4_outgrad_kernel - the weight gradient needs it anyway) and the forward's
+// own U = G w G^T:   dV[t] = dM[t] . U[t]   ([tiles x Co] x [Co x Ci], one 36-batch GEMM),   dx = sum over tiles of
+// B dV_tile B^T scattered back onto the tile's 6x6 input patch.  Saves, per convolution, the filter flip, the second
+// filter transform and the input transform of dY.  Patches of neighbouring tiles overlap by two pixels, so the scatter is
+// an overlap-ADD: a block owns one image x one channel chunk, keeps that image chunk in LDS and adds the patches in four
+// phases by tile parity (tiles of equal parity are 8 pixels apart: disjoint 6x6 patches) - no atomics, fixed order.
+template <typename T>
+__device__ __forceinline__ void f4_b(const T* v, T* o) {  // o = B v, 6 -> 6 (B = transpose of the B^T in f4_bt)
+  o[0] = 4.f * v[0];
+  o[1] = 4.f * (v[2] - v[1]) + 2.f * (v[4] - v[3]) + 4.f * v[5];
+  o[2] = -5.f * v[0] - 4.f * (v[1] + v[2]) - v[3] - v[4];
+  o[3] = v[1] - v[2] + 2.f * (v[3] - v[4]) - 5.f * v[5];
+  o[4] = v[0] + v[1] + v[2] + v[3] + v[4];
+  o[5] = v[5];
+}
+
+constexpr int ADJ_LDS_FLOATS = 16384;  // H * W * (channels per block) for every supported shape (see the launcher)
+
+__global__ __launch_bounds__(NT) void wino4_input_adjoint_kernel(const float* __restrict__ dV, const float* __restrict__ res,
+                                                                 float* __restrict__ dx, int H, int W, int C, int qpb) {
+  __shared__ __attribute__((aligned(16))) float img[ADJ_LDS_FLOATS];
+  const int th = H >> 2, tw = W >> 2, nt = th * tw;
+  const int b = blockIdx.x;
+  const int quad = threadIdx.x % qpb, tile = threadIdx.x / qpb;   // tile < nt by construction (NT == nt * qpb)
+  const int ti = tile / tw, tj = tile % tw;
+  const int cch = qpb * 4;                                         // channels of this block's chunk
+  const int c4 = (blockIdx.y * qpb + quad) * 4;
+  const int64_t Tall = (int64_t)gridDim.x * nt;
+  const int64_t gt = (int64_t)b * nt + tile;
+  for (int i = threadIdx.x; i < H * W * cch / 4; i += NT) reinterpret_cast<f32x4*>(img)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 t[6][6];  // B dV, built column by column so only one 6-vector of raw values is live
+#pragma unroll
+  for (int e = 0; e < 6; ++e) {
+    f32x4 v[6], o[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) v[a] = *reinterpret_cast<const f32x4*>(dV + ((size_t)(a * 6 + e) * Tall + gt) * C + c4);
+    f4_b(v, o);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) t[a][e] = o[a];
+  }
+  __syncthreads();
+  for (int ph = 0; ph < 4; ++ph) {
+    if (((ti & 1) * 2 + (tj & 1)) == ph) {
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const int y = 4 * ti - 1 + a;
+        f32x4 o[6];
+        f4_b(t[a], o);
+        if ((unsigned)y < (unsigned)H) {
+#pragma unroll
+          for (int e = 0; e < 6; ++e) {
+            const int x = 4 * tj - 1 + e;
+            if ((unsigned)x < (unsigned)W) {   // positions outside the image are the zero padding: their gradient is dropped
+              f32x4* p = reinterpret_cast<f32x4*>(img + ((size_t)y * W + x) * cch + quad * 4);
+              *p = *p + o[e];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int y = 4 * ti + p, x = 4 * tj + q;
+      f32x4 v = *reinterpret_cast<const f32x4*>(img + ((size_t)y * W + x) * cch + quad * 4);
+      const size_t off = (((size_t)b * H + y) * W + x) * C + c4;
+      if (res) v += *reinterpret_cast<const f32x4*>(res + off);
+      *reinterpret_cast<f32x4*>(dx + off) = v;
+    }
+}
+
 // dw[co][3][3][ci] = G^T dU[:, co, ci] G;  dU is [36][Co][Ci]
 __global__ __launch_bounds__(NT) void wino4_wgrad_out_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Co, int Ci) {
   const int64_t n = (int64_t)Co * Ci;
@@ -413,6 +488,17 @@ extern "C" int mmfn_wino_outgrad_f32(const float* dy, float* dMt, int B, int H, 
   if (!dy || !dMt || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
   hipLaunchKernelGGL(wino4_outgrad_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0, (hipStream_t)stream, dy,
                      dMt, B, H, W, C);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_wino_input_adjoint_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, void* stream) {
+  if (!dV || !dx || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
+  const int nt = (H / 4) * (W / 4);
+  if (nt <= 0 || nt > NT || NT % nt) return MMFN_EINVAL;        // 8x8 .. 32x32 images: 4, 16 or 64 tiles
+  const int qpb = NT / nt;                                        // channel quads per block: H * W * 4 * qpb == 16384 floats
+  if (H * W * 4 * qpb != ADJ_LDS_FLOATS || (C / 4) % qpb) return MMFN_EINVAL;
+  hipLaunchKernelGGL(wino4_input_adjoint_kernel, dim3(B, (C / 4) / qpb), dim3(NT), 0, (hipStream_t)stream, dV, res, dx, H, W, C, qpb);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

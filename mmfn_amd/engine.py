@@ -91,17 +91,20 @@ class ConvBN(object):
         B = x.shape[0]
         _, oshape = ops.conv_geom(x.shape, self.w.shape, self.stride, self.pad)
         co = ctx.bufs.get(self.name + ".conv", oshape)
-        keep_v = None
+        keep_v = keep_u = None
         if ctx.training and ops.winograd_wgrad_ok(x.shape, self.w.shape, self.stride, self.pad):
             # the transformed input of the Winograd path is what the weight gradient needs again: keep it per layer
             keep_v = ctx.bufs.get(self.name + ".winoV", (ops.winograd_v_numel(x.shape),))
+            if ops.winograd_adjoint_ok(x.shape, self.w.shape, self.stride, self.pad):
+                # ... and the transformed filter is what the data gradient (adjoint of this forward) needs again
+                keep_u = ctx.bufs.get(self.name + ".winoU", (36 * self.w.shape[0] * self.w.shape[3],))
         M = oshape[0] * oshape[1] * oshape[2]
         co2 = co.view(M, self.cout)
         mean = ctx.bufs.get(self.name + ".mean", (self.cout,))
         rstd = ctx.bufs.get(self.name + ".rstd", (self.cout,))
         if ctx.training:
             ops.conv2d_fwd_bn_stats(x, self.w, self.stride, self.pad, co, mean, rstd, self.bn.running_mean, self.bn.running_var,
-                                    self.bn.num_batches_tracked, self.bn.eps, self.bn.momentum, keep_v=keep_v)
+                                    self.bn.num_batches_tracked, self.bn.eps, self.bn.momentum, keep_v=keep_v, keep_u=keep_u)
         else:
             ops.conv2d_fwd(x, self.w, self.stride, self.pad, out=co)
             ops.bn_eval_prepare(self.bn.running_mean, self.bn.running_var, mean, rstd, self.bn.eps)
@@ -110,6 +113,7 @@ class ConvBN(object):
                      res=None if res is None else res.view(M, self.cout))
         self.saved = (x, co, y, mean, rstd, relu)
         self.saved_v = keep_v
+        self.saved_u = keep_u
         return y
 
     def bwd(self, ctx, g, need_dx=True, ge_out=None, dx_res=None, mask_y=None):
@@ -124,6 +128,11 @@ class ConvBN(object):
             ymask = (y if mask_y is None else mask_y).view(M, self.cout)
         ops.bn_bwd(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.bn_w, dco.view(M, self.cout),
                    self.g_bn_w, self.g_bn_b, ge_out=None if ge_out is None else ge_out.view(M, self.cout))
+        u = getattr(self, "saved_u", None)
+        if need_dx and u is not None:   # weight and data gradient together in the Winograd domain (shared A dy A^T)
+            dx = ctx.bufs.get(self.name + ".dx", x.shape)
+            ops.conv2d_bwd_winograd(dco, x, u, self.gw, dx, v=getattr(self, "saved_v", None), res=dx_res)
+            return dx
         ops.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, out=self.gw, v=getattr(self, "saved_v", None))
         if not need_dx:
             return None
@@ -220,10 +229,12 @@ class LayerNorm(object):
         self.saved = (x, mean, rstd, act)
         return y
 
-    def bwd(self, ctx, g, dres=None, out=None):
+    def bwd(self, ctx, g, dres=None, out=None, dropped=None, drop_p=0.0, rng_stream=0):
+        """dropped: buffer that receives dx with the dropout mask (p, stream) of the branch consuming dx applied."""
         x, mean, rstd, act = self.saved
         dx = ctx.bufs.get(self.name + ".dx", x.shape) if out is None else out
-        ops.layernorm_bwd(g, x, self.w, self.b, mean, rstd, dx, self.gw, self.gb, act, dres=dres)
+        ops.layernorm_bwd(g, x, self.w, self.b, mean, rstd, dx, self.gw, self.gb, act, dres=dres, dx_dropped=dropped,
+                          drop_p=drop_p, rng_state=ctx.rng_state if dropped is not None else None, rng_stream=rng_stream)
         return dx
 
 
@@ -303,40 +314,48 @@ class GPT(object):
         bufs, nm = ctx.bufs, self.name
         p_embd, p_attn, p_resid = ctx.drop
         scale = 1.0 / math.sqrt(hs)
-        g = self.ln_f.bwd(ctx, g_y.view(M, C))
-        for i in range(len(self.blocks) - 1, -1, -1):
+        nblk = len(self.blocks)
+        drop = p_resid > 0.0
+        # the LayerNorm backward that produces a block's incoming gradient also writes its dropped copy (the residual
+        # dropouts of the forward sit in GEMM epilogues; their masks are re-applied here without an extra pass)
+        sb_of = lambda i: self.stream_base + 1 + 3 * i
+        gd = bufs.get("%s.b%d.gdrop" % (nm, nblk - 1), (M, C)) if drop else None
+        g = self.ln_f.bwd(ctx, g_y.view(M, C), dropped=gd, drop_p=p_resid, rng_stream=sb_of(nblk - 1) + 2)
+        for i in range(nblk - 1, -1, -1):
             blk = self.blocks[i]
-            sb = self.stream_base + 1 + 3 * i
+            sb = sb_of(i)
             x, a, qkv, o, lse, x1, a2, h = self.acts[i]
             # Weight / bias gradients only feed the optimizer, so they go to the side stream (ctx.offload) while the
-            # dX chain continues; the block-end rejoin keeps the shared scratch buffers (gh, dqkv, ...) safe to reuse.
+            # dX chain continues.  Every buffer the side stream reads (gdrop*, gh, dqkv, the block's incoming g) is PER BLOCK,
+            # so the side stream may lag the main one by any number of blocks: one rejoin at the end of the transformer
+            # instead of one per block (at C = 64 / 128 the side stream's 16 launches per block outlast the main stream's 10).
             # ---- MLP branch: x2 = x1 + drop(fc2(relu(fc1(ln2(x1)))))
-            gp = g
-            if p_resid > 0.0:
-                gp = ops.dropout_apply(g, bufs.get(nm + ".gdrop", (M, C)), p_resid, ctx.rng_state, sb + 2)
-            ctx.offload(lambda gp=gp: (ops.colsum(gp, blk["fc2"].gb), ops.linear_dw(gp, h, out=blk["fc2"].gw)))
-            gh = bufs.get(nm + ".gh", (M, 4 * C))
+            gp = gd if drop else g
+            ctx.offload(lambda gp=gp, blk=blk, h=h: (ops.colsum(gp, blk["fc2"].gb), ops.linear_dw(gp, h, out=blk["fc2"].gw)))
+            gh = bufs.get("%s.b%d.gh" % (nm, i), (M, 4 * C))
             ops.linear_dx(gp, blk["fc2"].w, out=gh, aux=h, ldaux=4 * C)
-            ctx.offload(lambda: (ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
+            ctx.offload(lambda gh=gh, blk=blk, a2=a2: (ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
             ga2 = bufs.get(nm + ".ga", (M, C))
             ops.linear_dx(gh, blk["fc1"].w, out=ga2)
-            g1 = blk["ln2"].bwd(ctx, ga2, dres=g, out=bufs.get(nm + ".g1", (M, C)))
+            gd2 = bufs.get("%s.b%d.gdrop2" % (nm, i), (M, C)) if drop else None
+            g1 = blk["ln2"].bwd(ctx, ga2, dres=g, out=bufs.get("%s.b%d.g1" % (nm, i), (M, C)), dropped=gd2, drop_p=p_resid,
+                                rng_stream=sb + 1)
             # ---- attention branch: x1 = x + drop(proj(att(ln1(x))))
-            gp = g1
-            if p_resid > 0.0:
-                gp = ops.dropout_apply(g1, bufs.get(nm + ".gdrop2", (M, C)), p_resid, ctx.rng_state, sb + 1)
-            ctx.offload(lambda gp=gp: (ops.colsum(gp, blk["proj"].gb), ops.linear_dw(gp, o, out=blk["proj"].gw)))
+            gp = gd2 if drop else g1
+            ctx.offload(lambda gp=gp, blk=blk, o=o: (ops.colsum(gp, blk["proj"].gb), ops.linear_dw(gp, o, out=blk["proj"].gw)))
             go = bufs.get(nm + ".go", (M, C))
             ops.linear_dx(gp, blk["proj"].w, out=go)
-            dqkv = bufs.get(nm + ".dqkv", (M, 3 * C))
+            dqkv = bufs.get("%s.b%d.dqkv" % (nm, i), (M, 3 * C))
             delta = bufs.get(nm + ".delta", (B, nh, T))
             ops.attention_bwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, go, C, lse, delta, dqkv[:, C:], dqkv, dqkv[:, 2 * C:],
                               3 * C, B, T, nh, hs, scale, drop_p=p_attn, rng_state=ctx.rng_state, rng_stream=sb)
-            ctx.offload(lambda: (ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
+            ctx.offload(lambda dqkv=dqkv, blk=blk, a=a: (ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
             ga = bufs.get(nm + ".ga2", (M, C))
             ops.linear_dx(dqkv, blk["wqkv"], out=ga)
-            g = blk["ln1"].bwd(ctx, ga, dres=g1, out=bufs.get(nm + ".g0_%d" % (i & 1), (M, C)))
-            ctx.rejoin()
+            gd = bufs.get("%s.b%d.gdrop" % (nm, i - 1), (M, C)) if (drop and i > 0) else None
+            g = blk["ln1"].bwd(ctx, ga, dres=g1, out=bufs.get("%s.b%d.g0" % (nm, i), (M, C)), dropped=gd, drop_p=p_resid,
+                               rng_stream=sb_of(i - 1) + 2)
+        ctx.rejoin()
         gtok = g.view(B, T, C)
         ops.tokens_bwd(gtok, self.velocity, self.g_pos.view(T, C), self.vel.gw.view(C), self.vel.gb, p_embd, ctx.rng_state,
                        self.stream_base)

@@ -138,6 +138,43 @@ def test_winograd_conv_and_dgrad(cfg):
     assert (dw - dw_direct).abs().max().item() <= 3e-5 * dw_direct.abs().max().item()
 
 
+@pytest.mark.parametrize("cfg", [(3, 32, 128, 128), (2, 16, 256, 256), (5, 8, 512, 512), (2, 16, 128, 256)])
+def test_winograd_adjoint_backward(cfg):
+    """Weight + data gradient together in the F(4x4,3x3) domain (ops.conv2d_bwd_winograd): the data gradient is the adjoint of
+    the forward pipeline (dM . U, overlap-add of B dV B^T) and reuses the transformed filter the forward kept; against torch,
+    with and without the residual add, with the kept / recomputed transformed input, and bitwise repeatable."""
+    from mmfn_amd import ops
+    dev = _dev()
+    B, HW, Cin, Cout = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(B, Cin, HW, HW, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, padding=1)
+    dy = torch.randn(y_ref.shape, generator=g)
+    y_ref.backward(dy)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    w_ohwi = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    dy_nhwc = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    assert ops.winograd_adjoint_ok(x_nhwc.shape, w_ohwi.shape, 1, 1)
+    u = torch.empty(36 * Cout * Cin, device=dev)
+    v = torch.empty(ops.winograd_v_numel(x_nhwc.shape), device=dev)
+    y = ops.conv2d_fwd(x_nhwc, w_ohwi, 1, 1, keep_v=v, keep_u=u)
+    _close(y.permute(0, 3, 1, 2), y_ref.detach())
+    res = torch.randn(B, HW, HW, Cin, generator=g).to(dev)
+    outs = []
+    for kept_v, r in ((v, None), (None, res), (v, res)):
+        dw, dx = torch.empty_like(w_ohwi), torch.empty_like(x_nhwc)
+        ops.conv2d_bwd_winograd(dy_nhwc, x_nhwc, u, dw, dx, v=kept_v, res=r)
+        _close(dw.permute(0, 3, 1, 2), wr.grad)
+        _close((dx if r is None else dx - r).permute(0, 3, 1, 2), xr.grad)
+        outs.append((dw, dx))
+    assert torch.equal(outs[1][1], outs[2][1]) and torch.equal(outs[0][0], outs[2][0])
+    # against the flipped-filter data gradient (the path it replaces)
+    old = ops.conv2d_dgrad(dy_nhwc, w_ohwi, tuple(x_nhwc.shape), 1, 1)
+    assert (outs[0][1] - old).abs().max().item() <= 3e-5 * old.abs().max().item()
+
+
 @pytest.mark.parametrize("shape", [(384, 256, 512), (224, 160, 96), (6144, 512, 2048), (64, 2048, 6144)])
 def test_bf16_operand_gemm_forms(shape):
     """MMFN_EPI_BF16_OPERANDS: every plain form equals the fp32 product of the bf16-rounded operands (fp32 accumulate);

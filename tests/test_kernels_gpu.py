@@ -88,6 +88,14 @@ def test_layernorm(M, C, act):
     _close(dx, xr.grad + dres, 2e-5, "ln dx")
     _close(dw, wr.grad, 2e-5, "ln dw")
     _close(db, br.grad, 2e-5, "ln db")
+    # optional second output: dx with the residual-branch dropout mask applied == a separate dropout pass over dx, bit for bit
+    state = torch.tensor([1234, 7], dtype=torch.int64, device=DEV)
+    dx2, dxd = torch.empty_like(xd), torch.empty_like(xd)
+    ops.layernorm_bwd(gyd, xd, wd, bd, mean, rstd, dx2, dw, db, act, dres=dresd, dx_dropped=dxd, drop_p=0.1, rng_state=state,
+                      rng_stream=42)
+    assert torch.equal(dx2, dx)
+    ref = ops.dropout_apply(dx, torch.empty_like(dx), 0.1, state, 42)
+    assert torch.equal(dxd, ref) and (dxd == 0).float().mean().item() > 0.05
 
 
 def test_colsum():
