@@ -251,7 +251,12 @@ def main():
     net.train()
     B = args.batch
     inp, gt = synth_inputs(B, dev, seed=42 + rank, n_lidar=args.n_lidar, variant=args.variant, lane_format=args.lane_format)
-    dp = DataParallel(net, dist) if world > 1 else None
+    comm_capi = None
+    if world > 1 and os.environ.get("MMFN_DP_TRANSPORT") == "capi":
+        # gradient buckets through the C ABI (libmmfn_comm.so -> RCCL on our own stream) instead of torch's ProcessGroup
+        from mmfn_amd.comm import RcclComm
+        comm_capi = RcclComm(rank, world, dist=dist)
+    dp = DataParallel(net, dist, comm=comm_capi) if world > 1 else None
     if dp is not None:
         dp.broadcast_parameters()
     eng = net._engine_for()
@@ -322,6 +327,7 @@ def main():
         dist.all_reduce(ex, op=dist.ReduceOp.MAX)
         nbytes = 4 * sum(e - b for chunks in dp.buckets for b, e in chunks)
         comm = {"backend": dist.get_backend(), "library": "RCCL over xGMI" if dist.get_backend() == "nccl" else dist.get_backend(),
+                "transport": "mmfn_allreduce_sum_f32 (C ABI)" if comm_capi is not None else "torch.distributed",
                 "ranks": dist.get_world_size(), "allreduce_bytes_per_step": nbytes, "buckets": sum(len(c) for c in dp.buckets),
                 "exposed_ms_per_step": round(float(ex.item()), 3)}
     loss_val = None if image_only else float(eng._bufs_for(B).get("head.loss", (1,)).item())

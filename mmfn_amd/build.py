@@ -42,7 +42,27 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    build_comm(force=force, verbose=verbose)
     return LIB
+
+
+COMM_SRC = os.path.join(HERE, "csrc_comm", "comm.cpp")
+COMM_LIB = os.path.join(LIBDIR, "libmmfn_comm.so")
+
+
+def build_comm(force=False, verbose=True):
+    """libmmfn_comm.so: the RCCL gradient all-reduce behind a C ABI (include/mmfn_comm.h); host code only, linked against
+    librccl (the soname torch's own RCCL answers to, so both share one library instance in a process)."""
+    hdr = os.path.join(HERE, "..", "include", "mmfn_comm.h")
+    if not force and _fresh(COMM_LIB, [COMM_SRC, hdr]):
+        return COMM_LIB
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-o", COMM_LIB, COMM_SRC, "-L%s/lib" % rocm, "-lrccl",
+           "-Wl,-rpath,%s/lib" % rocm]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return COMM_LIB
 
 
 if __name__ == "__main__":

@@ -1,0 +1,95 @@
+"""RCCL gradient exchange through the C ABI of libmmfn_comm.so (include/mmfn_comm.h).
+
+Default transport of `parallel.DataParallel` is torch.distributed (backend "nccl" = RCCL on ROCm), which owns the
+communicator and its streams.  This module is the alternative SURVEY.md section 8(b) asks for: a communicator created
+through the C ABI (`mmfn_comm_*`) and collectives enqueued on a HIP stream of OUR choosing (`mmfn_allreduce_sum_f32`).
+Collectives on a caller-owned stream can be captured into a hipGraph, so a data-parallel step on this transport is one graph.
+
+The rendezvous id (128 bytes from rank 0) travels over the torch.distributed process group the launcher already set up
+(any backend: it is a one-off object broadcast), RCCL itself is driven only through the C ABI.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmmfn_comm.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "mmfn_comm.h")
+ID_BYTES = 128
+_lib = None
+
+
+class MMFNCommError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MMFNCommError("libmmfn_comm.so not found at %s - run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        h.mmfn_comm_abi_version.restype = i32
+        h.mmfn_comm_unique_id.argtypes = [vp]
+        h.mmfn_comm_init.argtypes = [ctypes.POINTER(vp), vp, i32, i32]
+        h.mmfn_comm_destroy.argtypes = [vp]
+        h.mmfn_comm_ranks.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+        h.mmfn_allreduce_sum_f32.argtypes = [vp, vp, i64, vp]
+        h.mmfn_broadcast_bytes.argtypes = [vp, vp, i64, i32, vp]
+        for name in ("mmfn_comm_unique_id", "mmfn_comm_init", "mmfn_comm_destroy", "mmfn_comm_ranks", "mmfn_allreduce_sum_f32",
+                     "mmfn_broadcast_bytes"):
+            getattr(h, name).restype = i32
+        _lib = h
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise MMFNCommError("%s failed with code %d (positive = ncclResult_t)" % (what, rc))
+
+
+class RcclComm(object):
+    """One RCCL communicator per process (= per GPU), created through the C ABI."""
+
+    def __init__(self, rank, world, unique_id=None, dist=None):
+        """unique_id: the 128 rendezvous bytes of rank 0 (bytes object).  When absent they are created on rank 0 and
+        broadcast over `dist` (a torch.distributed-like module with an initialised default group); world == 1 needs neither."""
+        L = lib()
+        if unique_id is None:
+            buf = (ctypes.c_char * ID_BYTES)()
+            if rank == 0:
+                _check(L.mmfn_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), "mmfn_comm_unique_id")
+            payload = [bytes(buf.raw)]
+            if world > 1:
+                if dist is None:
+                    raise ValueError("world > 1 needs the rendezvous id or a process group to broadcast it over")
+                dist.broadcast_object_list(payload, src=0)
+            unique_id = payload[0]
+        assert len(unique_id) == ID_BYTES
+        self.rank, self.world = rank, world
+        self._comm = ctypes.c_void_p()
+        idbuf = ctypes.create_string_buffer(unique_id, ID_BYTES)
+        _check(L.mmfn_comm_init(ctypes.byref(self._comm), ctypes.cast(idbuf, ctypes.c_void_p), world, rank), "mmfn_comm_init")
+
+    def all_reduce_sum_(self, t, stream=None):
+        """In-place sum over ranks of a contiguous fp32 device tensor, enqueued on `stream` (default: the current one)."""
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        st = (stream or torch.cuda.current_stream()).cuda_stream
+        _check(lib().mmfn_allreduce_sum_f32(self._comm, t.data_ptr(), t.numel(), st), "mmfn_allreduce_sum_f32")
+
+    def broadcast_(self, t, root=0, stream=None):
+        assert t.is_contiguous() and t.is_cuda
+        st = (stream or torch.cuda.current_stream()).cuda_stream
+        _check(lib().mmfn_broadcast_bytes(self._comm, t.data_ptr(), t.numel() * t.element_size(), root, st), "mmfn_broadcast_bytes")
+
+    def ranks(self):
+        n, r = ctypes.c_int(), ctypes.c_int()
+        _check(lib().mmfn_comm_ranks(self._comm, ctypes.byref(n), ctypes.byref(r)), "mmfn_comm_ranks")
+        return n.value, r.value
+
+    def destroy(self):
+        if self._comm:
+            lib().mmfn_comm_destroy(self._comm)
+            self._comm = ctypes.c_void_p()

@@ -258,6 +258,18 @@ struct Lds {
   static constexpr int AREA = OPERANDS > MERGE ? OPERANDS : MERGE;
 };
 
+// XCD-aware block order.  Workgroup L runs on XCD L % 8 (each XCD has its own L2).  The two halves of a (sample, head)
+// pair read the same K / V (forward, dQ pass) or Q / dO (dK/dV pass): they get ids that agree mod 8 and are adjacent in that
+// XCD's dispatch order, so the pair's shared operands come from HBM once and the second half hits L2.
+__device__ __forceinline__ bool decode_block(const AttnArgs& a, int& half, int& hd, int& b) {
+  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int pair = (slot >> 1) * 8 + xcd;
+  half = slot & 1;
+  hd = pair % a.NH;
+  b = pair / a.NH;
+  return pair < a.NH * a.B;
+}
+
 // dev instrumentation: s_memtime stamps of waves 0 and 7 of workgroup (0,0,0) at the phase boundaries
 __device__ __forceinline__ void stamp(const AttnArgs& a, int idx) {
   if (a.dbg && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x & 63) == 0 &&
@@ -273,7 +285,8 @@ __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
   constexpr int NDT = S::NDT, G = S::G, T = 64 * NT, P = L::P;
   __shared__ __attribute__((aligned(16))) float sm[L::AREA];
   __shared__ float sm_stat[2][2][4][G];   // [slice max | slice sum][query group][key slice][query]
-  const int half = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+  int half, hd, b;
+  if (!decode_block(a, half, hd, b)) return;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int qg = w >> 2, ks = w & 3;
   const size_t rowbase = (size_t)b * T;
@@ -384,7 +397,8 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
   constexpr int NDT = S::NDT, G = S::G, T = 64 * NT, P = L::P;
   __shared__ __attribute__((aligned(16))) float sm[L::AREA];
   __shared__ float sm_stat[2][2][4][G];   // [sum P dP | sum P][query group][key slice][query]
-  const int half = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+  int half, hd, b;
+  if (!decode_block(a, half, hd, b)) return;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int qg = w >> 2, ks = w & 3;
   const size_t rowbase = (size_t)b * T;
@@ -484,7 +498,8 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
   constexpr int NDT = S::NDT, G = S::G, T = 64 * NT, P = L::P;
   __shared__ __attribute__((aligned(16))) float sm[L::AREA];
   __shared__ float sm_rows[8][2][G];   // per wave: log-sum-exp and delta of its G queries
-  const int half = blockIdx.x, hd = blockIdx.y, b = blockIdx.z;
+  int half, hd, b;
+  if (!decode_block(a, half, hd, b)) return;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int kg = w >> 2, qs = w & 3;
   const size_t rowbase = (size_t)b * T;
@@ -581,7 +596,7 @@ template <int HS, int NT>
 int launch(int which, const AttnArgs& a_in, hipStream_t s) {
   AttnArgs a = a_in;
   a.dbg = which == 0 ? debug_buffer() : nullptr;
-  dim3 grid(2, a.NH, a.B);
+  dim3 grid(2 * 8 * ceil_div(a.NH * a.B, 8));
   if (which == 0) hipLaunchKernelGGL((attn_wg_fwd_kernel<HS, NT>), grid, dim3(NTHR), 0, s, a);
   else if (which == 1) hipLaunchKernelGGL((attn_wg_dq_kernel<HS, NT>), grid, dim3(NTHR), 0, s, a);
   else hipLaunchKernelGGL((attn_wg_dkv_kernel<HS, NT>), grid, dim3(NTHR), 0, s, a);

@@ -23,6 +23,8 @@
 #include <algorithm>
 #include <cstdlib>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -982,6 +984,12 @@ bool fast_ok(const mmfn_gemm_desc& d) {
   return true;
 }
 
+// experiment switch: extra dynamic LDS per block (bytes) to cap how many blocks share a CU (tools/wino_gemm_bench.py)
+int dyn_lds_bytes() {
+  static const int v = [] { const char* e = getenv("MMFN_GEMM_DYN_LDS"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 template <int AM, int BMODE>
 int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
   const int nkt = ceil_div(d.K, BK);
@@ -1012,7 +1020,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
   {                                                                                                                  \
     const int tn = ceil_div(d.N, BN_);                                                                               \
     dim3 grid(ceil_div(d.M, BM_) * tn, zdim, d.batch > 1 ? d.batch : 1);                                             \
-    hipLaunchKernelGGL((gemm_f32_fast_kernel<AM, BMODE, BM_, BN_>), grid, dim3(NT), 0, s, dd, kps, tn, l_ow, l_ohw); \
+    hipLaunchKernelGGL((gemm_f32_fast_kernel<AM, BMODE, BM_, BN_>), grid, dim3(NT), dyn_lds_bytes(), s, dd, kps, tn, l_ow, l_ohw); \
   }
     if (tile == 1) MMFN_LAUNCH_FAST(128, 128)
     else if (tile == 3) MMFN_LAUNCH_FAST(128, 64)

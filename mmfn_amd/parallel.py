@@ -17,9 +17,14 @@ import torch
 
 
 class DataParallel(object):
-    def __init__(self, module, dist, max_bucket_bytes=256 << 20):
+    def __init__(self, module, dist, max_bucket_bytes=256 << 20, comm=None):
+        """dist: torch.distributed (process group already initialised).  comm: optional mmfn_amd.comm.RcclComm - the
+        gradient buckets then go through the C ABI (mmfn_allreduce_sum_f32) on a side HIP stream owned by this object
+        instead of through torch's ProcessGroup; everything else (broadcasts, barriers) stays on `dist`."""
         self.module = module
         self.dist = dist
+        self.comm = comm
+        self.comm_stream = None
         self.world = dist.get_world_size()
         self.layout = module._layout
         self.buckets = []
@@ -55,6 +60,19 @@ class DataParallel(object):
     def on_stage(self, stage):
         """Called by Engine.backward when every gradient of `stage` has been written (enqueued)."""
         g = self.layout.grads
+        if self.comm is not None:
+            # C-ABI transport: the bucket's reduction is ordered after the backward so far by an event, runs on our own
+            # side stream (overlapping the rest of the backward), and finish() makes the compute stream wait for it.
+            # Plain stream work, no host wait: capturable into the same hipGraph as the kernels.
+            if self.comm_stream is None:
+                self.comm_stream = torch.cuda.Stream(device=self.layout.device)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            for b, e in self.buckets[stage]:
+                self.comm.all_reduce_sum_(g[b:e], stream=self.comm_stream)
+            self.pending.append(None)
+            return
         for b, e in self.buckets[stage]:
             self.pending.append(self.dist.all_reduce(g[b:e], op=self.dist.ReduceOp.SUM, async_op=True))
 
@@ -64,8 +82,14 @@ class DataParallel(object):
         if probe:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        for w in self.pending:
-            w.wait()
+        if self.comm is not None:
+            if self.pending:
+                done = torch.cuda.Event()
+                done.record(self.comm_stream)
+                torch.cuda.current_stream().wait_event(done)
+        else:
+            for w in self.pending:
+                w.wait()
         self.pending = []
         if probe:
             e1.record()

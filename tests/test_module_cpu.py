@@ -148,3 +148,20 @@ def test_decay_groups_follow_the_reference_rule():
     import pytest
     with pytest.raises(ValueError):
         FusedAdamW(m, param_groups=[{"params": groups[0]["params"]}])   # must cover every parameter
+
+
+def test_comm_library_exports_every_declared_symbol():
+    """libmmfn_comm.so (RCCL gradient all-reduce behind a C ABI, include/mmfn_comm.h): loads and exports every declared entry
+    point; no collective is called without a GPU."""
+    import ctypes
+    import re
+    from mmfn_amd import comm
+    text = re.sub(r"/\*.*?\*/", " ", open(comm.HEADER_PATH).read(), flags=re.S)
+    declared = re.findall(r"\bint\s+(mmfn_\w+)\s*\(", text)
+    assert set(declared) == {"mmfn_comm_abi_version", "mmfn_comm_unique_id", "mmfn_comm_init", "mmfn_comm_destroy", "mmfn_comm_ranks",
+                             "mmfn_allreduce_sum_f32", "mmfn_broadcast_bytes"}
+    handle = comm.lib()
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert handle.mmfn_comm_abi_version() == 1
+    assert handle.mmfn_allreduce_sum_f32(None, None, 0, None) == -1     # argument checking happens before any RCCL call

@@ -40,6 +40,6 @@ if os.environ.get("MMFN_ATTN_DEBUG") == "1":   # phase stamps of the forward ker
         rc = _lib.lib().mmfn_attn_debug_read(ctypes.cast(buf, ctypes.c_void_p))
         st = list(buf)
         for w0 in (0, 16):
-            d = [st[w0 + i + 1] - st[w0 + i] for i in range(5)]
-            print("HS=%3d wave %d: stage %d | product %d | softmax+V %d | second %d | merge %d  (s_memtime ticks, 100 MHz?) rc=%d"
+            d = [st[w0 + 2] - st[w0 + 0]] + [st[w0 + i + 1] - st[w0 + i] for i in range(2, 5)]
+            print("HS=%3d wave %d: staging + first product %d | softmax + V staging %d | second product %d | merge + store %d  (shader cycles) rc=%d"
                   % (HS, 0 if w0 == 0 else 7, *d, rc))

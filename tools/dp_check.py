@@ -57,7 +57,11 @@ def main():
     oracle = harness.build_oracle("vec", dropout=0.0)   # closed-form weights: identical on every rank
     if rank == 0:
         net.load_state_dict(oracle.state_dict(), strict=True)
-    dp = DataParallel(net, dist); dp.broadcast_parameters()
+    comm = None
+    if os.environ.get("MMFN_DP_TRANSPORT") == "capi" and backend == "nccl":   # buckets through libmmfn_comm.so (C ABI over RCCL)
+        from mmfn_amd.comm import RcclComm
+        comm = RcclComm(rank, world, dist=dist)
+    dp = DataParallel(net, dist, comm=comm); dp.broadcast_parameters()
     inp, gt = bench.synth_inputs(2, dev, seed=7 + rank, lanes=16, n_lidar=4096)
     L = net._layout
     eng = net._engine_for()
@@ -150,7 +154,8 @@ def main():
     flags = torch.tensor([1.0 if (same_seg and value_ok and same and same_g) else 0.0])
     dist.all_reduce(flags, group=cpu_pg)
     if rank == 0:
-        print("backend:", backend, "| ranks:", world, "| devices:", ndev)
+        print("backend:", backend, "| ranks:", world, "| devices:", ndev, "| gradient transport:",
+              "C ABI (mmfn_allreduce_sum_f32)" if comm is not None else "torch.distributed")
         print("params identical across ranks:", same, "| reduced grads identical:", same_g, "| max |dp|: %.3e" % moved,
               "| loss %.6f (oracle %.6f)" % (loss.item(), loss32.item()), "| segmented graphs == eager:", same_seg)
         print("reduced gradient == mean of per-rank oracle gradients:", value_ok, "| median error ratio %.2f" % ratios[len(ratios) // 2],

@@ -1,0 +1,68 @@
+#!/bin/bash
+# Kernel trace of the hipGraph-replayed step -> timeline analysis of ONE steady-state step: how much of the wall time has a
+# GEMM-family kernel resident, how much only "glue" kernels (and which), how much nothing.  Output: gpurun_out/timeline/summary.txt
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/timeline
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT -o g -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-oracle-check --profile-steps 1 $EXTRA > $OUT/g.log 2>&1
+python3 - <<'PY' > $OUT/summary.txt
+import csv, os, collections
+out = os.environ.get('GRAFT_REPO_ROOT', '.') + '/gpurun_out/timeline'
+rows = list(csv.DictReader(open(out + '/g_kernel_trace.csv')))
+ev = []
+for r in rows:
+    k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+    ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), k))
+ev.sort()
+# steady-state step = the window between the 4th and 5th adamw launches (graph replays; the profiled eager steps come last)
+ad = [e for e in ev if e[2].startswith('adamw')]
+if len(ad) < 6:
+    print("not enough steps in the trace", len(ad)); raise SystemExit
+w0, w1 = ad[3][1], ad[4][1]
+win = [e for e in ev if e[0] >= w0 and e[1] <= w1]
+def fam(k):
+    if k.startswith('gemm_') or k.startswith('splitk'): return 'gemm'
+    if k.startswith('wino'): return 'wino-transform'
+    if k.startswith('attn'): return 'attention'
+    if k.startswith('bn_') or k.startswith('col_partial'): return 'batchnorm'
+    if k.startswith('layernorm') or k.startswith('colsum'): return 'layernorm/colsum'
+    if k.startswith('adamw') or k.startswith('step_adv'): return 'adamw'
+    return 'other'
+# sweep: at each instant the set of resident families
+pts = []
+for s, e, k in win:
+    pts.append((s, 1, fam(k))); pts.append((e, -1, fam(k)))
+pts.sort()
+active = collections.Counter()
+last = w0
+alone = collections.Counter(); with_gemm = collections.Counter()
+idle = gemm_any = 0
+for t, d, f in pts:
+    dt = t - last
+    if dt > 0:
+        fams = [x for x, c in active.items() if c > 0]
+        if not fams: idle += dt
+        elif 'gemm' in fams: gemm_any += dt
+        else:
+            for x in fams: alone[x] += dt / len(fams)
+        for x in fams:
+            if 'gemm' in fams and x != 'gemm': with_gemm[x] += dt
+    active[f] += d
+    last = t
+wall = (w1 - w0)
+print("# one hipGraph-replayed training step (B=32 vec fp32, 3 branch streams): %d kernels, wall %.2f ms" % (len(win), wall / 1e6))
+print("a GEMM-family kernel is resident      %7.2f ms  (%4.1f %%)" % (gemm_any / 1e6, 100.0 * gemm_any / wall))
+print("nothing is resident (gaps)            %7.2f ms  (%4.1f %%)" % (idle / 1e6, 100.0 * idle / wall))
+print("only non-GEMM kernels are resident    %7.2f ms  (%4.1f %%), by family:" % (sum(alone.values()) / 1e6, 100.0 * sum(alone.values()) / wall))
+for f, v in alone.most_common():
+    print("    %-22s exposed %6.2f ms   (+ %5.2f ms hidden under GEMMs)" % (f, v / 1e6, with_gemm[f] / 1e6))
+dur = collections.defaultdict(lambda: [0, 0.0])
+for s, e, k in win:
+    d = dur[k]; d[0] += 1; d[1] += (e - s) / 1e3
+print("# kernels of the step by total duration")
+for k, (n, us) in sorted(dur.items(), key=lambda kv: -kv[1][1])[:45]:
+    print("%-56s n=%4d total=%9.1f us avg=%7.2f us" % (k[:56], n, us, us / n))
+print("sum of kernel durations %.2f ms" % (sum(v[1] for v in dur.values()) / 1e3))
+PY
+cat $OUT/summary.txt
