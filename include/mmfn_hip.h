@@ -42,6 +42,10 @@ int mmfn_conv_weight_flip_f32(const float* w, float* wt, int Co, int T, int Ci, 
  *   U[n][Co][Ci] = G w G^T,  V[n][tiles][C] = B^T x B  (tiles = B*(H/m)*(W/m), zero padding 1),
  *   y = A^T Mt A (+ res, NHWC like y).  H and W multiples of m, C % 4 == 0. */
 int mmfn_wino_weight_f32(const float* w, float* U, int Co, int Ci, int m, void* stream);
+/* F(4x4,3x3) filter transforms of many layers in one launch.  table: DEVICE array of n_layers records
+ * { const float* w; float* U; int32 Co; int32 Ci; int64 start } (32 bytes each, start = running sum of Co*Ci, ascending);
+ * total = sum of Co*Ci.  U[l] receives [36][Co][Ci] exactly as mmfn_wino_weight_f32(m = 4) writes it. */
+int mmfn_wino_weight_group_f32(const void* table, int n_layers, int64_t total, void* stream);
 int mmfn_wino_input_f32(const float* x, float* V, int B, int H, int W, int C, int m, void* stream);
 int mmfn_wino_output_f32(const float* Mt, const float* res, float* y, int B, int H, int W, int C, int m, void* stream);
 /* F(4x4) output transform that also writes the BatchNorm batch-statistics partial rows of y ([*nblk_out][2][C] doubles, at most
@@ -162,11 +166,13 @@ int mmfn_layernorm_bwd_f32(const float* g, const float* x, const float* weight, 
                            int act, void* workspace, void* stream);
 /* Same, plus an optional second output dx_dropped = dx * keep_scale(row * C + col) for the dropout that the forward applied
  * in the epilogue of the following residual branch's last GEMM (counter RNG: same state / stream / index), so the backward
- * needs no separate dropout pass over dx (model_vec.py:107-108,130-131: resid_drop).  dx_dropped NULL = plain. */
+ * needs no separate dropout pass over dx (model_vec.py:107-108,130-131: resid_drop).  dx_dropped NULL = plain.
+ * dx_colsum (optional, [C]): column sums of dx_dropped (of dx when dx_dropped is NULL) = the bias gradient of the Linear
+ * whose output gradient this tensor is (attn.proj / mlp.2), produced here instead of by a separate mmfn_colsum_f32. */
 int mmfn_layernorm_bwd_drop_f32(const float* g, const float* x, const float* weight, const float* bias, const float* mean,
                                 const float* rstd, const float* dres, float* dx, float* dweight, float* dbias, int M, int C,
                                 int act, float* dx_dropped, float drop_p, const uint64_t* rng_state, uint32_t rng_stream,
-                                void* workspace, void* stream);
+                                float* dx_colsum, void* workspace, void* stream);
 /* out[c] = sum_r in[r*ld + c]   (bias gradients) */
 int64_t mmfn_colsum_workspace_bytes(int64_t M, int C);
 int mmfn_colsum_f32(const float* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream);

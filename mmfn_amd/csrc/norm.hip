@@ -255,7 +255,8 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restri
                                                            const float* __restrict__ dres, float* __restrict__ dx,
                                                            float* __restrict__ partials /* [grid][2][C] */, int M,
                                                            int act, int rows_per_block, float* __restrict__ dxd, float drop_p,
-                                                           const uint64_t* __restrict__ rng_state, uint32_t rng_stream) {
+                                                           const uint64_t* __restrict__ rng_state, uint32_t rng_stream,
+                                                           int want_sum) {
   typedef float vec __attribute__((ext_vector_type(VW)));
   constexpr int C = 64 * VW * NCH;
   // optional second output dxd = dx * dropout keep-scale(row * C + col): the gradient entering the residual branch whose
@@ -264,14 +265,16 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restri
   float inv_keep = 1.f;
   if (dxd) { dkey = mmfn_rng_key(rng_state, rng_stream); inv_keep = 1.0f / (1.0f - drop_p); }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  vec dw[NCH], db[NCH], wv[NCH], bv[NCH];
+  // want_sum: third partial row = column sums of what leaves in dxd (or in dx when there is no dropped copy): the bias
+  // gradient of the Linear whose output gradient this is - saves the separate two-launch column sum
+  vec dw[NCH], db[NCH], wv[NCH], bv[NCH], ds[NCH];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = (i * 64 + lane) * VW;
     wv[i] = *reinterpret_cast<const vec*>(w + c);
     bv[i] = *reinterpret_cast<const vec*>(b + c);
 #pragma unroll
-    for (int j = 0; j < VW; ++j) { dw[i][j] = 0.f; db[i][j] = 0.f; }
+    for (int j = 0; j < VW; ++j) { dw[i][j] = 0.f; db[i][j] = 0.f; ds[i][j] = 0.f; }
   }
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(M, r0 + rows_per_block);
@@ -317,37 +320,45 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < VW; ++j) od[j] = o[j] * mmfn_dropout_scale(dkey, (uint64_t)off + j, drop_p, inv_keep);
         *reinterpret_cast<vec*>(dxd + off) = od;
+        o = od;
       }
+      if (want_sum) ds[i] += o;
     }
   }
-  __shared__ float red[2][NT / 64][C];
+  __shared__ float red[3][NT / 64][C];
 #pragma unroll
   for (int i = 0; i < NCH; ++i)
 #pragma unroll
     for (int j = 0; j < VW; ++j) {
       red[0][wave][(i * 64 + lane) * VW + j] = dw[i][j];
       red[1][wave][(i * 64 + lane) * VW + j] = db[i][j];
+      red[2][wave][(i * 64 + lane) * VW + j] = ds[i][j];
     }
   __syncthreads();
+  const int rows = want_sum ? 3 : 2;
   for (int c = threadIdx.x; c < C; c += NT) {
-    float sw = 0.f, sb = 0.f;
+    float sw = 0.f, sb = 0.f, ss = 0.f;
 #pragma unroll
-    for (int k = 0; k < NT / 64; ++k) { sw += red[0][k][c]; sb += red[1][k][c]; }
-    partials[(size_t)blockIdx.x * 2 * C + c] = sw;
-    partials[(size_t)blockIdx.x * 2 * C + C + c] = sb;
+    for (int k = 0; k < NT / 64; ++k) { sw += red[0][k][c]; sb += red[1][k][c]; ss += red[2][k][c]; }
+    partials[(size_t)blockIdx.x * rows * C + c] = sw;
+    partials[(size_t)blockIdx.x * rows * C + C + c] = sb;
+    if (want_sum) partials[(size_t)blockIdx.x * rows * C + 2 * C + c] = ss;
   }
 }
 
 __global__ void colsum_finalize_kernel(const float* __restrict__ partials, int nblk, int C, float* __restrict__ out0,
-                                       float* __restrict__ out1) {
+                                       float* __restrict__ out1, float* __restrict__ out2) {
   __shared__ double sh[FIN_LANES][FIN_COLS];
   const int c = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
   const bool valid = c < C;
-  const double s0 = reduce_partials(partials, nblk, (size_t)2 * C, c, valid, sh);
-  const double s1 = out1 ? reduce_partials(partials + C, nblk, (size_t)2 * C, c, valid, sh) : 0.0;
+  const size_t stride = (size_t)(out2 ? 3 : 2) * C;
+  const double s0 = reduce_partials(partials, nblk, stride, c, valid, sh);
+  const double s1 = out1 ? reduce_partials(partials + C, nblk, stride, c, valid, sh) : 0.0;
+  const double s2 = out2 ? reduce_partials(partials + 2 * C, nblk, stride, c, valid, sh) : 0.0;
   if (!valid || threadIdx.x >= FIN_COLS) return;
   out0[c] = (float)s0;
   if (out1) out1[c] = (float)s1;
+  if (out2) out2[c] = (float)s2;
 }
 
 // generic column sum: out[c] = sum_r in[r, c]   (bias gradients)
@@ -464,13 +475,14 @@ extern "C" int mmfn_layernorm_bwd_f32(const float* g, const float* x, const floa
                                       const float* mean, const float* rstd, const float* dres, float* dx, float* dweight,
                                       float* dbias, int M, int C, int act, void* workspace, void* stream) {
   return mmfn_layernorm_bwd_drop_f32(g, x, weight, bias, mean, rstd, dres, dx, dweight, dbias, M, C, act, nullptr, 0.f, nullptr, 0,
-                                     workspace, stream);
+                                     nullptr, workspace, stream);
 }
 
 extern "C" int mmfn_layernorm_bwd_drop_f32(const float* g, const float* x, const float* weight, const float* bias,
                                            const float* mean, const float* rstd, const float* dres, float* dx, float* dweight,
                                            float* dbias, int M, int C, int act, float* dx_dropped, float drop_p,
-                                           const uint64_t* rng_state, uint32_t rng_stream, void* workspace, void* stream) {
+                                           const uint64_t* rng_state, uint32_t rng_stream, float* dx_colsum, void* workspace,
+                                           void* stream) {
   if (M <= 0 || !workspace) return MMFN_EINVAL;
   if (dx_dropped && (!rng_state || drop_p <= 0.f || drop_p >= 1.f)) return MMFN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -479,7 +491,7 @@ extern "C" int mmfn_layernorm_bwd_drop_f32(const float* g, const float* x, const
   float* partials = (float*)workspace;
 #define MMFN_LN_BWD(VW, NCH) \
   hipLaunchKernelGGL((layernorm_bwd_kernel<VW, NCH>), dim3(nblk), dim3(NT), 0, s, g, x, weight, bias, mean, rstd, dres, dx, \
-                     partials, M, act, rpb, dx_dropped, drop_p, rng_state, rng_stream)
+                     partials, M, act, rpb, dx_dropped, drop_p, rng_state, rng_stream, dx_colsum ? 1 : 0)
   switch (C) {
     case 64: MMFN_LN_BWD(1, 1); break;
     case 128: MMFN_LN_BWD(2, 1); break;
@@ -489,7 +501,8 @@ extern "C" int mmfn_layernorm_bwd_drop_f32(const float* g, const float* x, const
   }
 #undef MMFN_LN_BWD
   MMFN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, partials, nblk, C, dweight, dbias);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, partials, nblk, C, dweight,
+                     dbias, dx_colsum);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

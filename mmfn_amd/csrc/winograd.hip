@@ -239,6 +239,43 @@ __global__ __launch_bounds__(NT) void wino4_output_kernel(const float* __restric
   }
 }
 
+// All filter transforms of a training step in ONE launch: the filters only change at the optimizer step, so the forward
+// transforms every Winograd layer's filter up front (55 layers in the vec model: 55 launches of ~7 us each become one
+// ~0.2 ms streaming kernel that runs beside the stem / layer1 convolutions).  table[l] = {w, U, Co, Ci, first element}.
+struct WinoGroupEntry { const float* w; float* U; int Co; int Ci; long long start; };
+
+__global__ __launch_bounds__(NT) void wino4_weight_group_kernel(const WinoGroupEntry* __restrict__ table, int n_layers,
+                                                                long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n_layers - 1;   // last entry with start <= i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (table[mid].start <= i) lo = mid; else hi = mid - 1;
+    }
+    const WinoGroupEntry e = table[lo];
+    const long long j = i - e.start;
+    const int Co = e.Co, Ci = e.Ci;
+    const int co = (int)(j / Ci), ci = (int)(j % Ci);
+    float t[6][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      float g[3], u[6];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) g[a] = e.w[(((size_t)co * 3 + a) * 3 + b) * Ci + ci];
+      f4_g(g, u);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) t[a][b] = u[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      float u[6];
+      f4_g(t[a], u);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) e.U[((size_t)(a * 6 + b) * Co + co) * Ci + ci] = u[b];
+    }
+  }
+}
+
 // ---- weight gradient in the F(4x4,3x3) domain:  dw = G^T [ sum_tiles (A dY A^T) . (B^T x B) ] G
 // dMt[t][tile][c] = (A dy A^T)[t] for the 4x4 output-gradient patch of the tile (A = transpose of A^T above, 6x4)
 template <typename T>
@@ -302,11 +339,13 @@ __device__ __forceinline__ void f4_b(const T* v, T* o) {  // o = B v, 6 -> 6 (B 
   o[5] = v[5];
 }
 
-constexpr int ADJ_LDS_FLOATS = 16384;  // H * W * (channels per block) for every supported shape (see the launcher)
-
-__global__ __launch_bounds__(NT) void wino4_input_adjoint_kernel(const float* __restrict__ dV, const float* __restrict__ res,
-                                                                 float* __restrict__ dx, int H, int W, int C, int qpb) {
-  __shared__ __attribute__((aligned(16))) float img[ADJ_LDS_FLOATS];
+// NTHR threads = (tiles of the image) x (qpb channel quads); LDSF = H * W * 4 * qpb floats.  The launcher picks the block
+// size per image size so that every shape gets >= 256 blocks (32x32: 256 threads / 4 quads, 16x16: 128 / 8, 8x8: 64 / 16).
+template <int NTHR, int LDSF>
+__global__ __launch_bounds__(NTHR) void wino4_input_adjoint_kernel(const float* __restrict__ dV, const float* __restrict__ res,
+                                                                   float* __restrict__ dx, int H, int W, int C, int qpb) {
+  constexpr int NT = NTHR;   // shadows the file-level block size inside this kernel
+  __shared__ __attribute__((aligned(16))) float img[LDSF];
   const int th = H >> 2, tw = W >> 2, nt = th * tw;
   const int b = blockIdx.x;
   const int quad = threadIdx.x % qpb, tile = threadIdx.x / qpb;   // tile < nt by construction (NT == nt * qpb)
@@ -455,6 +494,14 @@ extern "C" int mmfn_wino_weight_f32(const float* w, float* U, int Co, int Ci, in
   return 0;
 }
 
+extern "C" int mmfn_wino_weight_group_f32(const void* table, int n_layers, int64_t total, void* stream) {
+  if (!table || n_layers <= 0 || total <= 0) return MMFN_EINVAL;
+  hipLaunchKernelGGL(wino4_weight_group_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                     (const WinoGroupEntry*)table, n_layers, (long long)total);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmfn_wino_input_f32(const float* x, float* V, int B, int H, int W, int C, int m, void* stream) {
   if (!x || !V || (m != 2 && m != 4) || (H % m) || (W % m) || (C & 3) || B <= 0) return MMFN_EINVAL;
   if (m == 4) {
@@ -494,11 +541,20 @@ extern "C" int mmfn_wino_outgrad_f32(const float* dy, float* dMt, int B, int H, 
 
 extern "C" int mmfn_wino_input_adjoint_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, void* stream) {
   if (!dV || !dx || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
-  const int nt = (H / 4) * (W / 4);
-  if (nt <= 0 || nt > NT || NT % nt) return MMFN_EINVAL;        // 8x8 .. 32x32 images: 4, 16 or 64 tiles
-  const int qpb = NT / nt;                                        // channel quads per block: H * W * 4 * qpb == 16384 floats
-  if (H * W * 4 * qpb != ADJ_LDS_FLOATS || (C / 4) % qpb) return MMFN_EINVAL;
-  hipLaunchKernelGGL(wino4_input_adjoint_kernel, dim3(B, (C / 4) / qpb), dim3(NT), 0, (hipStream_t)stream, dV, res, dx, H, W, C, qpb);
+  if (H != W) return MMFN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (H == 32) {          // 64 tiles x 4 quads
+    if ((C / 4) % 4) return MMFN_EINVAL;
+    hipLaunchKernelGGL((wino4_input_adjoint_kernel<256, 32 * 32 * 16>), dim3(B, C / 16), dim3(256), 0, s, dV, res, dx, H, W, C, 4);
+  } else if (H == 16) {   // 16 tiles x 8 quads
+    if ((C / 4) % 8) return MMFN_EINVAL;
+    hipLaunchKernelGGL((wino4_input_adjoint_kernel<128, 16 * 16 * 32>), dim3(B, C / 32), dim3(128), 0, s, dV, res, dx, H, W, C, 8);
+  } else if (H == 8) {    // 4 tiles x 16 quads
+    if ((C / 4) % 16) return MMFN_EINVAL;
+    hipLaunchKernelGGL((wino4_input_adjoint_kernel<64, 8 * 8 * 64>), dim3(B, C / 64), dim3(64), 0, s, dV, res, dx, H, W, C, 16);
+  } else {
+    return MMFN_EINVAL;
+  }
   MMFN_LAUNCH_CHECK();
   return 0;
 }

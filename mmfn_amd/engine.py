@@ -46,12 +46,26 @@ class Buffers(object):
 class Ctx(object):
     """Per-call execution context."""
 
-    def __init__(self, bufs, training, drop_p, rng_state, side=None):
+    def __init__(self, bufs, training, drop_p, rng_state, side=None, engine=None):
         self.bufs = bufs
+        self.engine = engine
+        self.wino_ready = False   # True: the filters of the registered Winograd layers were transformed by the grouped launch
         self.training = training
         self.drop = drop_p if training else (0.0, 0.0, 0.0)  # (embd, attn, resid)
         self.rng_state = rng_state
         self.side = side  # side stream for work that is off the critical path (weight gradients), or None
+
+    def wino_u(self, name, w):
+        """Engine-wide buffer for a layer's transformed filter U [36][Co][Ci]; registers the layer for the grouped transform."""
+        eng = self.engine
+        u = eng.wino_layers.get(name)
+        if u is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("Winograd filter buffer %s first used during graph capture; run one eager step first" % name)
+            u = (w, torch.empty(36 * w.shape[0] * w.shape[3], dtype=torch.float32, device=w.device))
+            eng.wino_layers[name] = u
+            eng.wino_table = None   # rebuilt before the next forward
+        return u[1]
 
     def offload(self, fn):
         """Run fn (launches that only produce parameter gradients) on the side stream, ordered after everything
@@ -96,15 +110,17 @@ class ConvBN(object):
             # the transformed input of the Winograd path is what the weight gradient needs again: keep it per layer
             keep_v = ctx.bufs.get(self.name + ".winoV", (ops.winograd_v_numel(x.shape),))
             if ops.winograd_adjoint_ok(x.shape, self.w.shape, self.stride, self.pad):
-                # ... and the transformed filter is what the data gradient (adjoint of this forward) needs again
-                keep_u = ctx.bufs.get(self.name + ".winoU", (36 * self.w.shape[0] * self.w.shape[3],))
+                # ... and the transformed filter is what the data gradient (adjoint of this forward) needs again.  The
+                # buffer is engine-wide (it does not depend on the batch): Engine.forward transforms all of them in one launch
+                keep_u = ctx.wino_u(self.name, self.w)
         M = oshape[0] * oshape[1] * oshape[2]
         co2 = co.view(M, self.cout)
         mean = ctx.bufs.get(self.name + ".mean", (self.cout,))
         rstd = ctx.bufs.get(self.name + ".rstd", (self.cout,))
         if ctx.training:
             ops.conv2d_fwd_bn_stats(x, self.w, self.stride, self.pad, co, mean, rstd, self.bn.running_mean, self.bn.running_var,
-                                    self.bn.num_batches_tracked, self.bn.eps, self.bn.momentum, keep_v=keep_v, keep_u=keep_u)
+                                    self.bn.num_batches_tracked, self.bn.eps, self.bn.momentum, keep_v=keep_v, keep_u=keep_u,
+                                    u_ready=keep_u is not None and ctx.wino_ready)
         else:
             ops.conv2d_fwd(x, self.w, self.stride, self.pad, out=co)
             ops.bn_eval_prepare(self.bn.running_mean, self.bn.running_var, mean, rstd, self.bn.eps)
@@ -229,12 +245,14 @@ class LayerNorm(object):
         self.saved = (x, mean, rstd, act)
         return y
 
-    def bwd(self, ctx, g, dres=None, out=None, dropped=None, drop_p=0.0, rng_stream=0):
-        """dropped: buffer that receives dx with the dropout mask (p, stream) of the branch consuming dx applied."""
+    def bwd(self, ctx, g, dres=None, out=None, dropped=None, drop_p=0.0, rng_stream=0, colsum=None):
+        """dropped: buffer that receives dx with the dropout mask (p, stream) of the branch consuming dx applied.
+        colsum: [C] gradient buffer that receives the column sums of that tensor (the consuming Linear's bias gradient)."""
         x, mean, rstd, act = self.saved
         dx = ctx.bufs.get(self.name + ".dx", x.shape) if out is None else out
         ops.layernorm_bwd(g, x, self.w, self.b, mean, rstd, dx, self.gw, self.gb, act, dres=dres, dx_dropped=dropped,
-                          drop_p=drop_p, rng_state=ctx.rng_state if dropped is not None else None, rng_stream=rng_stream)
+                          drop_p=drop_p, rng_state=ctx.rng_state if dropped is not None else None, rng_stream=rng_stream,
+                          dx_colsum=colsum)
         return dx
 
 
@@ -320,7 +338,9 @@ class GPT(object):
         # dropouts of the forward sit in GEMM epilogues; their masks are re-applied here without an extra pass)
         sb_of = lambda i: self.stream_base + 1 + 3 * i
         gd = bufs.get("%s.b%d.gdrop" % (nm, nblk - 1), (M, C)) if drop else None
-        g = self.ln_f.bwd(ctx, g_y.view(M, C), dropped=gd, drop_p=p_resid, rng_stream=sb_of(nblk - 1) + 2)
+        # ... and its column sums, which are the bias gradient of the Linear that closes the residual branch (mlp.2 / attn.proj)
+        g = self.ln_f.bwd(ctx, g_y.view(M, C), dropped=gd, drop_p=p_resid, rng_stream=sb_of(nblk - 1) + 2,
+                          colsum=self.blocks[nblk - 1]["fc2"].gb)
         for i in range(nblk - 1, -1, -1):
             blk = self.blocks[i]
             sb = sb_of(i)
@@ -331,7 +351,7 @@ class GPT(object):
             # instead of one per block (at C = 64 / 128 the side stream's 16 launches per block outlast the main stream's 10).
             # ---- MLP branch: x2 = x1 + drop(fc2(relu(fc1(ln2(x1)))))
             gp = gd if drop else g
-            ctx.offload(lambda gp=gp, blk=blk, h=h: (ops.colsum(gp, blk["fc2"].gb), ops.linear_dw(gp, h, out=blk["fc2"].gw)))
+            ctx.offload(lambda gp=gp, blk=blk, h=h: ops.linear_dw(gp, h, out=blk["fc2"].gw))   # fc2.gb: from the LayerNorm backward
             gh = bufs.get("%s.b%d.gh" % (nm, i), (M, 4 * C))
             ops.linear_dx(gp, blk["fc2"].w, out=gh, aux=h, ldaux=4 * C)
             ctx.offload(lambda gh=gh, blk=blk, a2=a2: (ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
@@ -339,10 +359,10 @@ class GPT(object):
             ops.linear_dx(gh, blk["fc1"].w, out=ga2)
             gd2 = bufs.get("%s.b%d.gdrop2" % (nm, i), (M, C)) if drop else None
             g1 = blk["ln2"].bwd(ctx, ga2, dres=g, out=bufs.get("%s.b%d.g1" % (nm, i), (M, C)), dropped=gd2, drop_p=p_resid,
-                                rng_stream=sb + 1)
+                                rng_stream=sb + 1, colsum=blk["proj"].gb)
             # ---- attention branch: x1 = x + drop(proj(att(ln1(x))))
             gp = gd2 if drop else g1
-            ctx.offload(lambda gp=gp, blk=blk, o=o: (ops.colsum(gp, blk["proj"].gb), ops.linear_dw(gp, o, out=blk["proj"].gw)))
+            ctx.offload(lambda gp=gp, blk=blk, o=o: ops.linear_dw(gp, o, out=blk["proj"].gw))   # proj.gb: from ln2's backward
             go = bufs.get(nm + ".go", (M, C))
             ops.linear_dx(gp, blk["proj"].w, out=go)
             dqkv = bufs.get("%s.b%d.dqkv" % (nm, i), (M, 3 * C))
@@ -354,7 +374,7 @@ class GPT(object):
             ops.linear_dx(dqkv, blk["wqkv"], out=ga)
             gd = bufs.get("%s.b%d.gdrop" % (nm, i - 1), (M, C)) if (drop and i > 0) else None
             g = blk["ln1"].bwd(ctx, ga, dres=g1, out=bufs.get("%s.b%d.g0" % (nm, i), (M, C)), dropped=gd, drop_p=p_resid,
-                               rng_stream=sb_of(i - 1) + 2)
+                               rng_stream=sb_of(i - 1) + 2, colsum=self.blocks[i - 1]["fc2"].gb if i > 0 else None)
         ctx.rejoin()
         gtok = g.view(B, T, C)
         ops.tokens_bwd(gtok, self.velocity, self.g_pos.view(T, C), self.vel.gw.view(C), self.vel.gb, p_embd, ctx.rng_state,
@@ -742,6 +762,8 @@ class Engine(object):
         self.multi_stream = True
         # "f32" (parity path) or "bf16": bf16 MFMA operands with fp32 accumulation for the Linear / Winograd GEMMs
         self.gemm_dtype = getattr(cfg, "gemm_dtype", "f32")
+        self.wino_layers = {}     # ConvBN name -> (filter storage, transformed-filter buffer): filled by the first training forward
+        self.wino_table = None
         self.opt_group_of = None
         self.opt_hyper = torch.zeros(16, 8, dtype=torch.float32, device=dev)
         self._hyper_host = None
@@ -759,7 +781,7 @@ class Engine(object):
     def _ctx(self, B, training):
         cfg = self.cfg
         side = self.side[0] if (self.multi_stream and self.offload_wgrad and training) else None
-        return Ctx(self._bufs_for(B), training, (cfg.embd_pdrop, cfg.attn_pdrop, cfg.resid_pdrop), self.rng_state, side)
+        return Ctx(self._bufs_for(B), training, (cfg.embd_pdrop, cfg.attn_pdrop, cfg.resid_pdrop), self.rng_state, side, engine=self)
 
     def _ingest(self, ctx, inp):
         """inp: dict of device tensors -> NHWC network inputs."""
@@ -829,7 +851,17 @@ class Engine(object):
         vel = inp["velocity"]
         trunks = [self.img, self.lid, self.map]
 
+        if training and self.wino_layers:
+            # every Winograd filter transform of the step in one launch (the layers registered themselves in an earlier
+            # forward); it runs at the head of the shortest branch, the consumers (layer2 and deeper) come after the first
+            # fusion transformer, where all branches have joined
+            if self.wino_table is None and not torch.cuda.is_current_stream_capturing():
+                self.wino_table = ops.make_wino_group_table(list(self.wino_layers.values()), self.device)
+            ctx.wino_ready = self.wino_table is not None
+
         def map_stage1():
+            if ctx.wino_ready:
+                ops.wino_weight_group(*self.wino_table)
             if self.variant == "img":
                 return self.map.layer_fwd(ctx, 1, self.map.stem_fwd(ctx, mp))
             return self.vec.fwd(ctx, inp["lane"], inp["lane_num"])

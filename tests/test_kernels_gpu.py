@@ -96,6 +96,14 @@ def test_layernorm(M, C, act):
     assert torch.equal(dx2, dx)
     ref = ops.dropout_apply(dx, torch.empty_like(dx), 0.1, state, 42)
     assert torch.equal(dxd, ref) and (dxd == 0).float().mean().item() > 0.05
+    # optional third output: column sums of the dropped copy (of dx itself without one) = the next Linear's bias gradient
+    cs = torch.empty(C, device=DEV)
+    ops.layernorm_bwd(gyd, xd, wd, bd, mean, rstd, dx2, dw, db, act, dres=dresd, dx_dropped=dxd, drop_p=0.1, rng_state=state,
+                      rng_stream=42, dx_colsum=cs)
+    _close(cs, dxd.double().sum(0).float(), 2e-5, "ln dx colsum (dropped)")
+    _close(dw, wr.grad, 2e-5, "ln dw with the third partial row")
+    ops.layernorm_bwd(gyd, xd, wd, bd, mean, rstd, dx2, dw, db, act, dres=dresd, dx_colsum=cs)
+    _close(cs, dx.double().sum(0).float(), 2e-5, "ln dx colsum")
 
 
 def test_colsum():
