@@ -248,6 +248,14 @@ int mmfn_lidar_splat_f32(const float* pts, int B, int N, int stride_floats, floa
 int mmfn_lane_to_vector_f32(const float* lane, float* vec, int64_t R, int n, void* stream);
 
 /* ---- VectorNet polyline max-pool + concat (model_vec.py:269-282) -------------------------------- */
+/* Lane attention of VectorNet for QUERY 0 ONLY (model_vec.py:301-324 MaskSelfAttention, of which VectornetEncoder.forward
+ * :412 consumes lane 0's row alone): any number of lanes, keys >= kv_len[b] masked as the reference's -1e9 fill, kv_len 0 =
+ * uniform attention.  qkv [B*L, 3*heads*64] = [q | k | v]; att0 [B, heads*64]; prob [B, heads, L] (saved for the backward);
+ * the backward writes ALL of dqkv (dq of row 0, zeros for the dead query rows, dk / dv of every lane). */
+int mmfn_lane0_attention_fwd_f32(const float* qkv, const int32_t* kv_len, int B, int L, int heads, int head_dim, float scale,
+                                 float* att0, float* prob, void* stream);
+int mmfn_lane0_attention_bwd_f32(const float* qkv, const float* prob, const float* g_att0, const int32_t* kv_len, int B, int L,
+                                 int heads, int head_dim, float scale, float* dqkv, void* stream);
 int mmfn_polyline_pool_fwd_f32(const float* y, float* out, uint8_t* arg, int R, int V, int H, int last, void* stream);
 int mmfn_polyline_pool_bwd_f32(const float* gout, const uint8_t* arg, float* gy, int R, int V, int H, int last,
                                void* stream);

@@ -433,14 +433,14 @@ class VectorNet(object):
         tok = x  # [R,128] lane tokens
         qkv = bufs.get(nm + ".qkv", (R, 384))
         ops.linear_fwd(tok, self.qkv.w, None, out=qkv)
-        att = bufs.get(nm + ".att", (R, 128))
-        lse = bufs.get(nm + ".lse", (B, self.heads, L))
+        # Only lane 0's attended token feeds the encoder output (model_vec.py:412), so the lane attention runs for query 0
+        # alone: O(L) instead of O(L^2), and any number of lanes (the fused attention kernels stop at 256 tokens)
         hd = 128 // self.heads
-        ops.attention_fwd(qkv, qkv[:, 128:], qkv[:, 256:], 384, att, 128, lse, B, L, self.heads, hd, hd ** -0.5, kv_len=lane_num)
-        # lane 0 of every sample: strided rows of `att`
-        att0 = att.view(B, L * 128)[:, :128]
+        att0 = bufs.get(nm + ".att0", (B, 128))
+        prob = bufs.get(nm + ".prob", (B, self.heads, L))
+        ops.lane0_attention_fwd(qkv, lane_num, B, L, self.heads, hd, hd ** -0.5, att0, prob)
         t0 = bufs.get(nm + ".t0", (B, 128))
-        ops.gemm(att0, self.to_out.w, t0, B, 128, 128, L * 128, 128, 128, bias=self.to_out.b)
+        ops.gemm(att0, self.to_out.w, t0, B, 128, 128, 128, 128, 128, bias=self.to_out.b)
         # constant positional branch: pos_emb(zeros) = Linear(GELU(LN(bias0)))
         pe_pre = bufs.get(nm + ".pe.pre", (1, 64))
         zero2 = bufs.get(nm + ".zero2", (1, 2))
@@ -464,12 +464,12 @@ class VectorNet(object):
         ops.linear_fwd(gen_act, self.gen3.w, self.gen3.b, out=nchw)
         out = bufs.get(nm + ".out", (B, 64, 64, 64))
         ops.transpose(nchw, out, B, 64, 4096)  # "b (n d a)" -> NHWC [b, d, a, n]
-        self.saved = (B, L, V, tok, qkv, att, lse, lane_num, t0, pe, pe_act, af_act, fused, gen_act)
+        self.saved = (B, L, V, tok, qkv, att0, prob, lane_num, t0, pe, pe_act, af_act, fused, gen_act)
         return out
 
     def bwd(self, ctx, g_out):
         bufs, nm = ctx.bufs, self.name
-        B, L, V, tok, qkv, att, lse, lane_num, t0, pe, pe_act, af_act, fused, gen_act = self.saved
+        B, L, V, tok, qkv, att0, prob, lane_num, t0, pe, pe_act, af_act, fused, gen_act = self.saved
         R = B * L
         g_nchw = bufs.get(nm + ".g.nchw", (B, 64 * 64 * 64))
         ops.transpose(g_out.view(B, 4096, 64), g_nchw, B, 4096, 64)
@@ -502,16 +502,12 @@ class VectorNet(object):
         ops.fill(self.pe0.gw, 0.0)
         # to_out on lane 0 only
         ops.colsum(g_t0, self.to_out.gb)
-        att0 = att.view(B, L * 128)[:, :128]
-        ops.gemm(g_t0, att0, self.to_out.gw, 128, 128, B, 128, L * 128, 128, a_mode=ops.A_COLMAJOR, b_mode=ops.B_KN)
-        g_att = bufs.get(nm + ".g.att", (R, 128))
-        ops.fill(g_att, 0.0)
-        ops.gemm(g_t0, self.to_out.w, g_att.view(B, L * 128)[:, :128], B, 128, 128, 128, 128, L * 128, b_mode=ops.B_KN)
+        ops.gemm(g_t0, att0, self.to_out.gw, 128, 128, B, 128, 128, 128, a_mode=ops.A_COLMAJOR, b_mode=ops.B_KN)
+        g_att0 = bufs.get(nm + ".g.att0", (B, 128))
+        ops.gemm(g_t0, self.to_out.w, g_att0, B, 128, 128, 128, 128, 128, b_mode=ops.B_KN)
         dqkv = bufs.get(nm + ".g.qkv", (R, 384))
-        delta = bufs.get(nm + ".delta", (B, self.heads, L))
         hd = 128 // self.heads
-        ops.attention_bwd(qkv, qkv[:, 128:], qkv[:, 256:], 384, att, g_att, 128, lse, delta, dqkv, dqkv[:, 128:], dqkv[:, 256:],
-                          384, B, L, self.heads, hd, hd ** -0.5, kv_len=lane_num)
+        ops.lane0_attention_bwd(qkv, prob, g_att0, lane_num, B, L, self.heads, hd, hd ** -0.5, dqkv)
         ops.linear_dw(dqkv, tok, out=self.qkv.gw)
         g = ops.linear_dx(dqkv, self.qkv.w, out=bufs.get(nm + ".g.tok", (R, 128)))
         for i in range(len(self.sub) - 1, -1, -1):

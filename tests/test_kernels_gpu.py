@@ -100,10 +100,10 @@ def test_layernorm(M, C, act):
     cs = torch.empty(C, device=DEV)
     ops.layernorm_bwd(gyd, xd, wd, bd, mean, rstd, dx2, dw, db, act, dres=dresd, dx_dropped=dxd, drop_p=0.1, rng_state=state,
                       rng_stream=42, dx_colsum=cs)
-    _close(cs, dxd.double().sum(0).float(), 2e-5, "ln dx colsum (dropped)")
+    _close(cs, dxd.double().sum(0).float().cpu(), 2e-5, "ln dx colsum (dropped)")
     _close(dw, wr.grad, 2e-5, "ln dw with the third partial row")
     ops.layernorm_bwd(gyd, xd, wd, bd, mean, rstd, dx2, dw, db, act, dres=dresd, dx_colsum=cs)
-    _close(cs, dx.double().sum(0).float(), 2e-5, "ln dx colsum")
+    _close(cs, dx.double().sum(0).float().cpu(), 2e-5, "ln dx colsum")
 
 
 def test_colsum():

@@ -47,3 +47,39 @@ def report(tag, sd):
 report("reference init (seed 42)", None)
 from oracle import harness
 report("closed-form test fill", harness.build_oracle("vec", dropout=0.0).state_dict())
+
+
+def oracle_yardstick(Bo=8):
+    """What torch's OWN mixed precision does to this network's gradients: the CPU oracle under torch.autocast(bfloat16)
+    against itself in fp32, same reference-style init, per backward stage.  The yardstick for the HIP bf16 mode."""
+    from oracle import fixtures, harness
+    from mmfn_amd.params import FlatLayout
+    torch.manual_seed(42)
+    torch.set_num_threads(bench.usable_cores())
+    net = MMFN(GlobalConfig(embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0), "cpu")   # reference-style init (parameter skeleton)
+    oracle = harness.build_oracle("vec", dropout=0.0)
+    oracle.load_state_dict(net.state_dict(), strict=True)
+    inp, gt = bench.synth_inputs(Bo, torch.device("cpu"), seed=42)
+    args = harness.forward_args(bench.oracle_batch_from_inputs(inp, "vec"), "vec")
+
+    def run(autocast):
+        oracle.train()
+        for p in oracle.parameters():
+            p.grad = None
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            pred = oracle(*args)
+        loss = harness.l1_waypoint_loss(pred.float(), gt)
+        loss.backward()
+        return float(loss), {k: p.grad.detach().clone() for k, p in oracle.named_parameters() if p.grad is not None}
+
+    l32, g32 = run(False)
+    l16, g16 = run(True)
+    print("[CPU oracle, torch.autocast(bfloat16) vs fp32, batch %d] loss %.6f vs %.6f" % (Bo, l16, l32))
+    for st in range(4):
+        names = [k for k in g32 if FlatLayout.stage_of(k) == st]
+        a = torch.cat([g32[k].flatten().double() for k in names]); c = torch.cat([g16[k].flatten().double() for k in names])
+        print("   stage %d: cosine %.5f  rel err %.3e" % (st, float(torch.dot(a, c) / (a.norm() * c.norm())), float((a - c).norm() / a.norm())))
+
+
+if os.environ.get("ORACLE_YARDSTICK", "1") == "1":
+    oracle_yardstick()
