@@ -702,8 +702,15 @@ __device__ __forceinline__ int hslot(int row, int slot) { return slot ^ ((row >>
 // three bf16 terms x = hi + mid + lo (8 + 8 + 8 significand bits) kept as three LDS planes, and each product is formed from the
 // six leading cross terms hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid (each exact in the fp32 accumulator; the dropped
 // mid*lo, lo*mid, lo*lo are below 2^-24 relative), i.e. fp32-accurate at 16/6 = 2.7x the fp32 MFMA rate.
-template <bool A_KC, bool B_KC, int BM, int BN, int TERMS>
-__global__ __launch_bounds__(NT) void gemm_bf16_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, const int tiles_n) {
+// CONV = 0: plain operands.  CONV = 1: A is the implicit im2col matrix of a convolution input (rows = output pixels,
+// k = (tap, ci), k-contiguous; needs Cin % 32 == 0 so that a k-tile stays inside one tap) - forward convolutions and, over a
+// flipped filter, stride-1 data gradients.  CONV = 2: B is that im2col matrix with k = pixels and n = (tap, ci) (the weight
+// gradient dW = dY^T . im2col(x); OW and OH*OW powers of two).  In bf16 mode every convolution but the two 7x7 stems and the
+// stride-2 data gradients runs here as a DIRECT convolution: rounding Winograd-domain operands to bf16 amplifies the error
+// (the F(4x4,3x3) transforms have gains up to 100), measured as a gradient cosine of 0.65 against 0.79 for torch's own autocast.
+template <bool A_KC, bool B_KC, int BM, int BN, int TERMS, int CONV = 0>
+__global__ __launch_bounds__(NT) void gemm_bf16_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, const int tiles_n,
+                                                       const int log2_ow = 0, const int log2_ohw = 0) {
   const mmfn_gemm_desc d = batch_view(d_in);
   constexpr int TM = BM / 64, TN = BN / 64;            // 32x32 accumulator tiles per wave (2x2 waves)
   constexpr int UA = BM * 8 / NT, UB = BN * 8 / NT;    // k-contiguous staging units (row, k-quad) per thread
@@ -730,19 +737,62 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(const mmfn_gemm_desc d_in
   f32x4 ra[4], rb[4];
   const float* pa[4];
   const float* pb[4];
+  int ay0[4] = {0, 0, 0, 0}, ax0[4] = {0, 0, 0, 0};   // CONV 1: top-left input pixel of the unit's output pixel
+  int bkh = 0, bkw = 0;                                // CONV 2: tap of the thread's n-quad
+  const float* zero = g_zero_page;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int u = tid + i * NT;
-    if (A_KC) pa[i] = d.A + (size_t)min(m0 + (u >> 3), d.M - 1) * d.lda + (u & 7) * 4;
+    if (CONV == 1) {
+      const int m = min(m0 + (u >> 3), d.M - 1);
+      const int ohw = d.OH * d.OW;
+      const int b = m / ohw, rem = m - b * ohw;
+      const int oh = rem / d.OW, ow = rem - oh * d.OW;
+      ay0[i] = oh * d.stride - d.pad;
+      ax0[i] = ow * d.stride - d.pad;
+      pa[i] = d.A + (size_t)b * d.H * d.W * d.Cin + (u & 7) * 4;
+    } else if (A_KC) pa[i] = d.A + (size_t)min(m0 + (u >> 3), d.M - 1) * d.lda + (u & 7) * 4;
     else pa[i] = d.A + (size_t)(((tid / AQ) & 7) * 4 + i) * d.lda + min(m0 + (tid % AQ) * 4, d.M - 4);
-    if (B_KC) pb[i] = d.B + (size_t)min(n0 + (u >> 3), d.N - 1) * d.ldb + (u & 7) * 4;
+    if (CONV == 2) {
+      const int n = min(n0 + (tid % BQ) * 4, d.N - 4);
+      const int khw = n / d.Cin;
+      bkh = khw / d.KW;
+      bkw = khw - bkh * d.KW;
+      pb[i] = d.B + (n - khw * d.Cin);
+    } else if (B_KC) pb[i] = d.B + (size_t)min(n0 + (u >> 3), d.N - 1) * d.ldb + (u & 7) * 4;
     else pb[i] = d.B + (size_t)(((tid / BQ) & 7) * 4 + i) * d.ldb + min(n0 + (tid % BQ) * 4, d.N - 4);
   }
   auto load = [&](int kt) {
+    int t_kh = 0, t_kw = 0, t_c0 = 0;
+    if (CONV == 1) {   // wave-uniform tap of this k-tile
+      const int k0 = kt * HBK, tap = k0 / d.Cin;
+      t_c0 = k0 - tap * d.Cin;
+      t_kh = tap / d.KW;
+      t_kw = tap - t_kh * d.KW;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (A_KC ? i < UA : a_on) ra[i] = ld4(pa[i] + (A_KC ? (size_t)kt * HBK : (size_t)kt * HBK * d.lda));
-      if (B_KC ? i < UB : b_on) rb[i] = ld4(pb[i] + (B_KC ? (size_t)kt * HBK : (size_t)kt * HBK * d.ldb));
+      if (A_KC ? i < UA : a_on) {
+        if (CONV == 1) {
+          const int ih = ay0[i] + t_kh, iw = ax0[i] + t_kw;
+          const bool ok = (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+          ra[i] = ld4(ok ? pa[i] + ((size_t)ih * d.W + iw) * d.Cin + t_c0 : zero);
+        } else {
+          ra[i] = ld4(pa[i] + (A_KC ? (size_t)kt * HBK : (size_t)kt * HBK * d.lda));
+        }
+      }
+      if (B_KC ? i < UB : b_on) {
+        if (CONV == 2) {
+          const int kk = kt * HBK + ((tid / BQ) & 7) * 4 + i;   // pixel index of this k row
+          const int b = kk >> log2_ohw, rem = kk & ((1 << log2_ohw) - 1);
+          const int oh = rem >> log2_ow, ow = rem & ((1 << log2_ow) - 1);
+          const int ih = oh * d.stride - d.pad + bkh, iw = ow * d.stride - d.pad + bkw;
+          const bool ok = (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+          rb[i] = ld4(ok ? pb[i] + ((size_t)(b * d.H + ih) * d.W + iw) * d.Cin : zero);
+        } else {
+          rb[i] = ld4(pb[i] + (B_KC ? (size_t)kt * HBK : (size_t)kt * HBK * d.ldb));
+        }
+      }
     }
   };
   auto put = [&](__bf16* base, int off, const float* x) {  // 4 consecutive k of one row -> 1 or 3 bf16x4 planes
@@ -1054,8 +1104,20 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
   return 0;
 }
 
+int bf16_conv_form(const mmfn_gemm_desc& d) {   // 1: im2col A (fwd / flipped dgrad), 2: im2col B (wgrad), 0: not a covered convolution
+  if (d.flags & MMFN_EPI_BF16X3) return 0;
+  if (d.a_mode == MMFN_A_IM2COL && d.b_mode == MMFN_B_NK && d.Cin % HBK == 0 && d.K % HBK == 0 && !(d.ldb & 3) && d.batch <= 1)
+    return 1;
+  if (d.a_mode == MMFN_A_COLMAJOR && d.b_mode == MMFN_B_IM2COL && d.Cin % 4 == 0 && d.K % HBK == 0 && !(d.lda & 3) && !(d.M & 3) &&
+      d.M >= 4 && !(d.N & 3) && d.N >= 4 && d.batch <= 1 && ilog2_exact(d.OW) >= 0 && ilog2_exact(d.OH * d.OW) >= 0)
+    return 2;
+  return 0;
+}
+
 bool bf16_ok(const mmfn_gemm_desc& d) {
   if (!(d.flags & (MMFN_EPI_BF16_OPERANDS | MMFN_EPI_BF16X3))) return false;
+  if ((((uintptr_t)d.A) | ((uintptr_t)d.B)) & 15) return false;
+  if (bf16_conv_form(d)) return true;
   const bool a_kc = d.a_mode == MMFN_A_ROWMAJOR, a_mc = d.a_mode == MMFN_A_COLMAJOR;
   const bool b_kc = d.b_mode == MMFN_B_NK, b_mc = d.b_mode == MMFN_B_KN;
   if (!(a_kc || a_mc) || !(b_kc || b_mc)) return false;
@@ -1094,6 +1156,23 @@ int launch_bf16(const mmfn_gemm_desc& d, hipStream_t s) {
   dd.splitk = zdim;
   const int tn = ceil_div(d.N, bt);
   dim3 grid(ceil_div(d.M, bt) * tn, zdim, d.batch > 1 ? d.batch : 1);
+  const int conv = bf16_conv_form(d);
+  if (conv) {
+    const int l_ow = conv == 2 ? ilog2_exact(d.OW) : 0, l_ohw = conv == 2 ? ilog2_exact(d.OH * d.OW) : 0;
+    if (conv == 1) {
+      if (bt == 128) hipLaunchKernelGGL((gemm_bf16_kernel<true, true, 128, 128, 1, 1>), grid, dim3(NT), 0, s, dd, kps, tn, 0, 0);
+      else hipLaunchKernelGGL((gemm_bf16_kernel<true, true, 64, 64, 1, 1>), grid, dim3(NT), 0, s, dd, kps, tn, 0, 0);
+    } else {
+      if (bt == 128) hipLaunchKernelGGL((gemm_bf16_kernel<false, false, 128, 128, 1, 2>), grid, dim3(NT), 0, s, dd, kps, tn, l_ow, l_ohw);
+      else hipLaunchKernelGGL((gemm_bf16_kernel<false, false, 64, 64, 1, 2>), grid, dim3(NT), 0, s, dd, kps, tn, l_ow, l_ohw);
+    }
+    MMFN_LAUNCH_CHECK();
+    if (zdim > 1) {
+      launch_splitk_reduce(dd, s);
+      MMFN_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   const bool a_kc = d.a_mode == MMFN_A_ROWMAJOR, b_kc = d.b_mode == MMFN_B_NK;
   const bool x3 = (d.flags & MMFN_EPI_BF16X3) != 0;
 #define MMFN_LAUNCH_BF16(AK, BK_, T)                                                                                \

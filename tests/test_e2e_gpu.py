@@ -303,11 +303,11 @@ def test_driving_session_equals_reference_pipeline(golden_dir):
 
 
 def test_bf16_operand_mode_tracks_the_fp32_path():
-    """GlobalConfig(gemm_dtype="bf16"): the Linear / Winograd GEMMs round their operands to bf16 (fp32 accumulation,
-    activations, master weights).  Not a parity mode - the check is that waypoints and loss stay within bf16's rounding
-    of the fp32 path and that the backward runs.  (Gradients are not compared here: this network's backward amplifies a
-    1e-6 rounding difference ~100x, see test_train_step_matches_oracle, so bf16's 2e-3 shows up as noise: cosine 0.99 on the
-    deepest stage, 0.65 on the shallow ones at batch 32)"""
+    """GlobalConfig(gemm_dtype="bf16"): Linear GEMMs and direct convolutions take bf16 MFMA operands (fp32 accumulation,
+    activations, master weights).  Batch-2 smoke check with the closed-form test weights: waypoints and loss stay within
+    bf16's rounding of the fp32 path and the backward runs.  The gradient criterion (per-stage cosine against torch's own
+    autocast as the yardstick, reference-style init, batch 8 and 32) is tests/test_parity_benchsize_gpu.py::
+    test_bf16_mode_tracks_fp32_at_least_as_well_as_torch_autocast."""
     from mmfn_amd.config import GlobalConfig
     from mmfn_amd import model as M
     from oracle import harness

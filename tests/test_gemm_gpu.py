@@ -210,6 +210,47 @@ def test_bf16_operand_gemm_forms(shape):
     assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("cfg", [(2, 32, 64, 64, 3, 1), (2, 32, 64, 128, 3, 2), (3, 16, 128, 128, 3, 1), (2, 16, 256, 512, 1, 2),
+                                 (2, 8, 512, 512, 3, 1)])
+def test_bf16_direct_convolution_forms(cfg):
+    """bf16 mode runs the convolutions as DIRECT implicit GEMMs on the bf16 MFMA pipe (no Winograd domain rounding): forward,
+    stride-1 data gradient (flipped filter) and weight gradient equal torch's convolution of the bf16-rounded operands
+    accumulated in fp32; the stride-2 data gradient stays on the fp32 kernel and equals the fp32 result."""
+    from mmfn_amd import ops
+    dev = _dev()
+    B, H, Cin, Cout, k, st = cfg
+    p = k // 2
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    rnd = lambda t: t.bfloat16().float()
+    xr, wr = rnd(x).requires_grad_(True), rnd(w).requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, stride=st, padding=p)
+    dy = torch.randn(y_ref.shape, generator=g)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    w_ohwi = w.permute(0, 2, 3, 1).contiguous().to(dev)
+    dy_nhwc = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+
+    def close(got, ref, tol=3e-5):
+        err = (got.cpu() - ref).abs().max().item()
+        assert err <= tol * max(1.0, ref.abs().max().item()), err
+
+    with ops.precision("bf16"):
+        assert not ops.winograd_ok(x_nhwc.shape, w_ohwi.shape, st, p, {})
+        y = ops.conv2d_fwd(x_nhwc, w_ohwi, st, p)
+        close(y.permute(0, 3, 1, 2), y_ref.detach())
+        # gradients: the operands of each product are rounded, i.e. dw = conv(round(x), round(dy)), dx = conv(round(dy), round(w))
+        dw = ops.conv2d_wgrad(dy_nhwc, x_nhwc, tuple(w_ohwi.shape), st, p)
+        dw_ref = torch.nn.grad.conv2d_weight(rnd(x), w.shape, rnd(dy), stride=st, padding=p)
+        close(dw.permute(0, 3, 1, 2), dw_ref)
+        dx = ops.conv2d_dgrad(dy_nhwc, w_ohwi, tuple(x_nhwc.shape), st, p)
+        if st == 1:
+            dx_ref = torch.nn.grad.conv2d_input(x.shape, rnd(w), rnd(dy), stride=st, padding=p)
+        else:   # stride-2 data gradient: fp32 kernel, unrounded operands
+            dx_ref = torch.nn.grad.conv2d_input(x.shape, w, dy, stride=st, padding=p)
+        close(dx.permute(0, 3, 1, 2), dx_ref, 1e-4)
+
+
 def test_bf16_operand_batched_gemm():
     from mmfn_amd import ops
     dev = _dev()
