@@ -106,7 +106,8 @@ class ConvBN(object):
         _, oshape = ops.conv_geom(x.shape, self.w.shape, self.stride, self.pad)
         co = ctx.bufs.get(self.name + ".conv", oshape)
         keep_v = keep_u = None
-        if ctx.training and ops.winograd_wgrad_ok(x.shape, self.w.shape, self.stride, self.pad):
+        if ctx.training and ops.winograd_ok(x.shape, self.w.shape, self.stride, self.pad, {}) and \
+                ops.winograd_wgrad_ok(x.shape, self.w.shape, self.stride, self.pad):
             # the transformed input of the Winograd path is what the weight gradient needs again: keep it per layer
             keep_v = ctx.bufs.get(self.name + ".winoV", (ops.winograd_v_numel(x.shape),))
             if ops.winograd_adjoint_ok(x.shape, self.w.shape, self.stride, self.pad):

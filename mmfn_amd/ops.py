@@ -21,6 +21,11 @@ _lane = 0  # logical execution lane (0 = main stream, 1.. = engine side streams)
 
 
 _gemm_dtype = "f32"
+# bf16 mode keeps the convolution WEIGHT gradients in fp32: measured on MI355X the bf16 kernel's pixel-contracted form (both
+# operands pixel-major, transposed into k-contiguous LDS rows in registers) runs at 28-138 TF/s, slower than the fp32 Winograd-
+# domain weight gradient (and than the fp32 direct one at 64 channels), and fp32 weight gradients are the more accurate anyway.
+# MMFN_BF16_WGRAD=1 selects the bf16 kernel (kept for its tests and for a transpose-read rewrite).
+BF16_WGRAD = os.environ.get("MMFN_BF16_WGRAD", "0") == "1"
 
 
 class precision(object):
@@ -280,7 +285,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=N
         flags |= EPI_ACCUM
     # bf16 mode: plain GEMMs and - as DIRECT convolutions - the im2col forward / flipped data gradient and the weight gradient
     # (the library falls back to the fp32 kernel for what the bf16 kernel does not cover: 7x7 stems, stride-2 data gradients)
-    bf16 = _gemm_dtype != "f32" and (conv is None or (_gemm_dtype == "bf16" and (a_mode, b_mode) in ((A_IM2COL, B_NK), (A_COLMAJOR, B_IM2COL))))
+    bf16 = _gemm_dtype != "f32" and (conv is None or (_gemm_dtype == "bf16" and (
+        (a_mode, b_mode) == (A_IM2COL, B_NK) or (BF16_WGRAD and (a_mode, b_mode) == (A_COLMAJOR, B_IM2COL)))))
     if bf16:
         flags |= EPI_BF16X3 if _gemm_dtype == "f32x3" else EPI_BF16_OPERANDS
     d.flags = flags
@@ -386,10 +392,10 @@ def _wino_scratch(n, device):
     return buf
 
 
-def winograd_ok(x_shape, w_shape, stride, pad, epi):
+def winograd_ok(x_shape, w_shape, stride, pad, epi, for_wgrad=False):
     Co, KH, KW, Ci = w_shape
     B, H, W, _ = x_shape
-    if _gemm_dtype == "bf16":
+    if _gemm_dtype == "bf16" and not for_wgrad:
         # bf16 mode runs every 3x3 convolution as a direct implicit GEMM on the bf16 MFMA pipe: rounding Winograd-domain
         # operands to bf16 amplifies the error (transform gains up to ~100), and at 16x the fp32 MFMA rate the 4x FLOP saving
         # no longer pays for the 2.25x larger transformed tensors
@@ -534,7 +540,9 @@ WINOGRAD_WGRAD = os.environ.get("MMFN_WINOGRAD_WGRAD", "1") == "1"
 
 
 def winograd_wgrad_ok(x_shape, w_shape, stride, pad):
-    return (WINOGRAD_WGRAD and WINOGRAD_F4 and winograd_ok(x_shape, w_shape, stride, pad, {})
+    # also in bf16 mode (where the forward is a direct convolution): the weight gradient then runs in the Winograd domain in
+    # fp32, transforming x itself
+    return (WINOGRAD_WGRAD and WINOGRAD_F4 and winograd_ok(x_shape, w_shape, stride, pad, {}, for_wgrad=True)
             and x_shape[1] % 4 == 0 and x_shape[2] % 4 == 0)
 
 
@@ -550,8 +558,8 @@ def conv2d_wgrad_winograd(dy, x, out, v=None):
     dMt = buf[36 * (Co * Ci + T * Ci):36 * (Co * Ci + T * Ci + T * Co)]
     st = stream()
     with _whole_op("wgrad %dx%d c%d->%d k3 s1 (winograd F4)" % (H, W, Ci, Co), 2.0 * B * H * W * Co * 9 * Ci,
-                   4.0 * (B * H * W * (Ci + Co) + 9 * Co * Ci), 2.0 * 36 * T * Co * Ci):
-        _wgrad_winograd_body(dy, x, out, v, B, H, W, Ci, Co, T, dU, V, dMt, st)
+                   4.0 * (B * H * W * (Ci + Co) + 9 * Co * Ci), 2.0 * 36 * T * Co * Ci), precision("f32"):
+        _wgrad_winograd_body(dy, x, out, v, B, H, W, Ci, Co, T, dU, V, dMt, st)   # never rounded in the Winograd domain
     return out
 
 

@@ -239,10 +239,20 @@ def test_bf16_direct_convolution_forms(cfg):
         assert not ops.winograd_ok(x_nhwc.shape, w_ohwi.shape, st, p, {})
         y = ops.conv2d_fwd(x_nhwc, w_ohwi, st, p)
         close(y.permute(0, 3, 1, 2), y_ref.detach())
-        # gradients: the operands of each product are rounded, i.e. dw = conv(round(x), round(dy)), dx = conv(round(dy), round(w))
+        # weight gradient: kept in fp32 in bf16 mode (Winograd domain where that applies) - equals the unrounded result
         dw = ops.conv2d_wgrad(dy_nhwc, x_nhwc, tuple(w_ohwi.shape), st, p)
-        dw_ref = torch.nn.grad.conv2d_weight(rnd(x), w.shape, rnd(dy), stride=st, padding=p)
-        close(dw.permute(0, 3, 1, 2), dw_ref)
+        close(dw.permute(0, 3, 1, 2), torch.nn.grad.conv2d_weight(x, w.shape, dy, stride=st, padding=p), 1e-4)
+        # ... the bf16 kernel's own weight-gradient form (MMFN_BF16_WGRAD=1): dw = conv(round(x), round(dy))
+        ops.BF16_WGRAD = True
+        try:
+            g_, _ = ops.conv_geom(x_nhwc.shape, w_ohwi.shape, st, p)
+            dw16 = torch.empty_like(w_ohwi)
+            ops.gemm(dy_nhwc, x_nhwc, dw16, Cout, k * k * Cin, dy_nhwc.numel() // Cout, Cout, 0, k * k * Cin, ops.A_COLMAJOR,
+                     ops.B_IM2COL, conv=g_)
+        finally:
+            ops.BF16_WGRAD = False
+        close(dw16.permute(0, 3, 1, 2), torch.nn.grad.conv2d_weight(rnd(x), w.shape, rnd(dy), stride=st, padding=p))
+        # data gradient: dx = conv(round(dy), round(w)) over the flipped filter
         dx = ops.conv2d_dgrad(dy_nhwc, w_ohwi, tuple(x_nhwc.shape), st, p)
         if st == 1:
             dx_ref = torch.nn.grad.conv2d_input(x.shape, rnd(w), rnd(dy), stride=st, padding=p)
