@@ -57,7 +57,7 @@ int mmfn_wino_output_stats_f32(const float* Mt, float* y, double* partials, int*
 int mmfn_wino_outgrad_f32(const float* dy, float* dMt, int B, int H, int W, int C, void* stream);
 /* Data gradient of the same convolution as the ADJOINT of its forward Winograd pipeline: dV [36][tiles][Ci] (= dM . U, one
  * 36-batch GEMM over the forward's own transformed filter) -> dx = overlap-add of B dV B^T over the tiles' 6x6 input patches
- * (+ res).  H = W in {8, 16, 32}; replaces cuDNN's backward-data for the BasicBlock 3x3 convolutions (model_vec.py:539-593). */
+ * (+ res).  H, W multiples of 4; replaces cuDNN's backward-data for the BasicBlock 3x3 convolutions (model_vec.py:539-593). */
 int mmfn_wino_input_adjoint_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, void* stream);
 int mmfn_wino_wgrad_out_f32(const float* dU, float* dw, int Co, int Ci, void* stream);
 /* y = a*x + b*y (b == 0 ignores the old y) */

@@ -325,10 +325,9 @@ __global__ __launch_bounds__(NT) void wino4_outgrad_kernel(const float* __restri
 // ---- data gradient in the F(4x4,3x3) domain: the ADJOINT of the forward pipeline instead of a second convolution with
 // the flipped filter.  With dM = A dY A^T (wino4_outgrad_kernel - the weight gradient needs it anyway) and the forward's
 // own U = G w G^T:   dV[t] = dM[t] . U[t]   ([tiles x Co] x [Co x Ci], one 36-batch GEMM),   dx = sum over tiles of
-// B dV_tile B^T scattered back onto the tile's 6x6 input patch.  Saves, per convolution, the filter flip, the second
-// filter transform and the input transform of dY.  Patches of neighbouring tiles overlap by two pixels, so the scatter is
-// an overlap-ADD: a block owns one image x one channel chunk, keeps that image chunk in LDS and adds the patches in four
-// phases by tile parity (tiles of equal parity are 8 pixels apart: disjoint 6x6 patches) - no atomics, fixed order.
+// B dV_tile B^T put back onto the tile's 6x6 input patch.  Saves, per convolution, the filter flip, the second filter
+// transform and the input transform of dY.  Patches of neighbouring tiles overlap by two pixels, so this is an overlap-ADD,
+// done as a gather (below): no atomics, fixed order.
 template <typename T>
 __device__ __forceinline__ void f4_b(const T* v, T* o) {  // o = B v, 6 -> 6 (B = transpose of the B^T in f4_bt)
   o[0] = 4.f * v[0];
@@ -339,64 +338,85 @@ __device__ __forceinline__ void f4_b(const T* v, T* o) {  // o = B v, 6 -> 6 (B 
   o[5] = v[5];
 }
 
-// NTHR threads = (tiles of the image) x (qpb channel quads); LDSF = H * W * 4 * qpb floats.  The launcher picks the block
-// size per image size so that every shape gets >= 256 blocks (32x32: 256 threads / 4 quads, 16x16: 128 / 8, 8x8: 64 / 16).
-template <int NTHR, int LDSF>
-__global__ __launch_bounds__(NTHR) void wino4_input_adjoint_kernel(const float* __restrict__ dV, const float* __restrict__ res,
-                                                                   float* __restrict__ dx, int H, int W, int C, int qpb) {
-  constexpr int NT = NTHR;   // shadows the file-level block size inside this kernel
-  __shared__ __attribute__((aligned(16))) float img[LDSF];
-  const int th = H >> 2, tw = W >> 2, nt = th * tw;
-  const int b = blockIdx.x;
-  const int quad = threadIdx.x % qpb, tile = threadIdx.x / qpb;   // tile < nt by construction (NT == nt * qpb)
-  const int ti = tile / tw, tj = tile % tw;
-  const int cch = qpb * 4;                                         // channels of this block's chunk
-  const int c4 = (blockIdx.y * qpb + quad) * 4;
-  const int64_t Tall = (int64_t)gridDim.x * nt;
-  const int64_t gt = (int64_t)b * nt + tile;
-  for (int i = threadIdx.x; i < H * W * cch / 4; i += NT) reinterpret_cast<f32x4*>(img)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 t[6][6];  // B dV, built column by column so only one 6-vector of raw values is live
+// Gather form, no LDS and no phases.  A thread owns one 4x4 output block (= the interior of its own tile's 6x6 patch) and adds
+// what the eight neighbouring tiles' patches put on it.  Because rows 0 and 5 of B are 4*e0 and e5 (f4_b: o[0] = 4 v[0],
+// o[5] = v[5]), a neighbour's halo row / column needs only ONE row / column of its dV: 36 + 4*6 + 4 = 64 loads per thread
+// instead of 9*36, every addition in a fixed order.
+__global__ __launch_bounds__(NT) void wino4_input_adjoint_kernel(const float* __restrict__ dV, const float* __restrict__ res,
+                                                                 float* __restrict__ dx, int B, int H, int W, int C) {
+  const int cq = C >> 2, th = H >> 2, tw = W >> 2;
+  const int64_t T = (int64_t)B * th * tw, n = T * cq;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % cq) * 4;
+    const int64_t tile = idx / cq;
+    const int tj = (int)(tile % tw), ti = (int)((tile / tw) % th), b = (int)(tile / ((int64_t)tw * th));
+    auto at = [&](int64_t tl, int a, int e) { return *reinterpret_cast<const f32x4*>(dV + ((size_t)(a * 6 + e) * T + tl) * C + c4); };
+    f32x4 t[4][6];  // rows 1..4 of B dV, built column by column
 #pragma unroll
-  for (int e = 0; e < 6; ++e) {
-    f32x4 v[6], o[6];
+    for (int e = 0; e < 6; ++e) {
+      f32x4 v[6], o[6];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) v[a] = *reinterpret_cast<const f32x4*>(dV + ((size_t)(a * 6 + e) * Tall + gt) * C + c4);
-    f4_b(v, o);
+      for (int a = 0; a < 6; ++a) v[a] = at(tile, a, e);
+      f4_b(v, o);
 #pragma unroll
-    for (int a = 0; a < 6; ++a) t[a][e] = o[a];
-  }
-  __syncthreads();
-  for (int ph = 0; ph < 4; ++ph) {
-    if (((ti & 1) * 2 + (tj & 1)) == ph) {
+      for (int a = 0; a < 4; ++a) t[a][e] = o[a + 1];
+    }
+    f32x4 P[4][4];  // interior of B dV B^T
 #pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        const int y = 4 * ti - 1 + a;
-        f32x4 o[6];
-        f4_b(t[a], o);
-        if ((unsigned)y < (unsigned)H) {
+    for (int a = 0; a < 4; ++a) {
+      f32x4 o[6];
+      f4_b(t[a], o);
 #pragma unroll
-          for (int e = 0; e < 6; ++e) {
-            const int x = 4 * tj - 1 + e;
-            if ((unsigned)x < (unsigned)W) {   // positions outside the image are the zero padding: their gradient is dropped
-              f32x4* p = reinterpret_cast<f32x4*>(img + ((size_t)y * W + x) * cch + quad * 4);
-              *p = *p + o[e];
-            }
-          }
-        }
+      for (int e = 0; e < 4; ++e) P[a][e] = o[e + 1];
+    }
+    const bool up = ti > 0, down = ti < th - 1, left = tj > 0, right = tj < tw - 1;
+    if (up) {      // tile above: its patch row 5 lies on our first row
+      f32x4 v[6], o[6];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) v[e] = at(tile - tw, 5, e);
+      f4_b(v, o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) P[0][e] += o[e + 1];
+    }
+    if (down) {    // tile below: its patch row 0 (= 4 * dV row 0) lies on our last row
+      f32x4 v[6], o[6];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) v[e] = at(tile + tw, 0, e);
+      f4_b(v, o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) P[3][e] += 4.f * o[e + 1];
+    }
+    if (left) {
+      f32x4 v[6], o[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) v[a] = at(tile - 1, a, 5);
+      f4_b(v, o);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) P[a][0] += o[a + 1];
+    }
+    if (right) {
+      f32x4 v[6], o[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) v[a] = at(tile + 1, a, 0);
+      f4_b(v, o);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) P[a][3] += 4.f * o[a + 1];
+    }
+    if (up && left) P[0][0] += at(tile - tw - 1, 5, 5);
+    if (up && right) P[0][3] += 4.f * at(tile - tw + 1, 5, 0);
+    if (down && left) P[3][0] += 4.f * at(tile + tw - 1, 0, 5);
+    if (down && right) P[3][3] += 16.f * at(tile + tw + 1, 0, 0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const size_t off = (((size_t)b * H + 4 * ti + a) * W + 4 * tj) * C + c4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f32x4 v = P[a][e];
+        if (res) v += *reinterpret_cast<const f32x4*>(res + off + (size_t)e * C);
+        *reinterpret_cast<f32x4*>(dx + off + (size_t)e * C) = v;
       }
     }
-    __syncthreads();
   }
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int y = 4 * ti + p, x = 4 * tj + q;
-      f32x4 v = *reinterpret_cast<const f32x4*>(img + ((size_t)y * W + x) * cch + quad * 4);
-      const size_t off = (((size_t)b * H + y) * W + x) * C + c4;
-      if (res) v += *reinterpret_cast<const f32x4*>(res + off);
-      *reinterpret_cast<f32x4*>(dx + off) = v;
-    }
 }
 
 // dw[co][3][3][ci] = G^T dU[:, co, ci] G;  dU is [36][Co][Ci]
@@ -541,20 +561,8 @@ extern "C" int mmfn_wino_outgrad_f32(const float* dy, float* dMt, int B, int H, 
 
 extern "C" int mmfn_wino_input_adjoint_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, void* stream) {
   if (!dV || !dx || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
-  if (H != W) return MMFN_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  if (H == 32) {          // 64 tiles x 4 quads
-    if ((C / 4) % 4) return MMFN_EINVAL;
-    hipLaunchKernelGGL((wino4_input_adjoint_kernel<256, 32 * 32 * 16>), dim3(B, C / 16), dim3(256), 0, s, dV, res, dx, H, W, C, 4);
-  } else if (H == 16) {   // 16 tiles x 8 quads
-    if ((C / 4) % 8) return MMFN_EINVAL;
-    hipLaunchKernelGGL((wino4_input_adjoint_kernel<128, 16 * 16 * 32>), dim3(B, C / 32), dim3(128), 0, s, dV, res, dx, H, W, C, 8);
-  } else if (H == 8) {    // 4 tiles x 16 quads
-    if ((C / 4) % 16) return MMFN_EINVAL;
-    hipLaunchKernelGGL((wino4_input_adjoint_kernel<64, 8 * 8 * 64>), dim3(B, C / 64), dim3(64), 0, s, dV, res, dx, H, W, C, 16);
-  } else {
-    return MMFN_EINVAL;
-  }
+  hipLaunchKernelGGL(wino4_input_adjoint_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0,
+                     (hipStream_t)stream, dV, res, dx, B, H, W, C);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

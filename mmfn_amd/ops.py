@@ -578,10 +578,8 @@ WINOGRAD_ADJOINT_DGRAD = os.environ.get("MMFN_WINOGRAD_ADJOINT", "1") == "1"
 
 
 def winograd_adjoint_ok(x_shape, w_shape, stride, pad):
-    """Shapes the adjoint data-gradient transform covers (square 8 / 16 / 32-pixel images, see mmfn_wino_input_adjoint_f32)."""
-    B, H, W, Ci = x_shape
-    return (WINOGRAD_ADJOINT_DGRAD and winograd_wgrad_ok(x_shape, w_shape, stride, pad) and H == W and H in (8, 16, 32)
-            and Ci % {32: 16, 16: 32, 8: 64}[H] == 0)
+    """The adjoint data gradient covers whatever the F(4x4,3x3) weight gradient covers (image sides multiples of 4)."""
+    return WINOGRAD_ADJOINT_DGRAD and winograd_wgrad_ok(x_shape, w_shape, stride, pad)
 
 
 def conv2d_bwd_winograd(dy, x, u, dw_out, dx_out, v=None, res=None):
