@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (AMD's 5 PF headline includes 2:1 sparsity)
 ALGO_GFLOP_PER_SAMPLE = {"vec": 106.6, "img": 112.4, "rad": 117.7, "image-only": 28.4}
 
 
@@ -277,19 +278,19 @@ def main():
     torch.cuda.synchronize()
     runner = step
     graph = None
-    if not args.no_graph and world == 1:
+    if not args.no_graph and image_only:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             loss_buf = step()
         runner = graph.replay
     elif not args.no_graph:
-        # multi-GPU: five graphs cut at the gradient-bucket boundaries, RCCL all-reduces in between
+        # linear hipGraphs per branch lane (and, multi-GPU, per gradient bucket with the RCCL all-reduces in between)
         from mmfn_amd.parallel import GraphedStep
         try:
             graph = GraphedStep(eng, dp, inp, gt, lr=1e-4, warm=0)
             runner = graph
         except Exception as exc:  # keep the run alive: eager launches give the same numbers' meaning, only slower
-            sys.stderr.write("rank %d: segmented hipGraph capture failed (%s: %s); falling back to eager launches\n"
+            sys.stderr.write("rank %d: hipGraph capture failed (%s: %s); falling back to eager launches\n"
                              % (rank, type(exc).__name__, exc))
             graph = None
             torch.cuda.synchronize()
@@ -392,8 +393,23 @@ def main():
             "whole_step_algorithmic_tflops": round(ALGO_GFLOP_PER_SAMPLE.get("image-only" if image_only else args.variant, 0) * B / ms_per_step, 2),
         }
         if args.dtype != "f32":
-            result["roofline"]["note"] = ("bf16 mode: the GEMMs with bf16 MFMA operands are priced against the fp32 MFMA peak here "
-                                          "for comparability with the f32 run; their own dense peak is 2.5 PFLOP/s")
+            # bf16 mode: the dominant kernel is the bf16-operand GEMM; price ITS launches against the dense bf16 MFMA peak.
+            # What stays on the fp32 instruction (conv weight gradients in the Winograd domain, 7x7 stems, stride-2 data
+            # gradients) is reported next to it against the fp32 peak.
+            nb, fb, msb = prof.subset("bf16 ")
+            r = result["roofline"]
+            r["all_gemm_launches_vs_fp32_peak"] = {"achieved": r["achieved"], "peak": PEAK_FP32_MFMA_TFLOPS, "frac": r["frac"],
+                                                   "launches_per_step": r["launches_per_step"], "kernel_ms_per_step": r["kernel_ms_per_step"]}
+            ach = fb / (msb * 1e-3) / 1e12 if msb > 0 else 0.0
+            r.update({"achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
+                      "kernel": "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16; fp32 operands in HBM rounded to bf16 on the way into LDS, "
+                                "fp32 accumulate): Linear GEMMs and direct 3x3 convolutions fwd / data gradient",
+                      "launches_per_step": nb // steps_p, "kernel_ms_per_step": round(msb / steps_p, 3),
+                      "algorithmic_gflop_per_step": round(fb / steps_p / 1e9, 1), "traffic": None, "traffic_source": None,
+                      "note": "operands are read as fp32 from HBM (4 B/element), so these GEMMs are HBM/LDS-bound long before the "
+                              "2.5 PFLOP/s bf16 MFMA peak; see DESIGN.md section 7"})
+            for k in ("executed_gflop_per_step", "executed_tflops", "algorithmic_bytes_per_launch"):
+                r.pop(k, None)
         if not image_only and args.dtype == "f32" and not args.no_oracle_check:
             result["loss_vs_oracle"] = loss_vs_oracle(net, eng, inp, gt, args.variant)
         if not args.no_cpu_baseline and not image_only and args.variant == "vec":

@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmmfn_hip.so")
+LIB_PATH = os.environ.get("MMFN_HIP_LIB") or os.path.join(_HERE, "lib", "libmmfn_hip.so")   # MMFN_HIP_LIB: an experimental build
 
 # operand modes / epilogue flags (mirror include/mmfn_hip.h)
 A_ROWMAJOR, A_COLMAJOR, A_IM2COL, A_DGRAD = 0, 1, 2, 3

@@ -757,6 +757,7 @@ class Engine(object):
         # gaps; captured into the hipGraph this becomes a fork/join DAG.
         self.side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         self.multi_stream = True
+        self._recorder = None   # mmfn_amd.graphs.Recorder while a lane-graph capture is running
         # "f32" (parity path) or "bf16": bf16 MFMA operands with fp32 accumulation for the Linear / Winograd GEMMs
         self.gemm_dtype = getattr(cfg, "gemm_dtype", "f32")
         self.wino_layers = {}     # ConvBN name -> (filter storage, transformed-filter buffer): filled by the first training forward
@@ -807,6 +808,12 @@ class Engine(object):
         """Run fns[0] on the current stream and fns[1:] on the side streams, fork/join with events."""
         if not self.multi_stream:
             return [f() for f in fns]
+        rec = self._recorder
+        if rec is not None and rec.split_lanes:
+            # lane graphs (mmfn_amd.graphs): every lane becomes its own linear hipGraph, stitched with eager events
+            if self.n_lanes == 2:
+                return rec.branches([[fns[0]], (self.side[0], list(fns[1:]))])
+            return rec.branches([[fns[0]]] + [(self.side[i], [f]) for i, f in enumerate(fns[1:])])
         main = torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)

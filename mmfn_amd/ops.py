@@ -92,6 +92,13 @@ class GemmProfiler(object):
             out[tag] = (n + 1, fl + f, ms + s.elapsed_time(e))
         return out
 
+    def subset(self, prefix):
+        """(launches, algorithmic flops, ms) of the records whose tag starts with `prefix` ("bf16 ": the launches that ran on
+        the bf16-operand kernel)."""
+        torch.cuda.synchronize()
+        rows = [r for r in self.records if r[3].startswith(prefix)]
+        return len(rows), float(sum(r[2] for r in rows)), sum(r[0].elapsed_time(r[1]) for r in rows)
+
 
 class _whole_op(object):
     """Profiler bracket around a multi-kernel operation (Winograd convolution): one record with the operation's
@@ -332,7 +339,7 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=N
     e0.record()
     check(L.mmfn_gemm_f32(ctypes.byref(d), stream()), "mmfn_gemm_f32")
     e1.record()
-    _profiler.records.append((e0, e1, flops, tag, abytes, flops))
+    _profiler.records.append((e0, e1, flops, ("bf16 " if bf16 else "") + tag, abytes, flops))
     return C
 
 

@@ -106,17 +106,20 @@ class DataParallel(object):
 
 
 class GraphedStep(object):
-    """One data-parallel training step as five hipGraphs with the RCCL bucket reductions in between.
+    """One training step as a replayable sequence of linear hipGraphs (mmfn_amd.graphs.Recorder).
 
-    A single graph cannot contain the collectives (they run on RCCL's own stream through torch.distributed),
-    and an eager step is ~1900 Python-issued launches, which makes the host the bottleneck once eight ranks
-    share the node's cores.  So the step is cut at the backward-stage boundaries:
-        g0 = RNG advance + forward + loss + head backward + backward of fusion scale 4   -> all-reduce bucket 0
-        g1 = backward of scale 3 -> bucket 1;  g2 = scale 2 -> bucket 2;  g3 = scale 1 + stems -> bucket 3
-        g4 = fused AdamW (after every reduction has been waited on)
-    Each replay is one host call; the reductions still overlap the later backward graphs."""
+    The step is cut (a) wherever the engine forks into its branch lanes - every lane is its own linear graph on its own
+    stream, stitched with eager events, because a multi-stream DAG captured into ONE hipGraph is replayed with coarse
+    cross-queue dependencies that serialise the lanes (graphs.py) - and (b), under data parallelism, at the backward-stage
+    boundaries, where the gradient-bucket all-reduces are issued (through torch.distributed they cannot be captured):
+        RNG advance + forward + loss + head backward + backward of fusion scale 4   -> all-reduce bucket 0
+        backward of scale 3 -> bucket 1;  scale 2 -> bucket 2;  scale 1 + stems -> bucket 3
+        fused AdamW (after every reduction has been waited on)
+    An eager step is ~2200 Python-issued launches, which makes the host the bottleneck; a replay is ~35 host calls and the
+    reductions still overlap the later backward graphs."""
 
     def __init__(self, engine, dp, inp, gt, lr=1e-4, warm=2, **adam):
+        from .graphs import Recorder
         self.engine, self.dp = engine, dp
         eng = engine
         for _ in range(warm):  # size every buffer / scratch lane eagerly before capture
@@ -125,24 +128,22 @@ class GraphedStep(object):
         scale = 1.0 / (dp.world if dp is not None else 1)
         self.scale = scale
         eng.set_hyper(eng.hyper_rows(lr=lr, grad_scale=scale, **adam))  # the captured AdamW reads them from device memory
+        rec = self.recorder = Recorder(eng)
 
-        def first():
+        def body():
             from . import ops
             ops.rng_advance(eng.rng_state)
             eng.forward(inp, True, gt)
             eng.backward_begin()
-            eng.backward_scale(3)
+            for i in range(4):
+                eng.backward_scale(3 - i)
+                if dp is not None:
+                    rec.cut(lambda i=i: dp.on_stage(i))
+            if dp is not None:
+                rec.cut(dp.finish)
+            eng.optimizer_step(lr=lr, grad_scale=scale, **adam)
 
-        parts = [first, lambda: eng.backward_scale(2), lambda: eng.backward_scale(1), lambda: eng.backward_scale(0),
-                 lambda: eng.optimizer_step(lr=lr, grad_scale=scale, **adam)]
-        self.graphs = []
-        for fn in parts:
-            g = torch.cuda.CUDAGraph()
-            # thread_local: RCCL's watchdog thread polls events while we capture; under the default global mode
-            # any such call from another thread invalidates the capture
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                fn()
-            self.graphs.append(g)
+        rec.capture(body)
         self.loss = eng._bufs_for(inp["target_point"].shape[0]).get("head.loss", (1,))
 
     def set_hyper(self, lr, **adam):
@@ -150,20 +151,13 @@ class GraphedStep(object):
         self.engine.set_hyper(self.engine.hyper_rows(lr=lr, grad_scale=self.scale, **adam))
 
     def __call__(self):
-        g, dp = self.graphs, self.dp
-        for i in range(4):
-            g[i].replay()
-            if dp is not None:
-                dp.on_stage(i)
-        if dp is not None:
-            dp.finish()
-        g[4].replay()
+        self.recorder.replay()
         return self.loss
 
 
 class StaticBatchStep(object):
     """A replayable training step for a stream of different batches of one shape: the step is captured once over static
-    copies of the inputs (one hipGraph on a single GPU, the five-graph GraphedStep under data parallelism) and every call
+    copies of the inputs (GraphedStep: linear hipGraphs per lane and per gradient bucket) and every call
     copies the new batch into them first.  What a real training loop needs to run at the replay rate of bench.py instead
     of being bound by ~2500 Python-issued launches per step.  The engine's buffers for this shape must already exist
     (run one eager step of the shape first).  lr / betas / eps / weight decay (per optimizer group) are NOT baked into the
@@ -176,15 +170,9 @@ class StaticBatchStep(object):
         self.scale = 1.0 / (dp.world if dp is not None else 1)
         engine.set_hyper(engine.hyper_rows(lr=lr, grad_scale=self.scale, **adam))
         torch.cuda.synchronize()
-        if dp is None:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                self.loss = engine.train_step(self.inp, self.gt, lr=lr, **adam)
-            self.run = self.graph.replay
-        else:
-            self.seg = GraphedStep(engine, dp, self.inp, self.gt, lr=lr, warm=0, **adam)
-            self.loss = self.seg.loss
-            self.run = self.seg
+        self.seg = GraphedStep(engine, dp, self.inp, self.gt, lr=lr, warm=0, **adam)
+        self.loss = self.seg.loss
+        self.run = self.seg
 
     @staticmethod
     def signature(inp, gt):

@@ -20,7 +20,12 @@ def main():
     pts = np.stack([rng.uniform(-20, 20, 16384), rng.uniform(-12, 28, 16384), rng.uniform(-3, 1, 16384), rng.uniform(0, 1, 16384)], 1).astype(np.float32)
     lanes = rng.randn(40, 10, 5).astype(np.float32)
     out = {}
-    for name, use_graph in (("hipgraph", True), ("eager", False)):
+    eng = net._engine_for()
+    modes = (("hipgraph", True, "1", True), ("hipgraph_forked_in_one_graph", True, "0", True), ("hipgraph_single_stream", True, "1", False),
+             ("eager", False, "1", True))
+    for name, use_graph, lane_graphs, multi in modes:
+        os.environ["MMFN_LANE_GRAPHS"] = lane_graphs
+        eng.multi_stream = multi
         sess = DrivingSession(net, use_graph=use_graph)
         for _ in range(5):
             sess.predict(rgb, pts, lanes, (3.0, 20.0), 4.0)
@@ -37,6 +42,7 @@ def main():
         load_ms = (time.perf_counter() - t0) / 20 * 1e3
         out[name] = {"min_ms": round(ts[0], 3), "median_ms": round(ts[len(ts) // 2], 3), "p90_ms": round(ts[int(len(ts) * 0.9)], 3),
                      "max_ms": round(ts[-1], 3), "stage_inputs_ms": round(load_ms, 3)}
+    eng.multi_stream = True
     print(json.dumps({"workload": "batch-1 tick: 300x400 u8 frame + 32768-pt sweep + 40 lanes -> waypoints (host to host)", **out}))
 
 
