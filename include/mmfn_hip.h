@@ -173,6 +173,17 @@ int mmfn_layernorm_bwd_drop_f32(const float* g, const float* x, const float* wei
                                 const float* rstd, const float* dres, float* dx, float* dweight, float* dbias, int M, int C,
                                 int act, float* dx_dropped, float drop_p, const uint64_t* rng_state, uint32_t rng_stream,
                                 float* dx_colsum, void* workspace, void* stream);
+/* The same backward in two halves, for callers that take the row reductions off the critical path (dx is what the next
+ * kernel of the chain needs; dweight / dbias / dx_colsum only feed the optimizer): _partial_ writes dx (and dx_dropped) plus
+ * per-block partial rows to `partials` (mmfn_layernorm_bwd_rows(M) * (want_colsum ? 3 : 2) * C floats, caller-owned so that
+ * it survives until) _finalize_, which may run later or on another stream, reduces them into dweight / dbias / dx_colsum. */
+int mmfn_layernorm_bwd_rows(int M);
+int mmfn_layernorm_bwd_partial_f32(const float* g, const float* x, const float* weight, const float* bias, const float* mean,
+                                   const float* rstd, const float* dres, float* dx, int M, int C, int act, float* dx_dropped,
+                                   float drop_p, const uint64_t* rng_state, uint32_t rng_stream, int want_colsum,
+                                   float* partials, void* stream);
+int mmfn_layernorm_bwd_finalize_f32(const float* partials, int rows, int C, float* dweight, float* dbias, float* dx_colsum,
+                                    void* stream);
 /* out[c] = sum_r in[r*ld + c]   (bias gradients) */
 int64_t mmfn_colsum_workspace_bytes(int64_t M, int C);
 int mmfn_colsum_f32(const float* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream);

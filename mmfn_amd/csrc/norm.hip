@@ -478,20 +478,22 @@ extern "C" int mmfn_layernorm_bwd_f32(const float* g, const float* x, const floa
                                      nullptr, workspace, stream);
 }
 
-extern "C" int mmfn_layernorm_bwd_drop_f32(const float* g, const float* x, const float* weight, const float* bias,
-                                           const float* mean, const float* rstd, const float* dres, float* dx, float* dweight,
-                                           float* dbias, int M, int C, int act, float* dx_dropped, float drop_p,
-                                           const uint64_t* rng_state, uint32_t rng_stream, float* dx_colsum, void* workspace,
-                                           void* stream) {
-  if (M <= 0 || !workspace) return MMFN_EINVAL;
+static int ln_bwd_rows_per_block(int M) { return std::max(8, ceil_div(M, 768)); }
+
+extern "C" int mmfn_layernorm_bwd_rows(int M) { return M > 0 ? ceil_div(M, ln_bwd_rows_per_block(M)) : 0; }
+
+extern "C" int mmfn_layernorm_bwd_partial_f32(const float* g, const float* x, const float* weight, const float* bias,
+                                              const float* mean, const float* rstd, const float* dres, float* dx, int M, int C,
+                                              int act, float* dx_dropped, float drop_p, const uint64_t* rng_state,
+                                              uint32_t rng_stream, int want_colsum, float* partials, void* stream) {
+  if (M <= 0 || !partials) return MMFN_EINVAL;
   if (dx_dropped && (!rng_state || drop_p <= 0.f || drop_p >= 1.f)) return MMFN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const int rpb = std::max(8, ceil_div(M, 768));
+  const int rpb = ln_bwd_rows_per_block(M);
   const int nblk = ceil_div(M, rpb);
-  float* partials = (float*)workspace;
 #define MMFN_LN_BWD(VW, NCH) \
   hipLaunchKernelGGL((layernorm_bwd_kernel<VW, NCH>), dim3(nblk), dim3(NT), 0, s, g, x, weight, bias, mean, rstd, dres, dx, \
-                     partials, M, act, rpb, dx_dropped, drop_p, rng_state, rng_stream, dx_colsum ? 1 : 0)
+                     partials, M, act, rpb, dx_dropped, drop_p, rng_state, rng_stream, want_colsum ? 1 : 0)
   switch (C) {
     case 64: MMFN_LN_BWD(1, 1); break;
     case 128: MMFN_LN_BWD(2, 1); break;
@@ -501,10 +503,28 @@ extern "C" int mmfn_layernorm_bwd_drop_f32(const float* g, const float* x, const
   }
 #undef MMFN_LN_BWD
   MMFN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, partials, nblk, C, dweight,
-                     dbias, dx_colsum);
+  return 0;
+}
+
+extern "C" int mmfn_layernorm_bwd_finalize_f32(const float* partials, int rows, int C, float* dweight, float* dbias,
+                                               float* dx_colsum, void* stream) {
+  if (!partials || rows <= 0 || C <= 0 || !dweight || !dbias) return MMFN_EINVAL;
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, (hipStream_t)stream, partials,
+                     rows, C, dweight, dbias, dx_colsum);
   MMFN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int mmfn_layernorm_bwd_drop_f32(const float* g, const float* x, const float* weight, const float* bias,
+                                           const float* mean, const float* rstd, const float* dres, float* dx, float* dweight,
+                                           float* dbias, int M, int C, int act, float* dx_dropped, float drop_p,
+                                           const uint64_t* rng_state, uint32_t rng_stream, float* dx_colsum, void* workspace,
+                                           void* stream) {
+  if (M <= 0 || !workspace) return MMFN_EINVAL;
+  const int rc = mmfn_layernorm_bwd_partial_f32(g, x, weight, bias, mean, rstd, dres, dx, M, C, act, dx_dropped, drop_p, rng_state,
+                                                rng_stream, dx_colsum ? 1 : 0, (float*)workspace, stream);
+  if (rc) return rc;
+  return mmfn_layernorm_bwd_finalize_f32((const float*)workspace, mmfn_layernorm_bwd_rows(M), C, dweight, dbias, dx_colsum, stream);
 }
 
 static int colsum_blocks(int64_t M, int64_t* rpb) {

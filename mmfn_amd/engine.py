@@ -232,6 +232,9 @@ class Linear(object):
         self.gb = layout.g(prefix + ".bias") if bias else None
 
 
+DEFER_LN_REDUCTIONS = os.environ.get("MMFN_DEFER_LN", "1") == "1"   # A/B switch, see LayerNorm.bwd
+
+
 class LayerNorm(object):
     def __init__(self, name, layout, prefix):
         self.name = name
@@ -246,14 +249,25 @@ class LayerNorm(object):
         self.saved = (x, mean, rstd, act)
         return y
 
-    def bwd(self, ctx, g, dres=None, out=None, dropped=None, drop_p=0.0, rng_stream=0, colsum=None):
-        """dropped: buffer that receives dx with the dropout mask (p, stream) of the branch consuming dx applied.
+    def bwd(self, ctx, g, dres=None, out=None, dropped=None, drop_p=0.0, rng_stream=0, colsum=None, defer=False):
+        """defer: the caller rejoins the side stream before the gradients are consumed (GPT.bwd).  dropped: buffer that receives dx with the dropout mask (p, stream) of the branch consuming dx applied.
         colsum: [C] gradient buffer that receives the column sums of that tensor (the consuming Linear's bias gradient)."""
         x, mean, rstd, act = self.saved
         dx = ctx.bufs.get(self.name + ".dx", x.shape) if out is None else out
+        rng = ctx.rng_state if dropped is not None else None
+        if defer and ctx.side is not None and DEFER_LN_REDUCTIONS:
+            # the chain only needs dx: the reduction of the per-block partial rows into the weight / bias gradients (and the
+            # consuming Linear's bias gradient) goes to the side stream, like the weight-gradient GEMMs (0.8 ms of ~11 us
+            # launches per step off the transformers' dependent chain); own partial buffer, it must outlive this call
+            M, C = x.shape
+            rows = ops.layernorm_bwd_rows(M)
+            part = ctx.bufs.get(self.name + ".part", (rows, 3 if colsum is not None else 2, C))
+            ops.layernorm_bwd_partial(g, x, self.w, self.b, mean, rstd, dx, part, act, dres=dres, dx_dropped=dropped, drop_p=drop_p,
+                                      rng_state=rng, rng_stream=rng_stream, want_colsum=colsum is not None)
+            ctx.offload(lambda: ops.layernorm_bwd_finalize(part, rows, C, self.gw, self.gb, colsum))
+            return dx
         ops.layernorm_bwd(g, x, self.w, self.b, mean, rstd, dx, self.gw, self.gb, act, dres=dres, dx_dropped=dropped,
-                          drop_p=drop_p, rng_state=ctx.rng_state if dropped is not None else None, rng_stream=rng_stream,
-                          dx_colsum=colsum)
+                          drop_p=drop_p, rng_state=rng, rng_stream=rng_stream, dx_colsum=colsum)
         return dx
 
 
@@ -341,7 +355,7 @@ class GPT(object):
         gd = bufs.get("%s.b%d.gdrop" % (nm, nblk - 1), (M, C)) if drop else None
         # ... and its column sums, which are the bias gradient of the Linear that closes the residual branch (mlp.2 / attn.proj)
         g = self.ln_f.bwd(ctx, g_y.view(M, C), dropped=gd, drop_p=p_resid, rng_stream=sb_of(nblk - 1) + 2,
-                          colsum=self.blocks[nblk - 1]["fc2"].gb)
+                          colsum=self.blocks[nblk - 1]["fc2"].gb, defer=True)
         for i in range(nblk - 1, -1, -1):
             blk = self.blocks[i]
             sb = sb_of(i)
@@ -360,7 +374,7 @@ class GPT(object):
             ops.linear_dx(gh, blk["fc1"].w, out=ga2)
             gd2 = bufs.get("%s.b%d.gdrop2" % (nm, i), (M, C)) if drop else None
             g1 = blk["ln2"].bwd(ctx, ga2, dres=g, out=bufs.get("%s.b%d.g1" % (nm, i), (M, C)), dropped=gd2, drop_p=p_resid,
-                                rng_stream=sb + 1, colsum=blk["proj"].gb)
+                                rng_stream=sb + 1, colsum=blk["proj"].gb, defer=True)
             # ---- attention branch: x1 = x + drop(proj(att(ln1(x))))
             gp = gd2 if drop else g1
             ctx.offload(lambda gp=gp, blk=blk, o=o: ops.linear_dw(gp, o, out=blk["proj"].gw))   # proj.gb: from ln2's backward
@@ -375,7 +389,7 @@ class GPT(object):
             ops.linear_dx(dqkv, blk["wqkv"], out=ga)
             gd = bufs.get("%s.b%d.gdrop" % (nm, i - 1), (M, C)) if (drop and i > 0) else None
             g = blk["ln1"].bwd(ctx, ga, dres=g1, out=bufs.get("%s.b%d.g0" % (nm, i), (M, C)), dropped=gd, drop_p=p_resid,
-                               rng_stream=sb_of(i - 1) + 2, colsum=self.blocks[i - 1]["fc2"].gb if i > 0 else None)
+                               rng_stream=sb_of(i - 1) + 2, colsum=self.blocks[i - 1]["fc2"].gb if i > 0 else None, defer=True)
         ctx.rejoin()
         gtok = g.view(B, T, C)
         ops.tokens_bwd(gtok, self.velocity, self.g_pos.view(T, C), self.vel.gw.view(C), self.vel.gb, p_embd, ctx.rng_state,

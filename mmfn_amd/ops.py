@@ -711,6 +711,24 @@ def layernorm_bwd(g, x, w, b, mean, rstd, dx, dw, db, act=ACT_NONE, dres=None, d
     return dx
 
 
+def layernorm_bwd_rows(M):
+    return lib().mmfn_layernorm_bwd_rows(M)
+
+
+def layernorm_bwd_partial(g, x, w, b, mean, rstd, dx, partials, act=ACT_NONE, dres=None, dx_dropped=None, drop_p=0.0,
+                          rng_state=None, rng_stream=0, want_colsum=False):
+    """First half of layernorm_bwd: dx (and dx_dropped) now, the row reductions as partial rows in `partials`
+    ([layernorm_bwd_rows(M), 3 or 2, C] floats) for layernorm_bwd_finalize - which may run later, on another stream."""
+    M, C = x.shape
+    _call("mmfn_layernorm_bwd_partial_f32", ptr(g), ptr(x), ptr(w), ptr(b), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), M, C, act,
+          ptr(dx_dropped), float(drop_p), ptr(rng_state), rng_stream, 1 if want_colsum else 0, ptr(partials), stream())
+    return dx
+
+
+def layernorm_bwd_finalize(partials, rows, C, dw, db, dx_colsum=None):
+    _call("mmfn_layernorm_bwd_finalize_f32", ptr(partials), rows, C, ptr(dw), ptr(db), ptr(dx_colsum), stream())
+
+
 def colsum(x2d, out, M=None, C=None, ld=None):
     M = x2d.shape[0] if M is None else M
     C = x2d.shape[1] if C is None else C
