@@ -109,8 +109,8 @@ class GraphedStep(object):
     """One training step as a replayable sequence of linear hipGraphs (mmfn_amd.graphs.Recorder).
 
     The step is cut (a) wherever the engine forks into its branch lanes - every lane is its own linear graph on its own
-    stream, stitched with eager events, because a multi-stream DAG captured into ONE hipGraph is replayed with coarse
-    cross-queue dependencies that serialise the lanes (graphs.py) - and (b), under data parallelism, at the backward-stage
+    stream, stitched with eager events, because replaying a graph with cross-stream edges costs the host ~5 us per kernel
+    node against ~0.4 us for a linear graph (graphs.py) - and (b), under data parallelism, at the backward-stage
     boundaries, where the gradient-bucket all-reduces are issued (through torch.distributed they cannot be captured):
         RNG advance + forward + loss + head backward + backward of fusion scale 4   -> all-reduce bucket 0
         backward of scale 3 -> bucket 1;  scale 2 -> bucket 2;  scale 1 + stems -> bucket 3

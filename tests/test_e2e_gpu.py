@@ -242,7 +242,7 @@ def test_raw_sensor_ingest_path_equals_tensor_path():
 
 
 def test_segmented_graph_step_equals_eager_steps():
-    """parallel.GraphedStep (five hipGraphs cut at the gradient-bucket boundaries) replays to exactly the
+    """parallel.GraphedStep (linear hipGraphs per branch lane, cut at the gradient-bucket boundaries under data parallelism) replays to exactly the
     parameters the eager train_step produces, dropout included (counter RNG advances on the device)."""
     from mmfn_amd.parallel import GraphedStep
     _, net_a, batch, args = _setup("vec", dropout=0.1)

@@ -1,5 +1,5 @@
 """Two data-parallel ranks sharing the one GPU of the test box (gloo: RCCL refuses two ranks per device): the real
-DataParallel bucket overlap and the five-graph step on GPU tensors (tools/dp_check.py does the work and asserts)."""
+DataParallel bucket overlap and the graph-replayed step on GPU tensors (tools/dp_check.py does the work and asserts)."""
 import os
 import subprocess
 import sys

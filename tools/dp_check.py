@@ -11,7 +11,7 @@ Checks
      shard with per-rank BatchNorm statistics, exactly DDP's semantics, phase2_train_net.py:227,265-269), judged like
      tests/test_e2e_gpu.py against an fp64 oracle with the fp32 oracle's own error as yardstick; the updated weights equal
      a reference-style 2-rank loop (torch AdamW on the averaged oracle gradient) on every element whose sign is determined;
-  3. the five-graph step (collectives between hipGraph replays) reproduces the eager data-parallel step bit for bit.
+  3. the graph-replayed step (GraphedStep: collectives between hipGraph replays) reproduces the eager data-parallel step bit for bit.
 """
 import copy
 import os
@@ -135,7 +135,7 @@ def main():
     loss_ok = abs(loss.item() - loss32.item()) <= 1e-4
     value_ok = (not bad) and ratios[len(ratios) // 2] <= 2.5 and checked >= 0.1 * total and loss_ok
 
-    # ---- 3. the five-graph step == the eager data-parallel step, bit for bit
+    # ---- 3. the graph-replayed step == the eager data-parallel step, bit for bit
     steps = int(os.environ.get("DP_CHECK_STEPS", "1"))
     restore()
     for _ in range(steps):
