@@ -72,44 +72,68 @@ __global__ __launch_bounds__(NT) void col_partial_kernel(const float* __restrict
 }
 
 
-// Sum `nblk` partial rows for column c: 8 row-lanes per column + LDS tree (the serial per-column
-// loop this replaces took 50-90 us per launch at nblk ~ 400 and dominated the non-GEMM time).
-constexpr int FIN_COLS = 8, FIN_LANES = 32;
-template <typename T>
-__device__ __forceinline__ double reduce_partials(const T* __restrict__ partials, int nblk, size_t row_stride, int c, bool valid,
-                                                  double (*sh)[FIN_COLS]) {
+// Sum `nblk` partial rows of NV value-rows for column c in one pass: 4 columns x 64 row-lanes per block, the loads of all
+// NV sums in flight together, then a fixed-order two-stage LDS combine (the serial per-column loop this replaces took
+// 50-90 us per launch at nblk ~ 400; the 8 x 32 version with one value-row per pass 5.6-7.5 us - these launches sit on the
+// dependent chain of every BatchNorm).  partials: value-row v of partial row b at partials[b * row_stride + v * C + c].
+constexpr int FIN_COLS = 4, FIN_LANES = 64;
+template <int NV, typename T>
+__device__ __forceinline__ void reduce_partials(const T* __restrict__ partials, int nblk, size_t row_stride, int C, int c, bool valid,
+                                                double (*sh)[FIN_LANES][FIN_COLS], double* out) {
   const int cl = threadIdx.x % FIN_COLS, rl = threadIdx.x / FIN_COLS;
-  double s = 0;
+  double t0[NV], t1[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) { t0[v] = 0; t1[v] = 0; }
   if (valid) {
-    double t0 = 0, t1 = 0, t2 = 0, t3 = 0;  // four independent loads in flight (latency-bound otherwise)
     int b = rl;
-    for (; b + 3 * FIN_LANES < nblk; b += 4 * FIN_LANES) {
-      t0 += (double)partials[(size_t)b * row_stride + c];
-      t1 += (double)partials[(size_t)(b + FIN_LANES) * row_stride + c];
-      t2 += (double)partials[(size_t)(b + 2 * FIN_LANES) * row_stride + c];
-      t3 += (double)partials[(size_t)(b + 3 * FIN_LANES) * row_stride + c];
+    for (; b + FIN_LANES < nblk; b += 2 * FIN_LANES) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        t0[v] += (double)partials[(size_t)b * row_stride + (size_t)v * C + c];
+        t1[v] += (double)partials[(size_t)(b + FIN_LANES) * row_stride + (size_t)v * C + c];
+      }
     }
-    for (; b < nblk; b += FIN_LANES) t0 += (double)partials[(size_t)b * row_stride + c];
-    s = (t0 + t1) + (t2 + t3);
+    if (b < nblk) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) t0[v] += (double)partials[(size_t)b * row_stride + (size_t)v * C + c];
+    }
   }
-  sh[rl][cl] = s;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) sh[v][rl][cl] = t0[v] + t1[v];
   __syncthreads();
-  double tot = 0;
-  if (rl == 0)
-    for (int k = 0; k < FIN_LANES; ++k) tot += sh[k][cl];
+  if (rl < 8) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      double a = 0;
+      for (int k = rl; k < FIN_LANES; k += 8) a += sh[v][k][cl];
+      t0[v] = a;
+    }
+  }
   __syncthreads();
-  return tot;
+  if (rl < 8) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) sh[v][rl][cl] = t0[v];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    double a = 0;
+    if (rl == 0)
+      for (int k = 0; k < 8; ++k) a += sh[v][k][cl];
+    out[v] = a;
+  }
 }
 
 __global__ void bn_stats_finalize_kernel(const double* __restrict__ partials, int nblk, int64_t M, int C, float eps,
                                          float momentum, float* __restrict__ mean, float* __restrict__ rstd,
                                          float* __restrict__ running_mean, float* __restrict__ running_var,
                                          int64_t* __restrict__ num_batches_tracked) {
-  __shared__ double sh[FIN_LANES][FIN_COLS];
+  __shared__ double sh[2][FIN_LANES][FIN_COLS];
   const int c = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
   const bool valid = c < C;
-  const double s1 = reduce_partials(partials, nblk, (size_t)2 * C, c, valid, sh);
-  const double s2 = reduce_partials(partials + C, nblk, (size_t)2 * C, c, valid, sh);
+  double r[2];
+  reduce_partials<2>(partials, nblk, (size_t)2 * C, C, c, valid, sh, r);
+  const double s1 = r[0], s2 = r[1];
   if (!valid || threadIdx.x >= FIN_COLS) return;
   const double mu = s1 / (double)M;
   double var = s2 / (double)M - mu * mu;
@@ -164,11 +188,12 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int nblk, int64_t M, int C,
                                        float* __restrict__ dweight, float* __restrict__ dbias,
                                        float* __restrict__ means /* [2][C]: s1/M, s2/M */) {
-  __shared__ double sh[FIN_LANES][FIN_COLS];
+  __shared__ double sh[2][FIN_LANES][FIN_COLS];
   const int c = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
   const bool valid = c < C;
-  const double s1 = reduce_partials(partials, nblk, (size_t)2 * C, c, valid, sh);
-  const double s2 = reduce_partials(partials + C, nblk, (size_t)2 * C, c, valid, sh);
+  double r[2];
+  reduce_partials<2>(partials, nblk, (size_t)2 * C, C, c, valid, sh, r);
+  const double s1 = r[0], s2 = r[1];
   if (!valid || threadIdx.x >= FIN_COLS) return;
   dbias[c] = (float)s1;
   dweight[c] = (float)s2;
@@ -348,13 +373,14 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restri
 
 __global__ void colsum_finalize_kernel(const float* __restrict__ partials, int nblk, int C, float* __restrict__ out0,
                                        float* __restrict__ out1, float* __restrict__ out2) {
-  __shared__ double sh[FIN_LANES][FIN_COLS];
+  __shared__ double sh[3][FIN_LANES][FIN_COLS];
   const int c = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
   const bool valid = c < C;
-  const size_t stride = (size_t)(out2 ? 3 : 2) * C;
-  const double s0 = reduce_partials(partials, nblk, stride, c, valid, sh);
-  const double s1 = out1 ? reduce_partials(partials + C, nblk, stride, c, valid, sh) : 0.0;
-  const double s2 = out2 ? reduce_partials(partials + 2 * C, nblk, stride, c, valid, sh) : 0.0;
+  double r[3] = {0, 0, 0};
+  if (out2) reduce_partials<3>(partials, nblk, (size_t)3 * C, C, c, valid, sh, r);
+  else if (out1) reduce_partials<2>(partials, nblk, (size_t)2 * C, C, c, valid, sh, r);
+  else reduce_partials<1>(partials, nblk, (size_t)2 * C, C, c, valid, sh, r);
+  const double s0 = r[0], s1 = r[1], s2 = r[2];
   if (!valid || threadIdx.x >= FIN_COLS) return;
   out0[c] = (float)s0;
   if (out1) out1[c] = (float)s1;
@@ -381,10 +407,12 @@ __global__ __launch_bounds__(NT) void colsum_partial_kernel(const float* __restr
 }
 
 __global__ void colsum_finalize1_kernel(const float* __restrict__ partials, int nblk, int C, float* __restrict__ out) {
-  __shared__ double sh[FIN_LANES][FIN_COLS];
+  __shared__ double sh[1][FIN_LANES][FIN_COLS];
   const int c = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
   const bool valid = c < C;
-  const double s0 = reduce_partials(partials, nblk, (size_t)C, c, valid, sh);
+  double r[1];
+  reduce_partials<1>(partials, nblk, (size_t)C, C, c, valid, sh, r);
+  const double s0 = r[0];
   if (!valid || threadIdx.x >= FIN_COLS) return;
   out[c] = (float)s0;
 }
