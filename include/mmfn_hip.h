@@ -55,6 +55,12 @@ int mmfn_wino_output_stats_f32(const float* Mt, float* y, double* partials, int*
 /* weight gradient in the F(4x4,3x3) domain: dw = G^T [ sum_tiles (A dY A^T) . (B^T x B) ] G
  *   dMt[36][tiles][Co] = A dy A^T per 4x4 patch;  dU[t] = dMt[t]^T . V[t] (batched GEMM);  dw[Co][3][3][Ci] = G^T dU G */
 int mmfn_wino_outgrad_f32(const float* dy, float* dMt, int B, int H, int W, int C, void* stream);
+/* The same transform of dy = BatchNorm-backward(g, y, x) formed on the fly (mmfn_bn_bwd_f32's apply pass fused in): g = dL/d(BN
+ * output), y != NULL applies the ReLU mask (y > 0), x = the convolution output, means[2][C] from mmfn_bn_bwd_reduce_f32;
+ * ge_out (optional) = masked g.  dy itself is never written: these layers only consume it in the Winograd domain. */
+int mmfn_wino_outgrad_bn_f32(const float* g, const float* y, const float* x, const float* mean, const float* rstd,
+                             const float* weight, const float* means, float* ge_out, float* dMt, int B, int H, int W, int C,
+                             void* stream);
 /* Data gradient of the same convolution as the ADJOINT of its forward Winograd pipeline: dV [36][tiles][Ci] (= dM . U, one
  * 36-batch GEMM over the forward's own transformed filter) -> dx = overlap-add of B dV B^T over the tiles' 6x6 input patches
  * (+ res).  H, W multiples of 4; replaces cuDNN's backward-data for the BasicBlock 3x3 convolutions (model_vec.py:539-593). */
@@ -155,6 +161,9 @@ int mmfn_bn_apply_f32(const float* x, const float* res, float* y, int64_t M, int
 int mmfn_bn_bwd_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean, const float* rstd,
                     const float* weight, float* dx, float* ge_out, float* dweight, float* dbias, void* workspace,
                     void* stream);
+/* The reductions of mmfn_bn_bwd_f32 without its apply pass: dweight, dbias, means[2][C] = (mean(ge), mean(ge * xhat)) */
+int mmfn_bn_bwd_reduce_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean,
+                           const float* rstd, float* dweight, float* dbias, float* means, void* workspace, void* stream);
 /* LayerNorm over rows of x[M,C] (C % 64 == 0, C <= 512), optional fused activation on the output
  * (act: 0 none, 1 ReLU, 2 exact GELU).  Replaces aten native_layer_norm (+relu/gelu) of
  * model_vec.py:117-118,162 (GPT) and :252,335-336,345-346,352-353 (VectorNet). */

@@ -490,6 +490,24 @@ extern "C" int mmfn_bn_bwd_f32(const float* g, const float* y, const float* x, i
   return 0;
 }
 
+// First two launches of mmfn_bn_bwd_f32 only: dweight, dbias and means[2][C] = (mean(ge), mean(ge * xhat)); the caller
+// applies them itself (mmfn_wino_outgrad_bn_f32 forms dx inside the Winograd output-gradient transform).
+extern "C" int mmfn_bn_bwd_reduce_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean,
+                                      const float* rstd, float* dweight, float* dbias, float* means, void* workspace,
+                                      void* stream) {
+  if (C % 4 || C > 1024 || (NT % (C / 4)) || M <= 0 || !workspace || !means) return MMFN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t rpb;
+  const int nblk = bn_grid(M, C, &rpb);
+  double* partials = (double*)workspace;
+  hipLaunchKernelGGL(col_partial_kernel<1>, dim3(nblk), dim3(NT), 0, s, x, g, y, mean, rstd, M, C, rpb, partials);
+  MMFN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, partials, nblk, M, C, dweight, dbias,
+                     means);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmfn_layernorm_fwd_f32(const float* x, const float* weight, const float* bias, float* y, float* mean,
                                       float* rstd, int M, int C, float eps, int act, void* stream) {
   if (C % 64 || C > 512 || M <= 0) return MMFN_EINVAL;

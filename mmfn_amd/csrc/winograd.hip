@@ -322,6 +322,61 @@ __global__ __launch_bounds__(NT) void wino4_outgrad_kernel(const float* __restri
   }
 }
 
+// The same transform with the BatchNorm backward applied on the fly: the layer's output gradient
+//   dy = w * rstd * (ge - mean(ge) - xhat * mean(ge * xhat)),  ge = g * (y > 0),  xhat = (x - mean) * rstd
+// (bn_bwd_apply_kernel, norm.hip) is only ever consumed in the Winograd domain by these layers, so it is formed in registers
+// from g, y and the convolution output x instead of being written to HBM by one pass and read back by the next
+// (one launch and 2 x |dy| bytes less per convolution).  means = [2][C]: mean(ge), mean(ge * xhat) from the reduction
+// kernels.  ge_out (optional) receives ge, the gradient of the residual branch.
+__global__ __launch_bounds__(NT) void wino4_outgrad_bn_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                              const float* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ w,
+                                                              const float* __restrict__ means, float* __restrict__ ge_out,
+                                                              float* __restrict__ dMt, int B, int H, int W, int C) {
+  const int cq = C >> 2, th = H >> 2, tw = W >> 2;
+  const int64_t T = (int64_t)B * th * tw, n = T * cq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % cq) * 4;
+    const int64_t tile = i / cq;
+    const int j = (int)(tile % tw), ii = (int)((tile / tw) % th), b = (int)(tile / ((int64_t)tw * th));
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4), rs = *reinterpret_cast<const f32x4*>(rstd + c4);
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c4);
+    const f32x4 m1 = *reinterpret_cast<const f32x4*>(means + c4), m2 = *reinterpret_cast<const f32x4*>(means + C + c4);
+    f32x4 r[6][4];  // A dy, column by column
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 d[4], m[6];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const size_t off = (((size_t)b * H + 4 * ii + p) * W + 4 * j + q) * C + c4;
+        f32x4 gv = *reinterpret_cast<const f32x4*>(g + off);
+        if (y) {
+          const f32x4 yv = *reinterpret_cast<const f32x4*>(y + off);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.0f ? gv[e] : 0.0f;
+        }
+        if (ge_out) *reinterpret_cast<f32x4*>(ge_out + off) = gv;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xv[e] - mu[e]) * rs[e];
+          d[p][e] = (gv[e] - m1[e] - xh * m2[e]) * (wv[e] * rs[e]);   // same expression as bn_bwd_apply_kernel
+        }
+      }
+      f4_a(d, m);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) r[a][q] = m[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      f32x4 m[6];
+      f4_a(r[a], m);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) *reinterpret_cast<f32x4*>(dMt + ((size_t)(a * 6 + e) * T + tile) * C + c4) = m[e];
+    }
+  }
+}
+
 // ---- data gradient in the F(4x4,3x3) domain: the ADJOINT of the forward pipeline instead of a second convolution with
 // the flipped filter.  With dM = A dY A^T (wino4_outgrad_kernel - the weight gradient needs it anyway) and the forward's
 // own U = G w G^T:   dV[t] = dM[t] . U[t]   ([tiles x Co] x [Co x Ci], one 36-batch GEMM),   dx = sum over tiles of
@@ -555,6 +610,16 @@ extern "C" int mmfn_wino_outgrad_f32(const float* dy, float* dMt, int B, int H, 
   if (!dy || !dMt || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
   hipLaunchKernelGGL(wino4_outgrad_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0, (hipStream_t)stream, dy,
                      dMt, B, H, W, C);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_wino_outgrad_bn_f32(const float* g, const float* y, const float* x, const float* mean, const float* rstd,
+                                        const float* weight, const float* means, float* ge_out, float* dMt, int B, int H, int W,
+                                        int C, void* stream) {
+  if (!g || !x || !mean || !rstd || !weight || !means || !dMt || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
+  hipLaunchKernelGGL(wino4_outgrad_bn_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
+                     g, y, x, mean, rstd, weight, means, ge_out, dMt, B, H, W, C);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

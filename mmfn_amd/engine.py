@@ -88,6 +88,9 @@ class Ctx(object):
 
 
 # ----------------------------------------------------------------------------- conv + BN
+FUSE_BN_BWD_APPLY = os.environ.get("MMFN_FUSE_BN_BWD", "1") == "1"   # A/B switch, see ConvBN.bwd
+
+
 class ConvBN(object):
     """conv (bias-free) -> BatchNorm2d -> [+ residual] -> [ReLU]."""
 
@@ -143,9 +146,18 @@ class ConvBN(object):
         ymask = None
         if relu:
             ymask = (y if mask_y is None else mask_y).view(M, self.cout)
+        u = getattr(self, "saved_u", None)
+        if need_dx and u is not None and FUSE_BN_BWD_APPLY:
+            # weight and data gradient together in the Winograd domain (shared A dy A^T), and dy = the BatchNorm backward of g
+            # is formed inside that transform: only the two reductions run as kernels of their own, dy never goes to HBM
+            means = ctx.bufs.get(self.name + ".bnmeans", (2, self.cout))
+            ops.bn_bwd_reduce(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.g_bn_w, self.g_bn_b, means)
+            dx = ctx.bufs.get(self.name + ".dx", x.shape)
+            ops.conv2d_bwd_winograd(dco, x, u, self.gw, dx, v=getattr(self, "saved_v", None), res=dx_res,
+                                    bn=(g, None if ymask is None else ymask.view(g.shape), co, mean, rstd, self.bn_w, means, ge_out))
+            return dx
         ops.bn_bwd(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.bn_w, dco.view(M, self.cout),
                    self.g_bn_w, self.g_bn_b, ge_out=None if ge_out is None else ge_out.view(M, self.cout))
-        u = getattr(self, "saved_u", None)
         if need_dx and u is not None:   # weight and data gradient together in the Winograd domain (shared A dy A^T)
             dx = ctx.bufs.get(self.name + ".dx", x.shape)
             ops.conv2d_bwd_winograd(dco, x, u, self.gw, dx, v=getattr(self, "saved_v", None), res=dx_res)

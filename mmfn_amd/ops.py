@@ -570,12 +570,17 @@ def conv2d_wgrad_winograd(dy, x, out, v=None):
     return out
 
 
-def _wgrad_winograd_body(dy, x, out, v, B, H, W, Ci, Co, T, dU, V, dMt, st):
+def _wgrad_winograd_body(dy, x, out, v, B, H, W, Ci, Co, T, dU, V, dMt, st, bn=None):
     if v is not None:
         V = v.view(-1)[:36 * T * Ci]
     else:
         _call("mmfn_wino_input_f32", ptr(x), ptr(V), B, H, W, Ci, 4, st)
-    _call("mmfn_wino_outgrad_f32", ptr(dy), ptr(dMt), B, H, W, Co, st)
+    if bn is not None:
+        g, ymask, co, mean, rstd, weight, means, ge_out = bn
+        _call("mmfn_wino_outgrad_bn_f32", ptr(g), ptr(ymask), ptr(co), ptr(mean), ptr(rstd), ptr(weight), ptr(means), ptr(ge_out),
+              ptr(dMt), B, H, W, Co, st)
+    else:
+        _call("mmfn_wino_outgrad_f32", ptr(dy), ptr(dMt), B, H, W, Co, st)
     gemm(dMt, V, dU, Co, Ci, T, Co, Ci, Ci, A_COLMAJOR, B_KN, batch=36, strideA=T * Co, strideB=T * Ci, strideC=Co * Ci)
     _call("mmfn_wino_wgrad_out_f32", ptr(dU), ptr(out), Co, Ci, st)
     return out
@@ -589,12 +594,14 @@ def winograd_adjoint_ok(x_shape, w_shape, stride, pad):
     return WINOGRAD_ADJOINT_DGRAD and winograd_wgrad_ok(x_shape, w_shape, stride, pad)
 
 
-def conv2d_bwd_winograd(dy, x, u, dw_out, dx_out, v=None, res=None):
+def conv2d_bwd_winograd(dy, x, u, dw_out, dx_out, v=None, res=None, bn=None):
     """Weight AND data gradient of a 3x3 stride-1 'same' convolution in the F(4x4,3x3) domain, sharing the transformed
     output gradient dM = A dy A^T:
         dw = G^T [ sum_tiles dM^T . V ] G          (V = B^T x B, kept by the forward or recomputed)
         dx = overlap-add( B (dM . U) B^T ) (+ res)  (U = G w G^T, kept by the forward: the ADJOINT of the forward pipeline,
-                                                     no flipped filter, no second filter / input transform)"""
+                                                     no flipped filter, no second filter / input transform)
+    bn = (g, ymask or None, conv_out, mean, rstd, weight, means, ge_out or None), all NHWC / [C]: dy is then the BatchNorm backward
+    of g (reductions already done by bn_bwd_reduce) formed on the fly inside the transform; the `dy` argument only gives the shape."""
     B, H, W, Ci = x.shape
     Co = dy.shape[3]
     T = B * (H // 4) * (W // 4)
@@ -606,7 +613,7 @@ def conv2d_bwd_winograd(dy, x, u, dw_out, dx_out, v=None, res=None):
     conv_flops = 2.0 * B * H * W * Co * 9 * Ci
     conv_bytes = 4.0 * (B * H * W * (Ci + Co) + 9 * Co * Ci)
     with _whole_op("wgrad %dx%d c%d->%d k3 s1 (winograd F4)" % (H, W, Ci, Co), conv_flops, conv_bytes, 2.0 * 36 * T * Co * Ci):
-        _wgrad_winograd_body(dy, x, dw_out, v, B, H, W, Ci, Co, T, dU, Vs, dMt, st)
+        _wgrad_winograd_body(dy, x, dw_out, v, B, H, W, Ci, Co, T, dU, Vs, dMt, st, bn=bn)
     with _whole_op("dgrad %dx%d c%d->%d k3 s1 (winograd F4 adjoint)" % (H, W, Ci, Co), conv_flops, conv_bytes, 2.0 * 36 * T * Co * Ci):
         dV = Vs  # the scratch V region is free again: with a kept V it was never used, otherwise the wgrad GEMM is done with it
         gemm(dMt, u.view(-1)[:36 * Co * Ci], dV, T, Ci, Co, Co, Ci, Ci, A_ROWMAJOR, B_KN, batch=36, strideA=T * Co, strideB=Co * Ci,
@@ -689,6 +696,15 @@ def bn_bwd(g2d, y2d, x2d, mean, rstd, weight, dx, dweight, dbias, ge_out=None):
     _call("mmfn_bn_bwd_f32", ptr(g2d), ptr(y2d), ptr(x2d), M, C, ptr(mean), ptr(rstd), ptr(weight), ptr(dx), ptr(ge_out),
           ptr(dweight), ptr(dbias), ptr(norm_workspace(x2d.device)), stream())
     return dx
+
+
+def bn_bwd_reduce(g2d, y2d, x2d, mean, rstd, dweight, dbias, means):
+    """The reductions of bn_bwd only (dweight, dbias, means[2][C]); conv2d_bwd_winograd(bn=...) applies them inside its
+    output-gradient transform."""
+    M, C = x2d.shape
+    _call("mmfn_bn_bwd_reduce_f32", ptr(g2d), ptr(y2d), ptr(x2d), M, C, ptr(mean), ptr(rstd), ptr(dweight), ptr(dbias), ptr(means),
+          ptr(norm_workspace(x2d.device)), stream())
+    return means
 
 
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2

@@ -175,6 +175,44 @@ def test_winograd_adjoint_backward(cfg):
     assert (outs[0][1] - old).abs().max().item() <= 3e-5 * old.abs().max().item()
 
 
+@pytest.mark.parametrize("relu", [True, False])
+def test_winograd_backward_with_fused_batchnorm_backward(relu):
+    """conv2d_bwd_winograd(bn=...): the BatchNorm backward of g is formed inside the output-gradient transform (its reductions
+    done by bn_bwd_reduce) instead of by bn_bwd's apply pass - same dx / dw / parameter gradients / masked g as the two-pass path."""
+    from mmfn_amd import ops
+    dev = _dev()
+    B, HW, Cin, Cout = 3, 16, 128, 256
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(B, HW, HW, Cin, generator=gen).to(dev)
+    w = (torch.randn(Cout, 3, 3, Cin, generator=gen) * 0.05).to(dev)
+    u = torch.empty(36 * Cout * Cin, device=dev)
+    v = torch.empty(ops.winograd_v_numel(x.shape), device=dev)
+    co = ops.conv2d_fwd(x, w, 1, 1, keep_v=v, keep_u=u)
+    M = B * HW * HW
+    mean, var = co.view(M, Cout).mean(0), co.view(M, Cout).var(0, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    bn_w = (torch.rand(Cout, generator=gen) + 0.5).to(dev)
+    y = ((co - mean) * rstd * bn_w + 0.1)
+    y = torch.relu(y) if relu else y
+    g = torch.randn(B, HW, HW, Cout, generator=gen).to(dev)
+    ymask = y.view(M, Cout) if relu else None
+    # two passes
+    dco, ge_a = torch.empty_like(co), torch.empty_like(g)
+    dbw_a, dbb_a = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
+    ops.bn_bwd(g.view(M, Cout), ymask, co.view(M, Cout), mean, rstd, bn_w, dco.view(M, Cout), dbw_a, dbb_a, ge_out=ge_a.view(M, Cout))
+    dw_a, dx_a = torch.empty_like(w), torch.empty_like(x)
+    ops.conv2d_bwd_winograd(dco, x, u, dw_a, dx_a, v=v)
+    # fused
+    means = torch.empty(2, Cout, device=dev)
+    dbw_b, dbb_b = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
+    ops.bn_bwd_reduce(g.view(M, Cout), ymask, co.view(M, Cout), mean, rstd, dbw_b, dbb_b, means)
+    dw_b, dx_b, ge_b = torch.empty_like(w), torch.empty_like(x), torch.empty_like(g)
+    ops.conv2d_bwd_winograd(dco, x, u, dw_b, dx_b, v=v, bn=(g, None if ymask is None else y, co, mean, rstd, bn_w, means, ge_b))
+    assert torch.equal(dbw_a, dbw_b) and torch.equal(dbb_a, dbb_b) and torch.equal(ge_a, ge_b)
+    for a, b in ((dx_a, dx_b), (dw_a, dw_b)):
+        assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item()   # fma contraction may differ between the two kernels
+
+
 @pytest.mark.parametrize("shape", [(384, 256, 512), (224, 160, 96), (6144, 512, 2048), (64, 2048, 6144)])
 def test_bf16_operand_gemm_forms(shape):
     """MMFN_EPI_BF16_OPERANDS: every plain form equals the fp32 product of the bf16-rounded operands (fp32 accumulate);
