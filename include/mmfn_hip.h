@@ -126,7 +126,8 @@ typedef struct mmfn_gemm_desc {
   uint32_t rng_stream;  /* distinguishes dropout sites                                    */
   float drop_p;
   /* batched GEMM (radar GAT, model_rad.py:816-824): problem z uses A + z*strideA, ... (floats);
-   * batch <= 1 means a single problem.  Split-K is disabled for batch > 1. */
+   * batch <= 1 means a single problem.  Batched launches split K when the epilogue has no per-batch operand
+   * (no residual / mask / accumulate; dropout only with packed outputs, strideC == M*N). */
   int32_t batch;
   int32_t dg_parity; /* internal: set by the launcher for stride-2 dgrad (output-parity decomposition) */
   int64_t strideA, strideB, strideC;
@@ -196,6 +197,10 @@ int mmfn_layernorm_bwd_finalize_f32(const float* partials, int rows, int C, floa
 /* out[c] = sum_r in[r*ld + c]   (bias gradients) */
 int64_t mmfn_colsum_workspace_bytes(int64_t M, int C);
 int mmfn_colsum_f32(const float* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream);
+/* `batch` such sums in one launch pair: entry z reads in + z*stride_in, writes out + z*stride_out (floats); workspace =
+ * batch * mmfn_colsum_workspace_bytes(M, C).  (The same bias gradient of the eight blocks of a fusion transformer.) */
+int mmfn_colsum_batched_f32(const float* in, int batch, int64_t stride_in, int64_t M, int C, int ld, float* out,
+                            int64_t stride_out, void* workspace, void* stream);
 
 /* ---- pooling / token assembly / upsampling on NHWC maps ----------------------------------- */
 /* MaxPool2d(3,2,1) with first-max argmax (uint8 tap index) — torchvision stem (model_vec.py:512,518) */

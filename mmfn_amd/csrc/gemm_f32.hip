@@ -907,9 +907,17 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(const mmfn_gemm_desc d_in
 
 // Deterministic split-K combine: slabs [splitk][M][N] -> epilogue(C).  One thread per 4 consecutive
 // columns (16-byte loads), 4 independent partial sums so the slab loads pipeline.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const mmfn_gemm_desc d) {
-  const size_t total = (size_t)d.M * d.N;
-  const size_t total4 = total >> 2;
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const mmfn_gemm_desc d_in) {
+  // batch > 1 here: outputs of the batch entries are NOT packed (strideC != M*N, e.g. the same weight of eight transformer
+  // blocks in the flat gradient buffer): blockIdx.y is the batch entry, slabs are [split][batch][M][N]
+  mmfn_gemm_desc d = d_in;
+  const size_t per = (size_t)d.M * d.N;
+  const size_t total = per * (size_t)max(1, d_in.batch);   // one slab
+  if (d_in.batch > 1) {
+    d.C += (size_t)blockIdx.y * d_in.strideC;
+    d.workspace += (size_t)blockIdx.y * per;
+  }
+  const size_t total4 = per >> 2;
   uint64_t key = 0;
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
   const bool vec = (d.N & 3) == 0;
@@ -935,7 +943,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const mmfn_gemm_desc
       for (int q = 0; q < 4; ++q) epilogue_store(d, key, row, col + q, (s0[q] + s1[q]) + (s2[q] + s3[q]));
     }
   } else {
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per; idx += (size_t)gridDim.x * blockDim.x) {
       float v = 0.0f;
       for (int z = 0; z < d.splitk; ++z) v += d.workspace[(size_t)z * total + idx];
       const int row = (int)(idx / d.N), col = (int)(idx - (size_t)row * d.N);
@@ -981,13 +989,25 @@ __global__ __launch_bounds__(1024) void splitk_reduce_deep_kernel(const mmfn_gem
 
 // Batched launches may split K too when the batch's outputs are packed back to back (strideC == M*N, ldc == N) and the
 // epilogue has no per-batch operand: the slabs are then [split][batch][M][N] and the combine kernel sees one (batch*M) x N matrix.
+// ... or, when the outputs are strided (the same weight gradient of several transformer blocks, each in its own place of the
+// flat gradient buffer), the combine kernel takes the batch entry from blockIdx.y.
+bool batch_packed(const mmfn_gemm_desc& d) { return d.strideC == (int64_t)d.M * d.N && d.ldc == d.N; }
 bool batch_can_split(const mmfn_gemm_desc& d) {
-  return d.batch > 1 && d.strideC == (int64_t)d.M * d.N && d.ldc == d.N && !(d.flags & (MMFN_EPI_RESIDUAL | MMFN_EPI_MASK_AUX | MMFN_EPI_ACCUM));
+  return d.batch > 1 && !(d.flags & (MMFN_EPI_RESIDUAL | MMFN_EPI_MASK_AUX | MMFN_EPI_ACCUM)) &&
+         (batch_packed(d) || !(d.flags & MMFN_EPI_DROPOUT));
 }
 
 void launch_splitk_reduce(const mmfn_gemm_desc& dd_in, hipStream_t s) {
   mmfn_gemm_desc dd = dd_in;
-  if (dd.batch > 1) {  // (only reached when batch_can_split)
+  if (dd.batch > 1 && !batch_packed(dd)) {  // strided outputs: one grid row per batch entry
+    const size_t per = (size_t)dd.M * dd.N;
+    const bool vec = (dd.N & 3) == 0;
+    const size_t work = vec ? per / 4 : per;
+    const int blocks = (int)std::min<size_t>((work + 255) / 256 + 1, 1024);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, dd.batch), dim3(256), 0, s, dd);
+    return;
+  }
+  if (dd.batch > 1) {  // packed outputs (only reached when batch_can_split): one (batch*M) x N matrix
     dd.M *= dd.batch;
     dd.batch = 1;
   }

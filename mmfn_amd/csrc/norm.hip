@@ -389,7 +389,10 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ partials, int n
 
 // generic column sum: out[c] = sum_r in[r, c]   (bias gradients)
 __global__ __launch_bounds__(NT) void colsum_partial_kernel(const float* __restrict__ in, int64_t M, int C, int ld,
-                                                            int64_t rows_per_block, float* __restrict__ partials) {
+                                                            int64_t rows_per_block, float* __restrict__ partials,
+                                                            int64_t stride_in) {
+  in += (size_t)blockIdx.z * stride_in;                       // batch entry (blockIdx.z): its matrix, its partial rows
+  partials += (size_t)blockIdx.z * gridDim.x * C;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
   for (int c = blockIdx.y * NT + threadIdx.x; c < C; c += gridDim.y * NT) {
@@ -406,7 +409,10 @@ __global__ __launch_bounds__(NT) void colsum_partial_kernel(const float* __restr
   }
 }
 
-__global__ void colsum_finalize1_kernel(const float* __restrict__ partials, int nblk, int C, float* __restrict__ out) {
+__global__ void colsum_finalize1_kernel(const float* __restrict__ partials, int nblk, int C, float* __restrict__ out,
+                                        int64_t stride_out) {
+  partials += (size_t)blockIdx.y * nblk * C;                  // batch entry (blockIdx.y)
+  out += (size_t)blockIdx.y * stride_out;
   __shared__ double sh[1][FIN_LANES][FIN_COLS];
   const int c = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
   const bool valid = c < C;
@@ -583,16 +589,22 @@ extern "C" int64_t mmfn_colsum_workspace_bytes(int64_t M, int C) {
   return (int64_t)colsum_blocks(M, &rpb) * C * (int64_t)sizeof(float);
 }
 
-extern "C" int mmfn_colsum_f32(const float* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream) {
-  if (M <= 0 || C <= 0 || !workspace) return MMFN_EINVAL;
+extern "C" int mmfn_colsum_batched_f32(const float* in, int batch, int64_t stride_in, int64_t M, int C, int ld, float* out,
+                                       int64_t stride_out, void* workspace, void* stream) {
+  if (M <= 0 || C <= 0 || batch <= 0 || batch > 65535 || !workspace) return MMFN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   int64_t rpb;
   const int nblk = colsum_blocks(M, &rpb);
   float* partials = (float*)workspace;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, std::min(ceil_div(C, NT), 1024)), dim3(NT), 0, s, in, M, C, ld, rpb,
-                     partials);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, std::min(ceil_div(C, NT), 1024), batch), dim3(NT), 0, s, in, M, C, ld, rpb,
+                     partials, stride_in);
   MMFN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(colsum_finalize1_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, partials, nblk, C, out);
+  hipLaunchKernelGGL(colsum_finalize1_kernel, dim3(ceil_div(C, FIN_COLS), batch), dim3(FIN_COLS * FIN_LANES), 0, s, partials, nblk, C,
+                     out, stride_out);
   MMFN_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int mmfn_colsum_f32(const float* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream) {
+  return mmfn_colsum_batched_f32(in, 1, 0, M, C, ld, out, 0, workspace, stream);
 }

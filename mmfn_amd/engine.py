@@ -72,8 +72,35 @@ class Ctx(object):
         enqueued so far on the current stream.  Inline when no side stream is configured."""
         if self.side is None:
             return fn()
+        rec = self.recorder()
+        if rec is not None:
+            return rec.side(self.side, fn, lane_id=1)   # its own linear graph, exact eager dependencies (graphs.Recorder.side)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side), ops.lane(1):
+            fn()
+
+    def recorder(self):
+        """The lane-graph recorder while a split capture is running, else None."""
+        rec = self.engine._recorder if self.engine is not None else None
+        return rec if (rec is not None and rec.split_lanes) else None
+
+    def fork_point(self):
+        """An event at the current point of the current stream, for offload_at()."""
+        if self.side is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def offload_at(self, ev, fn):
+        """Like offload(), but ordered after the earlier fork_point() `ev` instead of after everything enqueued so far.
+        Used to enqueue side work AFTER the chain's next kernel: when a captured graph is replayed, the first-captured child
+        of a node stays on the node's hardware queue and later children move to other queues; capturing the chain's
+        continuation first keeps the dependent chain on one queue (a queue hop costs 10-16 us of idle time)."""
+        if self.side is None or ev is None:
+            return fn()
         self.side.wait_event(ev)
         with torch.cuda.stream(self.side), ops.lane(1):
             fn()
@@ -82,6 +109,9 @@ class Ctx(object):
         """Current stream waits for all offloaded work (before its input buffers are reused)."""
         if self.side is None:
             return
+        rec = self.recorder()
+        if rec is not None:
+            return rec.join(self.side)
         ev = torch.cuda.Event()
         ev.record(self.side)
         torch.cuda.current_stream().wait_event(ev)
@@ -253,9 +283,9 @@ class LayerNorm(object):
         self.w, self.b = layout.w(prefix + ".weight"), layout.w(prefix + ".bias")
         self.gw, self.gb = layout.g(prefix + ".weight"), layout.g(prefix + ".bias")
 
-    def fwd(self, ctx, x, act=ACT_NONE):
+    def fwd(self, ctx, x, act=ACT_NONE, out=None):
         M, C = x.shape
-        y = ctx.bufs.get(self.name + ".y", (M, C))
+        y = ctx.bufs.get(self.name + ".y", (M, C)) if out is None else out
         mean, rstd = ctx.bufs.get(self.name + ".mu", (M,)), ctx.bufs.get(self.name + ".rs", (M,))
         ops.layernorm_fwd(x, self.w, self.b, y, mean, rstd, act)
         self.saved = (x, mean, rstd, act)
@@ -267,7 +297,7 @@ class LayerNorm(object):
         x, mean, rstd, act = self.saved
         dx = ctx.bufs.get(self.name + ".dx", x.shape) if out is None else out
         rng = ctx.rng_state if dropped is not None else None
-        if defer and ctx.side is not None and DEFER_LN_REDUCTIONS:
+        if (defer is True or isinstance(defer, list)) and ctx.side is not None and DEFER_LN_REDUCTIONS:
             # the chain only needs dx: the reduction of the per-block partial rows into the weight / bias gradients (and the
             # consuming Linear's bias gradient) goes to the side stream, like the weight-gradient GEMMs (0.8 ms of ~11 us
             # launches per step off the transformers' dependent chain); own partial buffer, it must outlive this call
@@ -276,7 +306,11 @@ class LayerNorm(object):
             part = ctx.bufs.get(self.name + ".part", (rows, 3 if colsum is not None else 2, C))
             ops.layernorm_bwd_partial(g, x, self.w, self.b, mean, rstd, dx, part, act, dres=dres, dx_dropped=dropped, drop_p=drop_p,
                                       rng_state=rng, rng_stream=rng_stream, want_colsum=colsum is not None)
-            ctx.offload(lambda: ops.layernorm_bwd_finalize(part, rows, C, self.gw, self.gb, colsum))
+            fin = lambda: ops.layernorm_bwd_finalize(part, rows, C, self.gw, self.gb, colsum)
+            if isinstance(defer, list):
+                defer.append(fin)      # the caller decides where the reductions run (GPT.bwd: one fork per block / none)
+            else:
+                ctx.offload(fin)
             return dx
         ops.layernorm_bwd(g, x, self.w, self.b, mean, rstd, dx, self.gw, self.gb, act, dres=dres, dx_dropped=dropped,
                           drop_p=drop_p, rng_state=rng, rng_stream=rng_stream, dx_colsum=colsum)
@@ -284,6 +318,25 @@ class LayerNorm(object):
 
 
 # ----------------------------------------------------------------------------- GPT fusion transformer
+GPT_LATE_FORK = os.environ.get("MMFN_GPT_LATE_FORK", "1") == "1"   # A/B: see Ctx.offload_at
+GPT_FORK_EACH = os.environ.get("MMFN_GPT_FORK_EACH", "0") == "1"   # A/B: fork every piece of side work where it arises (round-2a behaviour)
+
+
+class _ForkEach(list):
+    """list stand-in whose append() forks the closure to the side stream immediately."""
+
+    def __init__(self, ctx):
+        list.__init__(self)
+        self.ctx = ctx
+
+    def append(self, fn):
+        self.ctx.offload(fn)
+
+
+GPT_GROUP_MIN_C = int(os.environ.get("MMFN_GPT_GROUP_MIN_C", "512"))
+GPT_GROUP_MAX_C = int(os.environ.get("MMFN_GPT_GROUP_MAX_C", "512"))   # widest transformer whose weight gradients run as batched launches
+
+
 class GPT(object):
     """model_vec.py:136-246 (GPT), :112-133 (Block), :73-109 (SelfAttention)."""
 
@@ -312,6 +365,25 @@ class GPT(object):
             blk["bqkv"], blk["g_bqkv"] = layout.packed(bp + ".attn.key.bias", 3 * C)
             self.blocks.append(blk)
         self.ln_f = LayerNorm(name + ".ln_f", layout, prefix + ".ln_f")
+        # The eight blocks are laid out one after the other in the flat buffer, every block with the same tensors: block i's
+        # gradient of any tensor is block 0's + i * stride.  That lets ONE batched launch write the same weight gradient of
+        # all blocks (bwd, `grouped`).
+        self.block_stride = None
+        if len(self.blocks) > 1:
+            keys = [("fc1", "gw"), ("fc1", "gb"), ("fc2", "gw"), ("proj", "gw")]
+            def off(blk, k):
+                t = getattr(blk[k[0]], k[1])
+                return t.data_ptr()
+            strides = set()
+            for k in keys:
+                for i in range(1, len(self.blocks)):
+                    strides.add((off(self.blocks[i], k) - off(self.blocks[i - 1], k)) // 4)
+            for i in range(1, len(self.blocks)):
+                strides.add((self.blocks[i]["g_wqkv"].data_ptr() - self.blocks[i - 1]["g_wqkv"].data_ptr()) // 4)
+                strides.add((self.blocks[i]["g_bqkv"].data_ptr() - self.blocks[i - 1]["g_bqkv"].data_ptr()) // 4)
+            if len(strides) == 1:
+                self.block_stride = strides.pop()
+        self.grouped = self.block_stride is not None and GPT_GROUP_MIN_C <= self.C <= GPT_GROUP_MAX_C
 
     def fwd(self, ctx, feats, velocity):
         B = feats[0].shape[0]
@@ -326,12 +398,17 @@ class GPT(object):
         x = x.view(M, C)
         self.acts = []
         scale = 1.0 / math.sqrt(hs)
+        nb = len(self.blocks)
+        # the activations the weight gradients read again, stacked over the blocks (one batched launch per weight in bwd)
+        S_a, S_a2 = bufs.get(nm + ".S.a", (nb, M, C)), bufs.get(nm + ".S.a2", (nb, M, C))
+        S_o, S_h = bufs.get(nm + ".S.att", (nb, M, C)), bufs.get(nm + ".S.h", (nb, M, 4 * C))
+        self.stacks = (S_a, S_a2, S_o, S_h)
         for i, blk in enumerate(self.blocks):
             sb = self.stream_base + 1 + 3 * i
-            a = blk["ln1"].fwd(ctx, x)
+            a = blk["ln1"].fwd(ctx, x, out=S_a[i])
             qkv = bufs.get("%s.b%d.qkv" % (nm, i), (M, 3 * C))
             ops.linear_fwd(a, blk["wqkv"], blk["bqkv"], out=qkv)
-            o = bufs.get("%s.b%d.att" % (nm, i), (M, C))
+            o = S_o[i]
             lse = bufs.get("%s.b%d.lse" % (nm, i), (B, nh, T))
             # packed columns: [key | query | value]  (reference registration order, model_vec.py:82-84)
             ops.attention_fwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, C, lse, B, T, nh, hs, scale, drop_p=p_attn,
@@ -339,8 +416,8 @@ class GPT(object):
             x1 = bufs.get("%s.b%d.x1" % (nm, i), (M, C))
             ops.linear_fwd(o, blk["proj"].w, blk["proj"].b, out=x1, res=x, ldr=C, drop_p=p_resid, rng_state=ctx.rng_state,
                            rng_stream=sb + 1)
-            a2 = blk["ln2"].fwd(ctx, x1)
-            h = bufs.get("%s.b%d.h" % (nm, i), (M, 4 * C))
+            a2 = blk["ln2"].fwd(ctx, x1, out=S_a2[i])
+            h = S_h[i]
             ops.linear_fwd(a2, blk["fc1"].w, blk["fc1"].b, out=h, relu=True)
             x2 = bufs.get("%s.b%d.x2" % (nm, i), (M, C))
             ops.linear_fwd(h, blk["fc2"].w, blk["fc2"].b, out=x2, res=x1, ldr=C, drop_p=p_resid, rng_state=ctx.rng_state,
@@ -361,47 +438,93 @@ class GPT(object):
         scale = 1.0 / math.sqrt(hs)
         nblk = len(self.blocks)
         drop = p_resid > 0.0
+        grouped = self.grouped and ctx.side is not None
         # the LayerNorm backward that produces a block's incoming gradient also writes its dropped copy (the residual
         # dropouts of the forward sit in GEMM epilogues; their masks are re-applied here without an extra pass)
         sb_of = lambda i: self.stream_base + 1 + 3 * i
-        gd = bufs.get("%s.b%d.gdrop" % (nm, nblk - 1), (M, C)) if drop else None
+        # Per-block gradient tensors, stacked over the blocks: G[i] = gradient arriving at block i's output, GD[i] its dropped copy
+        # (what enters the MLP branch), G1 / GD2 the same for the attention branch, GH / DQKV the gradients of the hidden / qkv
+        # activations.  The side stream reads them for the weight gradients, so they are per block and it may lag by any number
+        # of blocks: one rejoin at the end of the transformer.
+        G = bufs.get(nm + ".S.g", (nblk, M, C))
+        GD = bufs.get(nm + ".S.gdrop", (nblk, M, C)) if drop else None
+        G1 = bufs.get(nm + ".S.g1", (nblk, M, C))
+        GD2 = bufs.get(nm + ".S.gdrop2", (nblk, M, C)) if drop else None
+        GH = bufs.get(nm + ".S.gh", (nblk, M, 4 * C))
+        DQKV = bufs.get(nm + ".S.dqkv", (nblk, M, 3 * C))
         # ... and its column sums, which are the bias gradient of the Linear that closes the residual branch (mlp.2 / attn.proj)
-        g = self.ln_f.bwd(ctx, g_y.view(M, C), dropped=gd, drop_p=p_resid, rng_stream=sb_of(nblk - 1) + 2,
-                          colsum=self.blocks[nblk - 1]["fc2"].gb, defer=True)
+        # Side work (everything that only feeds the optimizer) is collected and forked to the side stream ONCE per block: in a
+        # replayed graph every fork moves the continuation of the chain to another hardware queue, and each such hop costs
+        # 10-16 us of idle time (profiles/r02c_graph_timeline.txt) - with a fork per weight gradient and per LayerNorm
+        # reduction (7 per block) that was 0.3 ms per transformer.  Grouped transformers (C <= 256) do not fork at all: their
+        # side work runs as a handful of batched launches after the chain, and the whole backward is one linear graph.
+        side = _ForkEach(ctx) if GPT_FORK_EACH else []
+        pending = None
+        g = self.ln_f.bwd(ctx, g_y.view(M, C), out=G[nblk - 1], dropped=GD[nblk - 1] if drop else None, drop_p=p_resid,
+                          rng_stream=sb_of(nblk - 1) + 2, colsum=self.blocks[nblk - 1]["fc2"].gb, defer=side)
         for i in range(nblk - 1, -1, -1):
             blk = self.blocks[i]
             sb = sb_of(i)
             x, a, qkv, o, lse, x1, a2, h = self.acts[i]
-            # Weight / bias gradients only feed the optimizer, so they go to the side stream (ctx.offload) while the
-            # dX chain continues.  Every buffer the side stream reads (gdrop*, gh, dqkv, the block's incoming g) is PER BLOCK,
-            # so the side stream may lag the main one by any number of blocks: one rejoin at the end of the transformer
-            # instead of one per block (at C = 64 / 128 the side stream's 16 launches per block outlast the main stream's 10).
+            # Weight / bias gradients only feed the optimizer, so they go to the side stream (ctx.offload) while the dX chain
+            # continues: block by block for the wide transformer (its weight-gradient GEMMs are as big as the chain's), and
+            # for C <= 256 - where a block's 14 side launches of 8-11 us each outlast its chain - as ONE batched launch per
+            # weight over all blocks after the chain (below).
             # ---- MLP branch: x2 = x1 + drop(fc2(relu(fc1(ln2(x1)))))
-            gp = gd if drop else g
-            ctx.offload(lambda gp=gp, blk=blk, h=h: ops.linear_dw(gp, h, out=blk["fc2"].gw))   # fc2.gb: from the LayerNorm backward
-            gh = bufs.get("%s.b%d.gh" % (nm, i), (M, 4 * C))
+            gp = GD[i] if drop else g
+            if not grouped:
+                side.append(lambda gp=gp, blk=blk, h=h: ops.linear_dw(gp, h, out=blk["fc2"].gw))   # fc2.gb: from the LayerNorm backward
+            gh = GH[i]
             ops.linear_dx(gp, blk["fc2"].w, out=gh, aux=h, ldaux=4 * C)
-            ctx.offload(lambda gh=gh, blk=blk, a2=a2: (ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
+            if pending is not None:
+                ctx.offload_at(pending[0], lambda work=pending[1]: [f() for f in work])
+                pending = None
+            if not grouped:
+                side.append(lambda gh=gh, blk=blk, a2=a2: (ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
             ga2 = bufs.get(nm + ".ga", (M, C))
             ops.linear_dx(gh, blk["fc1"].w, out=ga2)
-            gd2 = bufs.get("%s.b%d.gdrop2" % (nm, i), (M, C)) if drop else None
-            g1 = blk["ln2"].bwd(ctx, ga2, dres=g, out=bufs.get("%s.b%d.g1" % (nm, i), (M, C)), dropped=gd2, drop_p=p_resid,
-                                rng_stream=sb + 1, colsum=blk["proj"].gb, defer=True)
+            g1 = blk["ln2"].bwd(ctx, ga2, dres=g, out=G1[i], dropped=GD2[i] if drop else None, drop_p=p_resid,
+                                rng_stream=sb + 1, colsum=blk["proj"].gb, defer=side)
             # ---- attention branch: x1 = x + drop(proj(att(ln1(x))))
-            gp = gd2 if drop else g1
-            ctx.offload(lambda gp=gp, blk=blk, o=o: ops.linear_dw(gp, o, out=blk["proj"].gw))   # proj.gb: from ln2's backward
+            gp = GD2[i] if drop else g1
+            if not grouped:
+                side.append(lambda gp=gp, blk=blk, o=o: ops.linear_dw(gp, o, out=blk["proj"].gw))   # proj.gb: from ln2's backward
             go = bufs.get(nm + ".go", (M, C))
             ops.linear_dx(gp, blk["proj"].w, out=go)
-            dqkv = bufs.get("%s.b%d.dqkv" % (nm, i), (M, 3 * C))
+            dqkv = DQKV[i]
             delta = bufs.get(nm + ".delta", (B, nh, T))
             ops.attention_bwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, go, C, lse, delta, dqkv[:, C:], dqkv, dqkv[:, 2 * C:],
                               3 * C, B, T, nh, hs, scale, drop_p=p_attn, rng_state=ctx.rng_state, rng_stream=sb)
-            ctx.offload(lambda dqkv=dqkv, blk=blk, a=a: (ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
+            if not grouped:
+                side.append(lambda dqkv=dqkv, blk=blk, a=a: (ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
             ga = bufs.get(nm + ".ga2", (M, C))
             ops.linear_dx(dqkv, blk["wqkv"], out=ga)
-            gd = bufs.get("%s.b%d.gdrop" % (nm, i - 1), (M, C)) if (drop and i > 0) else None
-            g = blk["ln1"].bwd(ctx, ga, dres=g1, out=bufs.get("%s.b%d.g0" % (nm, i), (M, C)), dropped=gd, drop_p=p_resid,
-                               rng_stream=sb_of(i - 1) + 2, colsum=self.blocks[i - 1]["fc2"].gb if i > 0 else None, defer=True)
+            g = blk["ln1"].bwd(ctx, ga, dres=g1, out=G[i - 1] if i > 0 else bufs.get(nm + ".g_tok", (M, C)),
+                               dropped=GD[i - 1] if (drop and i > 0) else None, drop_p=p_resid,
+                               rng_stream=sb_of(i - 1) + 2, colsum=self.blocks[i - 1]["fc2"].gb if i > 0 else None, defer=side)
+            if not grouped and not GPT_FORK_EACH:   # this block's side work: one fork, behind everything the chain has enqueued so far
+                work, side = side, []
+                if GPT_LATE_FORK and ctx.recorder() is None:
+                    pending = (ctx.fork_point(), work)   # enqueued after the next block's first kernel (Ctx.offload_at)
+                else:
+                    ctx.offload(lambda work=work: [f() for f in work])
+        if pending is not None:
+            ctx.offload_at(pending[0], lambda work=pending[1]: [f() for f in work])
+        if grouped:
+            S_a, S_a2, S_o, S_h = self.stacks
+            b0, st = self.blocks[0], self.block_stride
+
+            def all_blocks():
+                ops.linear_dw_batched(GD if drop else G, S_h, b0["fc2"].gw, st)
+                ops.colsum_batched(GH, b0["fc1"].gb, st)
+                ops.linear_dw_batched(GH, S_a2, b0["fc1"].gw, st)
+                ops.linear_dw_batched(GD2 if drop else G1, S_o, b0["proj"].gw, st)
+                ops.colsum_batched(DQKV, b0["g_bqkv"], st)
+                ops.linear_dw_batched(DQKV, S_a, b0["g_wqkv"], st)
+
+            all_blocks()
+            for f in side:     # the LayerNorm reductions (17 small launches)
+                f()
         ctx.rejoin()
         gtok = g.view(B, T, C)
         ops.tokens_bwd(gtok, self.velocity, self.g_pos.view(T, C), self.vel.gw.view(C), self.vel.gb, p_embd, ctx.rng_state,

@@ -1,22 +1,27 @@
-"""Lane graphs: a step replayed as a sequence of LINEAR hipGraphs, one per branch lane and per stretch of the main
-stream, stitched with eager HIP events.
+"""Replay of a captured step, and the optional "lane graph" scheme.
+
+Default (MMFN_LANE_GRAPHS=0): the step is captured into one hipGraph per stretch between data-parallel hooks (one graph on a
+single GPU), with the branch lanes and the side work forked INSIDE it.  Two things measured on gfx950 / ROCm 7 shape how the
+engine forks (profiles/r02c_graph_timeline.txt, tools/queue_overlap.py):
+  * when such a graph is replayed, the first-captured child of a node stays on the node's hardware queue and later children move
+    to other queues; a dependent chain that hops queues idles 10-16 us per hop.  The engine therefore forks side work once per
+    transformer block (not per weight gradient) and captures the chain's next kernel BEFORE the side branch (Ctx.offload_at):
+    the chain stays on one queue.  7 forks per block -> 1 late fork: 39.3 -> 37.9 ms on the same box;
+  * replaying a graph with cross-stream edges costs the host ~5 us per kernel node (6-7 ms per step), a linear graph ~0.4 us.
+
+Lane graphs (MMFN_LANE_GRAPHS=1): every branch lane and every piece of side work is its own LINEAR hipGraph on its own stream,
+stitched with eager HIP events:
 
     main graph | fork event | lane graph on side stream 0 | lane graph on side stream 1 | main-lane graph | join | ...
 
-Why not one hipGraph with the branch streams forked inside it (round 1): measured on gfx950 / ROCm 7
-(tools/experiments/host_ahead.py, lane_overlap.py), replaying a graph that contains cross-stream edges costs the host
-~5 us per kernel node (the runtime walks the DAG and wires signals at launch), a linear graph ~0.4 us (pre-built packets
-copied into the queue).  For the 2227-kernel training step that is 6.0-7.7 ms of host time per replay against 3.1-4.4 ms
-for the 33 linear graphs - it matters once eight ranks share the node's cores - and for lanes of small kernels the forked
-graph is host-bound outright (three lanes of 20 x [64-tile GEMM + 3 LayerNorms]: 1092 us forked, 845 us stitched).  On the
-single-GPU training step both schemes replay in the same 37.4 ms: there the lanes overlap as far as the chip lets them
-(tools/experiments/segment_times.py: lanes alone 20.0 ms, overlapped 15.7; a chip-filling GEMM of one lane leaves the
-other lanes' kernels waiting for CUs either way).
+Exact dependencies (the side work of a transformer block starts the moment the block's chain is through) and 1.5-2.8 ms of
+host time per step instead of 6-7, but 40-90 us of idle time wherever the main stream passes from one graph to the next:
+35.6 vs 35.2 ms per step on one GPU (tools/ab_bench.sh), so it is the option, not the default; for lanes of small kernels
+(tools/experiments/lane_overlap.py: 3 x 20 x [64-tile GEMM + 3 LayerNorms]) it wins, 845 vs 1092 us.
 
-Engine._branches() calls Recorder.branches() while a Recorder is attached; everything else (the fusion transformers, whose
-weight-gradient GEMMs fork to the side stream and rejoin inside one graph) is captured into the current main graph.
-Data-parallel hooks (gradient-bucket all-reduces through torch.distributed, which cannot be captured) are cut points too.
-MMFN_LANE_GRAPHS=0 keeps the lanes as forks inside the main graphs (A/B switch).
+Engine._branches() / Ctx.offload() / Ctx.rejoin() call Recorder.branches() / side() / join() while a lane-graph Recorder is
+attached.  Data-parallel hooks (gradient-bucket all-reduces through torch.distributed, which cannot be captured) are cut
+points in both schemes.
 """
 import gc
 import os
@@ -27,9 +32,10 @@ import torch
 class Recorder(object):
     def __init__(self, engine, split_lanes=None):
         self.engine = engine
-        # MMFN_LANE_GRAPHS=0: keep the branch lanes as forks inside one graph (the round-1 scheme, for A/B measurements)
-        self.split_lanes = (os.environ.get("MMFN_LANE_GRAPHS", "1") == "1") if split_lanes is None else bool(split_lanes)
-        self.ops = []           # ("graph", g) | ("lanes", fork_event, [(stream, g, done_event), ...]) | ("join", [events]) | ("call", fn)
+        # MMFN_LANE_GRAPHS=1: every branch lane / piece of side work its own linear graph (module docstring); default: forks inside
+        # the main graphs
+        self.split_lanes = (os.environ.get("MMFN_LANE_GRAPHS", "0") == "1") if split_lanes is None else bool(split_lanes)
+        self.ops = []           # ("graph", g) | ("lanes", fork, [(stream, g, done), ...]) | ("join", [events]) | ("side", ev, stream, g) | ("wait", ev, stream) | ("call", fn)
         self._g = None
         self.n_graphs = 0
 
@@ -100,6 +106,29 @@ class Recorder(object):
             outs.extend(so)
         return outs
 
+    def side(self, stream, fn, lane_id=1):
+        """fn's launches (work that only feeds the optimizer) as a linear graph of their own on `stream`, ordered after
+        everything the main stream has captured so far and NOT joined back here: the main stream continues at once, a later
+        join(stream) waits for it.  Inside one captured graph such a fork is replayed with coarse dependencies - measured: the
+        side work of all eight blocks of a transformer started only when the chain was nearly through, and every fork moved
+        the chain to another hardware queue (10-16 us idle per hop); an eager event between two linear graphs is exact."""
+        from . import ops
+        self._end()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream), ops.lane(lane_id):
+            g.capture_begin(capture_error_mode="thread_local")
+            fn()
+            g.capture_end()
+        self.n_graphs += 1
+        self.ops.append(("side", torch.cuda.Event(), stream, g))
+        self._begin()
+
+    def join(self, stream):
+        """The main stream waits for everything replayed on `stream` so far."""
+        self._end()
+        self.ops.append(("wait", torch.cuda.Event(), stream))
+        self._begin()
+
     # ------------------------------------------------------------------ replay
     def replay(self):
         main = torch.cuda.current_stream()
@@ -118,5 +147,14 @@ class Recorder(object):
             elif kind == "join":
                 for d in op[1]:
                     main.wait_event(d)
+            elif kind == "side":
+                _, ev, st, g = op
+                ev.record(main)
+                st.wait_event(ev)
+                with torch.cuda.stream(st):
+                    g.replay()
+            elif kind == "wait":
+                op[1].record(op[2])
+                main.wait_event(op[1])
             else:
                 op[1]()

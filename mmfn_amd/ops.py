@@ -754,6 +754,24 @@ def colsum(x2d, out, M=None, C=None, ld=None):
     return out
 
 
+def colsum_batched(x3d, out0, stride_out):
+    """out0 + z*stride_out <- column sums of x3d[z] for every z (x3d: [batch, M, C] contiguous); out0: the first entry's [C] view
+    of a buffer in which the entries are stride_out floats apart (bias gradients of a transformer's blocks in the flat buffer)."""
+    nb, M, C = x3d.shape
+    need = nb * lib().mmfn_colsum_workspace_bytes(M, C)
+    _call("mmfn_colsum_batched_f32", ptr(x3d), nb, M * C, M, C, C, ptr(out0), int(stride_out), ptr(norm_workspace(x3d.device, need)),
+          stream())
+
+
+def linear_dw_batched(dy3d, x3d, out0, stride_out, **epi):
+    """dw[z] = dy3d[z]^T @ x3d[z] for every z in one (split-K) launch; dy3d [batch, M, N], x3d [batch, M, K] contiguous,
+    out0 = entry 0's [N, K] view, the entries stride_out floats apart."""
+    nb, M, N = dy3d.shape
+    K = x3d.shape[2]
+    return gemm(dy3d, x3d, out0, N, K, M, N, K, out0.stride(0), A_COLMAJOR, B_KN, batch=nb, strideA=M * N, strideB=M * K,
+                strideC=int(stride_out), **epi)
+
+
 # ---------------------------------------------------------------- pooling / tokens / upsample
 def maxpool_fwd(x, y, idx):
     B, H, W, C = x.shape
