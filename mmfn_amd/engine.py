@@ -333,8 +333,8 @@ class _ForkEach(list):
         self.ctx.offload(fn)
 
 
-GPT_GROUP_MIN_C = int(os.environ.get("MMFN_GPT_GROUP_MIN_C", "512"))
-GPT_GROUP_MAX_C = int(os.environ.get("MMFN_GPT_GROUP_MAX_C", "512"))   # widest transformer whose weight gradients run as batched launches
+GPT_GROUP_MIN_C = int(os.environ.get("MMFN_GPT_GROUP_MIN_C", "0"))
+GPT_GROUP_MAX_C = int(os.environ.get("MMFN_GPT_GROUP_MAX_C", "0"))   # widest transformer whose weight gradients run as batched launches
 
 
 class GPT(object):

@@ -241,6 +241,38 @@ def test_raw_sensor_ingest_path_equals_tensor_path():
     assert torch.equal(pred, ref)
 
 
+def test_batched_transformer_weight_gradients_equal_per_block_ones(monkeypatch):
+    """engine.GPT `grouped` mode (MMFN_GPT_GROUP_MAX_C): the weight / bias gradients of all blocks of a transformer from one batched
+    split-K launch per weight (strided outputs in the flat gradient buffer, stacked per-block activations) instead of one launch
+    per block: same gradients up to the rounding of a different split, same loss."""
+    from mmfn_amd import engine
+    _, net_a, batch, args = _setup("vec", dropout=0.1)
+    net_a._engine_for()                                   # engines are built at first use: build this one un-grouped
+    monkeypatch.setattr(engine, "GPT_GROUP_MIN_C", 0)
+    monkeypatch.setattr(engine, "GPT_GROUP_MAX_C", 512)
+    _, net_b, _, _ = _setup("vec", dropout=0.1)
+    assert all(g.grouped for g in net_b._engine_for().gpts) and not any(g.grouped for g in net_a._engine_for().gpts)
+    dargs = _dev_args(args)
+    gt = batch["gt_wp"].to(DEV)
+    losses = []
+    for net in (net_a, net_b):
+        net.train()
+        eng = net._engine_for()
+        inp = net._pack(*dargs)
+        _, loss = eng.forward(inp, True, gt)
+        eng.backward()
+        losses.append(loss.item())
+    assert losses[0] == losses[1]
+    ga, gb = net_a._layout.grads, net_b._layout.grads
+    n = net_a._layout.tail
+    err = (ga[:n] - gb[:n]).abs().max().item()
+    assert err <= 2e-5 * ga[:n].abs().max().item(), err
+    names = [k for k in net_a._layout.grad_views if "transformer" in k and ("mlp.0" in k or "attn.proj" in k or "key" in k)]
+    for k in names:
+        a, b = net_a._layout.grad_views[k], net_b._layout.grad_views[k]
+        assert (a - b).abs().max().item() <= 1e-5 * max(a.abs().max().item(), 1e-6), k
+
+
 def test_segmented_graph_step_equals_eager_steps():
     """parallel.GraphedStep (linear hipGraphs per branch lane, cut at the gradient-bucket boundaries under data parallelism) replays to exactly the
     parameters the eager train_step produces, dropout included (counter RNG advances on the device)."""

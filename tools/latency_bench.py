@@ -21,10 +21,8 @@ def main():
     lanes = rng.randn(40, 10, 5).astype(np.float32)
     out = {}
     eng = net._engine_for()
-    modes = (("hipgraph", True, "1", True), ("hipgraph_forked_in_one_graph", True, "0", True), ("hipgraph_single_stream", True, "1", False),
-             ("eager", False, "1", True))
-    for name, use_graph, lane_graphs, multi in modes:
-        os.environ["MMFN_LANE_GRAPHS"] = lane_graphs
+    modes = (("hipgraph", True, True), ("hipgraph_single_stream", True, False), ("eager", False, True))
+    for name, use_graph, multi in modes:
         eng.multi_stream = multi
         sess = DrivingSession(net, use_graph=use_graph)
         for _ in range(5):
