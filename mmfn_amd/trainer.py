@@ -22,7 +22,7 @@ import torch
 
 from . import data as D
 from . import ops
-from .parallel import StaticBatchStep
+from .parallel import StaticBatchStep, StaticEvalStep
 
 
 class Trainer(object):
@@ -105,14 +105,43 @@ class Trainer(object):
         return self.train_loss[-1]
 
     # ------------------------------------------------------------------ validation (no grad, eval-mode BN, no dropout)
-    def validate(self, model, dataloader_val, config):
+    def validate(self, model, dataloader_val, config, graph=True, lane_bucket=16):
+        """Mean L1 loss over the validation set in eval mode (phase2_train_net.py:124-177).  graph=True: as in train(), the
+        second batch of a shape captures the forward into a hipGraph over static inputs (parallel.StaticEvalStep) and later
+        batches of that shape replay it; lane sets are padded to a multiple of `lane_bucket` (padded lanes are masked by
+        lane_num: the loss is unchanged)."""
         model.eval()
         eng = model._engine_for()
+        if not hasattr(self, "_static_evals"):
+            self._static_evals = {}      # input-shape signature -> "seen" | "eager" | StaticEvalStep, in LRU order
+            self._retired_evals = []
         total = torch.zeros(1, dtype=torch.float32, device=model._layout.device)
         num_batches = 0
         with torch.no_grad():
             for args, gt in D.DevicePrefetcher(dataloader_val, self.device, config, variant=model.variant):
-                _, loss = eng.forward(args if isinstance(args, dict) else model._pack(*args), False, gt)
+                inp = args if isinstance(args, dict) else model._pack(*args)
+                if graph:
+                    inp = _bucket_lanes(inp, lane_bucket)
+                    sig = StaticBatchStep.signature(inp, gt)
+                    state = self._static_evals.pop(sig, None)
+                    if state is None:
+                        state = "seen"
+                        _, loss = eng.forward(inp, False, gt)
+                    else:
+                        if state == "seen":
+                            try:
+                                state = StaticEvalStep(eng, inp, gt)
+                            except RuntimeError as exc:
+                                import warnings
+                                warnings.warn("hipGraph capture of the validation step failed (%s); continuing with eager launches" % exc)
+                                torch.cuda.synchronize()
+                                state = "eager"
+                        loss = eng.forward(inp, False, gt)[1] if state == "eager" else state(inp, gt)
+                    self._static_evals[sig] = state
+                    while len(self._static_evals) > self.max_captured_shapes:
+                        self._retired_evals.append(self._static_evals.pop(next(iter(self._static_evals))))
+                else:
+                    _, loss = eng.forward(inp, False, gt)
                 total += loss
                 num_batches += 1
         if num_batches:

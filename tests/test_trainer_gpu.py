@@ -148,6 +148,32 @@ def test_graph_replay_epoch_equals_eager_epoch(store):
     assert nets[0][0] == nets[1][0] and worst[0] == 0.0, (nets[0][0], nets[1][0], worst)
 
 
+def test_graph_replayed_validation_equals_eager_validation(store):
+    """Trainer.validate(graph=True): the eval forward captured per input shape and replayed over changing batches gives the same
+    validation loss as eager launches, before and after the weights change (the capture reads the weights at replay time)."""
+    from mmfn_amd import data as D
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd import model as M
+    from mmfn_amd.optim import FusedAdamW
+    from mmfn_amd.parallel import StaticEvalStep
+    from mmfn_amd.trainer import Trainer
+    from oracle import harness
+    oracle = harness.build_oracle("vec", dropout=0.0)
+    cfg = GlobalConfig(embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0)
+    loader = D.make_loader(store, batch_size=1, num_workers=0)  # 4 batches with 5 / 9 / 3 / 7 lanes -> one 16-lane bucket
+    net = M.MMFN(cfg, DEV)
+    net.load_state_dict(oracle.state_dict(), strict=True)
+    tr_g, tr_e = Trainer(DEV, None), Trainer(DEV, None)
+    opt = FusedAdamW(net, lr=1e-3)
+    for _ in range(2):
+        vg = tr_g.validate(net, loader, cfg, graph=True)
+        ve = tr_e.validate(net, loader, cfg, graph=False)
+        assert vg == ve, (vg, ve)
+        tr_g.train(net, loader, cfg, opt, graph=False)     # move the weights, then validate again through the same capture
+    assert len(tr_g._static_evals) == 1 and isinstance(next(iter(tr_g._static_evals.values())), StaticEvalStep)
+    assert tr_g.val_loss[0] != tr_g.val_loss[1]
+
+
 def test_param_groups_match_torch_adamw_and_round_trip(store, tmp_path):
     """The reference's decay / no-decay groups (model_vec.py:179-209) through FusedAdamW == torch.optim.AdamW with the same
     groups; the multi-group optimizer state file loads into torch's optimizer and back."""
