@@ -103,7 +103,9 @@ enum {
   MMFN_EPI_BF16_OPERANDS = 128, /* opt-in mixed precision for plain GEMM forms: A and B rounded to bf16 on the way into LDS,
                                   bf16 MFMA, fp32 accumulate / epilogue / output (autocast-style; BASELINE configs[2]) */
   MMFN_EPI_BF16X3 = 256    /* fp32 arithmetic on the bf16 MFMA pipe (plain GEMM forms): each operand element split exactly
-                              into three bf16 terms, six cross products accumulated in fp32: product error < 2^-22 relative */
+                              into three bf16 terms, six cross products accumulated in fp32: product error < 2^-22 relative */,
+  MMFN_EPI_RELU_LAST = 512 /* max(v, 0) as the LAST step, after residual / accumulate: conv + folded BatchNorm + skip + ReLU in one
+                              launch (eval mode, mmfn_bn_fold_f32) */
 };
 
 typedef struct mmfn_gemm_desc {
@@ -155,6 +157,11 @@ int mmfn_bn_finalize_stats_f32(const double* partials, int nblk, int64_t M, int 
 int mmfn_bn_eval_prepare_f32(const float* running_mean, const float* running_var, float eps, int C, float* mean,
                              float* rstd, void* stream);
 /* y = [relu]( (x - mean) * rstd * weight + bias [+ res] ) */
+/* Eval-mode BatchNorm folded into the preceding convolution: w_out[co][k] = w[co][k] * s[co], b_out[co] = beta[co] - mean[co] * s[co],
+ * s = gamma * rsqrt(var + eps) over the RUNNING statistics (model_vec.py:509-593 in eval mode); the convolution then runs with
+ * bias = b_out (+ residual, MMFN_EPI_RELU / MMFN_EPI_RELU_LAST).  K = KH*KW*Cin elements per output channel. */
+int mmfn_bn_fold_f32(const float* w, int Cout, int K, const float* gamma, const float* beta, const float* running_mean,
+                     const float* running_var, float eps, float* w_out, float* b_out, void* stream);
 int mmfn_bn_apply_f32(const float* x, const float* res, float* y, int64_t M, int C, const float* mean, const float* rstd,
                       const float* weight, const float* bias, int relu, void* stream);
 /* backward of y = relu?(bn(x) [+res]): g = dL/dy; if y != NULL the ReLU mask (y > 0) is applied first.

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("MMFN_HIP_LIB") or os.path.join(_HERE, "lib", "libmmfn
 A_ROWMAJOR, A_COLMAJOR, A_IM2COL, A_DGRAD = 0, 1, 2, 3
 B_NK, B_KN, B_IM2COL, B_DGRADW = 0, 1, 2, 3
 EPI_BIAS, EPI_RELU, EPI_GELU, EPI_MASK_AUX, EPI_DROPOUT, EPI_RESIDUAL, EPI_ACCUM, EPI_BF16_OPERANDS, EPI_BF16X3 = 1, 2, 4, 8, 16, 32, 64, 128, 256
+EPI_RELU_LAST = 512
 
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32

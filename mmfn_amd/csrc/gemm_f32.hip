@@ -59,6 +59,7 @@ __device__ __forceinline__ void epilogue_store(const mmfn_gemm_desc& d, uint64_t
   if (f & MMFN_EPI_RESIDUAL) v += d.res[(size_t)row * d.ldr + col];
   float* c = d.C + (size_t)row * d.ldc + col;
   if (f & MMFN_EPI_ACCUM) v += *c;
+  if (f & MMFN_EPI_RELU_LAST) v = fmaxf(v, 0.0f);
   *c = v;
 }
 

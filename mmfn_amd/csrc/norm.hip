@@ -156,6 +156,16 @@ __global__ void bn_eval_prepare_kernel(const float* __restrict__ rm, const float
   rstd[c] = 1.0f / sqrtf(rv[c] + eps);
 }
 
+__global__ __launch_bounds__(NT) void bn_fold_kernel(const float* __restrict__ w, int K, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ rm,
+                                                     const float* __restrict__ rv, float eps, float* __restrict__ w_out,
+                                                     float* __restrict__ b_out) {
+  const int co = blockIdx.x;
+  const float s = gamma[co] / sqrtf(rv[co] + eps);
+  for (int k = threadIdx.x; k < K; k += NT) w_out[(size_t)co * K + k] = w[(size_t)co * K + k] * s;
+  if (threadIdx.x == 0) b_out[co] = beta[co] - rm[co] * s;
+}
+
 // y = [relu]( x * alpha + beta [+ res] ), alpha = w * rstd, beta = b - mean * alpha
 __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                       float* __restrict__ y, int64_t total4, int C,
@@ -459,6 +469,15 @@ extern "C" int mmfn_bn_eval_prepare_f32(const float* running_mean, const float* 
                                         float* rstd, void* stream) {
   hipLaunchKernelGGL(bn_eval_prepare_kernel, dim3(ceil_div(C, 128)), dim3(128), 0, (hipStream_t)stream, running_mean,
                      running_var, eps, C, mean, rstd);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_bn_fold_f32(const float* w, int Cout, int K, const float* gamma, const float* beta, const float* running_mean,
+                                const float* running_var, float eps, float* w_out, float* b_out, void* stream) {
+  if (!w || !w_out || !b_out || Cout <= 0 || K <= 0) return MMFN_EINVAL;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(Cout), dim3(NT), 0, (hipStream_t)stream, w, K, gamma, beta, running_mean, running_var, eps,
+                     w_out, b_out);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

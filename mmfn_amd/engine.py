@@ -54,6 +54,7 @@ class Ctx(object):
         self.drop = drop_p if training else (0.0, 0.0, 0.0)  # (embd, attn, resid)
         self.rng_state = rng_state
         self.side = side  # side stream for work that is off the critical path (weight gradients), or None
+        self.folded = False  # eval forward over BatchNorm-folded filters (Engine.fold_batchnorm)
 
     def wino_u(self, name, w):
         """Engine-wide buffer for a layer's transformed filter U [36][Co][Ci]; registers the layer for the grouped transform."""
@@ -148,6 +149,17 @@ class ConvBN(object):
                 # buffer is engine-wide (it does not depend on the batch): Engine.forward transforms all of them in one launch
                 keep_u = ctx.wino_u(self.name, self.w)
         M = oshape[0] * oshape[1] * oshape[2]
+        if not ctx.training and ctx.folded:
+            # eval with BatchNorm folded into the filter (Engine.fold_batchnorm): convolution + shift + skip + ReLU in ONE launch,
+            # as a direct implicit GEMM (at batch 1 the Winograd form - transform, 36-batch GEMM, transform - measured slower: 4.99 vs
+            # 4.59 ms per tick)
+            wf, bf = ctx.engine.folded[self.name]
+            y = ctx.bufs.get(self.name + ".out", oshape)
+            if res is None:
+                ops.conv2d_fwd(x, wf, self.stride, self.pad, out=y, bias=bf, relu=relu)
+            else:
+                ops.conv2d_fwd(x, wf, self.stride, self.pad, out=y, bias=bf, res=res.view(M, self.cout), ldr=self.cout, relu_last=relu)
+            return y
         co2 = co.view(M, self.cout)
         mean = ctx.bufs.get(self.name + ".mean", (self.cout,))
         rstd = ctx.bufs.get(self.name + ".rstd", (self.cout,))
@@ -238,6 +250,16 @@ class ResNetTrunk(object):
             seq = getattr(mod, "layer%d" % li)
             self.layers[li] = [BasicBlock("%s.l%d.%d" % (name, li, j), layout, "%s.layer%d.%d" % (prefix, li, j), blk)
                                for j, blk in enumerate(seq)]
+
+    def convbns(self):
+        if self.stem is not None:
+            yield self.stem
+        for li in sorted(self.layers):
+            for blk in self.layers[li]:
+                yield blk.c1
+                yield blk.c2
+                if blk.down is not None:
+                    yield blk.down
 
     def stem_fwd(self, ctx, x):
         y = self.stem.fwd(ctx, x, relu=True)
@@ -907,6 +929,7 @@ class Engine(object):
         self.side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         self.multi_stream = True
         self._recorder = None   # mmfn_amd.graphs.Recorder while a lane-graph capture is running
+        self.folded = {}        # ConvBN name -> (BatchNorm-folded filter, shift), see fold_batchnorm()
         # "f32" (parity path) or "bf16": bf16 MFMA operands with fp32 accumulation for the Linear / Winograd GEMMs
         self.gemm_dtype = getattr(cfg, "gemm_dtype", "f32")
         self.wino_layers = {}     # ConvBN name -> (filter storage, transformed-filter buffer): filled by the first training forward
@@ -995,10 +1018,26 @@ class Engine(object):
         return outs
 
     # ------------------------------------------------------------------ forward / backward
+    def fold_batchnorm(self):
+        """(Re)compute the BatchNorm-folded filters / shifts of every convolution from the current weights and running
+        statistics, for eval forwards with folded=True.  The caller owns freshness: call it again after the weights or the
+        running statistics change (DrivingSession does at construction and in refresh())."""
+        for trunk in (self.img, self.lid, self.map):
+            for cb in trunk.convbns():
+                ent = self.folded.get(cb.name)
+                if ent is None:
+                    ent = (torch.empty_like(cb.w), torch.empty(cb.cout, dtype=torch.float32, device=self.device))
+                    self.folded[cb.name] = ent
+                ops.bn_fold(cb.w, cb.bn_w, cb.bn_b, cb.bn.running_mean, cb.bn.running_var, cb.bn.eps, ent[0], ent[1])
+
     @_in_precision
-    def forward(self, inp, training, gt=None):
+    def forward(self, inp, training, gt=None, folded=False):
         B = inp["target_point"].shape[0]
         ctx = self._ctx(B, training)
+        if folded:
+            if training or not self.folded:
+                raise ValueError("folded=True is an eval-mode option and needs Engine.fold_batchnorm() first")
+            ctx.folded = True
         self._last = (ctx, B)
         img, lid, mp = self._ingest(ctx, inp)
         vel = inp["velocity"]

@@ -18,7 +18,7 @@ FAR = 1.0e6  # x coordinate of padding points: outside every histogram bin, igno
 
 
 class DrivingSession(object):
-    def __init__(self, net, image_hw=(300, 400), max_points=1 << 17, max_lanes=128, use_graph=True):
+    def __init__(self, net, image_hw=(300, 400), max_points=1 << 17, max_lanes=128, use_graph=True, fold_batchnorm=True):
         if net.variant != "vec":
             raise NotImplementedError("closed-loop session is built for the vec model (mmfn_vectornet agent)")
         self.net = net.eval()
@@ -44,14 +44,26 @@ class DrivingSession(object):
         self._n_points = 0
         self._n_dev = 0
         self.graph = None
+        self.fold = fold_batchnorm
         with torch.no_grad():
-            self.pred, _ = self.eng.forward(self.inp, False, None)  # sizes every buffer
+            if self.fold:
+                # eval-mode BatchNorm folded into the filters: convolution + shift + skip + ReLU is one launch instead of
+                # transform / GEMM / transform / prepare / apply (85 convolutions: ~700 -> ~330 dependent kernels per tick)
+                self.eng.fold_batchnorm()
+            self.pred, _ = self.eng.forward(self.inp, False, None, folded=self.fold)  # sizes every buffer
             torch.cuda.synchronize()
             if use_graph:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self.pred, _ = self.eng.forward(self.inp, False, None)
+                    self.pred, _ = self.eng.forward(self.inp, False, None, folded=self.fold)
                 self.graph = g
+
+    def refresh(self):
+        """Call after the network's weights or BatchNorm running statistics changed (load_state_dict, further training): the
+        folded filters are recomputed in place, the captured graph stays valid."""
+        if self.fold:
+            with torch.no_grad():
+                self.eng.fold_batchnorm()
 
     # ------------------------------------------------------------------ one tick
     def _load(self, rgb, sweep, lanes, target_point, speed):
@@ -103,7 +115,7 @@ class DrivingSession(object):
         if self.graph is not None:
             self.graph.replay()
         else:
-            self.pred, _ = self.eng.forward(self.inp, False, None)
+            self.pred, _ = self.eng.forward(self.inp, False, None, folded=self.fold)
         self.out_host.copy_(self.pred, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         return torch.from_numpy(self.out_host.numpy().copy())

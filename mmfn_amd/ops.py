@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import (A_COLMAJOR, A_DGRAD, A_IM2COL, A_ROWMAJOR, B_DGRADW, B_IM2COL, B_KN, B_NK,
-                   EPI_ACCUM, EPI_BF16_OPERANDS, EPI_BF16X3, EPI_BIAS, EPI_DROPOUT, EPI_GELU, EPI_MASK_AUX, EPI_RELU, EPI_RESIDUAL,
+                   EPI_ACCUM, EPI_BF16_OPERANDS, EPI_BF16X3, EPI_BIAS, EPI_DROPOUT, EPI_GELU, EPI_MASK_AUX, EPI_RELU, EPI_RELU_LAST, EPI_RESIDUAL,
                    GemmDesc, check, lib, ptr, stream)
 
 _workspace = {}
@@ -261,7 +261,7 @@ def _f32c(t, name):
 
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=None, res=None, ldr=0,
-         aux=None, ldaux=0, relu=False, gelu=False, accum=False, drop_p=0.0, rng_state=None, rng_stream=0,
+         aux=None, ldaux=0, relu=False, gelu=False, accum=False, relu_last=False, drop_p=0.0, rng_state=None, rng_stream=0,
          conv=None, splitk=0, tile=0, batch=1, strideA=0, strideB=0, strideC=0):
     d = GemmDesc()
     d.batch, d.strideA, d.strideB, d.strideC = batch, strideA, strideB, strideC
@@ -290,6 +290,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=N
         flags |= EPI_RESIDUAL
     if accum:
         flags |= EPI_ACCUM
+    if relu_last:
+        flags |= EPI_RELU_LAST
     # bf16 mode: plain GEMMs and - as DIRECT convolutions - the im2col forward / flipped data gradient and the weight gradient
     # (the library falls back to the fp32 kernel for what the bf16 kernel does not cover: 7x7 stems, stride-2 data gradients)
     bf16 = _gemm_dtype != "f32" and (conv is None or (_gemm_dtype == "bf16" and (
@@ -678,6 +680,13 @@ def bn_train_stats(x2d, mean, rstd, running_mean, running_var, nbt, eps=1e-5, mo
     M, C = x2d.shape
     _call("mmfn_bn_train_stats_f32", ptr(x2d), M, C, eps, momentum, ptr(mean), ptr(rstd), ptr(running_mean),
           ptr(running_var), ptr(nbt), ptr(norm_workspace(x2d.device)), stream())
+
+
+def bn_fold(w, gamma, beta, running_mean, running_var, eps, w_out, b_out):
+    """Eval-mode BatchNorm folded into the convolution before it: w_out = w * s per output channel, b_out = beta - mean * s."""
+    Cout = w.shape[0]
+    _call("mmfn_bn_fold_f32", ptr(w), Cout, w.numel() // Cout, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps),
+          ptr(w_out), ptr(b_out), stream())
 
 
 def bn_eval_prepare(running_mean, running_var, mean, rstd, eps=1e-5):

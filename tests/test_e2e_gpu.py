@@ -367,3 +367,41 @@ def test_bf16_operand_mode_tracks_the_fp32_path():
     with torch.no_grad():
         a, b = net32(*dargs), net16(*dargs)
     assert (a - b).abs().max().item() <= 2e-2 * max(1.0, a.abs().max().item()), (a - b).abs().max().item()
+
+
+def test_folded_batchnorm_session_matches_unfolded_and_follows_weight_changes():
+    """DrivingSession folds the eval-mode BatchNorms into the convolution filters (conv + shift + skip + ReLU in one launch,
+    MMFN_EPI_RELU_LAST): same waypoints as the unfolded eval forward, and refresh() picks up changed weights / running statistics
+    without a new capture."""
+    from mmfn_amd.inference import DrivingSession
+    from oracle import harness
+    oracle, net, batch, args = _setup("vec", B=2)
+    harness.calibrate_bn(oracle, args)
+    net.load_state_dict(oracle.state_dict(), strict=True)
+    folded = DrivingSession(net, max_points=1 << 14, max_lanes=16)
+    plain = DrivingSession(net, max_points=1 << 14, max_lanes=16, fold_batchnorm=False)
+    rng = np.random.RandomState(1)
+    rgb = rng.randint(0, 256, (300, 400, 3)).astype(np.uint8)
+    pts = np.stack([rng.uniform(-20, 20, 5000), rng.uniform(-12, 28, 5000), rng.uniform(-3, 1, 5000), rng.uniform(0, 1, 5000)], 1).astype(np.float32)
+    lanes = rng.randn(6, 10, 5).astype(np.float32)
+
+    def both():
+        a = folded.predict(rgb, pts, lanes, (2.0, 15.0), 3.0, merge_previous_sweep=False)
+        b = plain.predict(rgb, pts, lanes, (2.0, 15.0), 3.0, merge_previous_sweep=False)
+        return a, b
+
+    a0, b0 = both()
+    assert (a0 - b0).abs().max().item() <= 2e-5
+    with torch.no_grad():   # change filters and running statistics in place
+        for name, p in net.named_parameters():
+            if "image_encoder" in name and name.endswith("conv1.weight"):
+                p.mul_(1.05)
+        for name, b in net.named_buffers():
+            if name.endswith("running_var"):
+                b.mul_(1.1)
+    a1, b1 = both()
+    assert (b1 - b0).abs().max().item() > 1e-4          # the network did change
+    assert (a1 - a0).abs().max().item() <= 1e-6         # ... and the folded session still holds the old filters
+    folded.refresh()
+    a2, _ = both()
+    assert (a2 - b1).abs().max().item() <= 2e-5

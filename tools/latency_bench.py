@@ -21,10 +21,11 @@ def main():
     lanes = rng.randn(40, 10, 5).astype(np.float32)
     out = {}
     eng = net._engine_for()
-    modes = (("hipgraph", True, True), ("hipgraph_single_stream", True, False), ("eager", False, True))
-    for name, use_graph, multi in modes:
+    modes = (("hipgraph", True, True, True), ("hipgraph_batchnorm_not_folded", True, True, False), ("hipgraph_single_stream", True, False, True),
+             ("eager", False, True, True))
+    for name, use_graph, multi, fold in modes:
         eng.multi_stream = multi
-        sess = DrivingSession(net, use_graph=use_graph)
+        sess = DrivingSession(net, use_graph=use_graph, fold_batchnorm=fold)
         for _ in range(5):
             sess.predict(rgb, pts, lanes, (3.0, 20.0), 4.0)
         ts = []
