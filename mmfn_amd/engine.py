@@ -1048,12 +1048,19 @@ class Engine(object):
             # forward); it runs at the head of the shortest branch, the consumers (layer2 and deeper) come after the first
             # fusion transformer, where all branches have joined
             if self.wino_table is None and not torch.cuda.is_current_stream_capturing():
-                self.wino_table = ops.make_wino_group_table(list(self.wino_layers.values()), self.device)
+                # two launches: the filters of layer1 (consumed inside the first fork, by lanes that run beside the lane that
+                # would transform them: they go first, on the main stream, a few microseconds) and all the others
+                early = [v for k, v in self.wino_layers.items() if ".l1." in k]
+                late = [v for k, v in self.wino_layers.items() if ".l1." not in k]
+                self.wino_table = (ops.make_wino_group_table(early, self.device) if early else None,
+                                   ops.make_wino_group_table(late, self.device) if late else None)
             ctx.wino_ready = self.wino_table is not None
+            if ctx.wino_ready and self.wino_table[0] is not None:
+                ops.wino_weight_group(*self.wino_table[0])
 
         def map_stage1():
-            if ctx.wino_ready:
-                ops.wino_weight_group(*self.wino_table)
+            if ctx.wino_ready and self.wino_table[1] is not None:
+                ops.wino_weight_group(*self.wino_table[1])
             if self.variant == "img":
                 return self.map.layer_fwd(ctx, 1, self.map.stem_fwd(ctx, mp))
             return self.vec.fwd(ctx, inp["lane"], inp["lane_num"])

@@ -384,7 +384,7 @@ def conv_geom(x_shape, w_shape, stride, pad):
 
 
 _wino = {}
-WINOGRAD_MIN_CHANNELS = int(os.environ.get("MMFN_WINOGRAD_MIN_C", "128"))  # 0 disables the Winograd path
+WINOGRAD_MIN_CHANNELS = int(os.environ.get("MMFN_WINOGRAD_MIN_C", "64"))  # 0 disables the Winograd path
 
 
 def _wino_scratch(n, device):
