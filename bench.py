@@ -383,7 +383,7 @@ def main():
             "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch",
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(prof.algo_bytes() / max(n_launch, 1)),
             "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32 GEMM / implicit-GEMM conv fwd+dgrad+wgrad; 3x3 stride-1 "
-                      "convolutions with >=128 channels as Winograd F(4x4,3x3): their transform kernels are inside the timed span)",
+                      "convolutions as Winograd F(4x4,3x3): their transform kernels are inside the timed span)",
             "launches_per_step": n_launch // steps_p,
             "algorithmic_gflop_per_step": round(flops / steps_p / 1e9, 1),
             # what the MFMA units execute: less than the algorithmic count where Winograd replaces the direct convolution
