@@ -549,7 +549,9 @@ extern "C" int mmfn_layernorm_bwd_f32(const float* g, const float* x, const floa
                                      nullptr, workspace, stream);
 }
 
-static int ln_bwd_rows_per_block(int M) { return std::max(8, ceil_div(M, 768)); }
+// 384 blocks of >= 8 rows: interleaved A/B of the training step (tools/ab_bench.sh) - 768 blocks 34.71 ms, 512 34.65, 384 34.46,
+// 256 34.44, 192 34.50, 128 34.77: fewer partial rows for the finalize and more rows per block to amortise the block's LDS combine
+static int ln_bwd_rows_per_block(int M) { return std::max(8, ceil_div(M, 384)); }
 
 extern "C" int mmfn_layernorm_bwd_rows(int M) { return M > 0 ? ceil_div(M, ln_bwd_rows_per_block(M)) : 0; }
 
