@@ -141,7 +141,7 @@ def set_gemm_profiler(p):
 # extended at run time: an unknown shape is timed once over the candidate grid on a scratch output (never inside
 # graph capture) and the winner cached.  Both fields are plain inputs of the C ABI (mmfn_gemm_desc.tile/.splitk).
 _tuned = {}
-_TUNE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "gfx950.json")
+_TUNE_FILE = os.environ.get("MMFN_TUNING_FILE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "gfx950.json")
 AUTOTUNE = os.environ.get("MMFN_AUTOTUNE", "0") == "1"
 F32X3 = os.environ.get("MMFN_F32X3", "0") == "1"  # let fp32 GEMMs use the bf16x3 emulation kernel where the table says so
 USE_TABLE = os.environ.get("MMFN_TUNING_TABLE", "1") != "0"
