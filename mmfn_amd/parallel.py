@@ -118,7 +118,7 @@ class GraphedStep(object):
     An eager step is ~2200 Python-issued launches, which makes the host the bottleneck; a replay is ~35 host calls and the
     reductions still overlap the later backward graphs."""
 
-    def __init__(self, engine, dp, inp, gt, lr=1e-4, warm=2, **adam):
+    def __init__(self, engine, dp, inp, gt, lr=1e-4, warm=2, lane_graphs=None, **adam):
         from .graphs import Recorder
         self.engine, self.dp = engine, dp
         eng = engine
@@ -128,7 +128,7 @@ class GraphedStep(object):
         scale = 1.0 / (dp.world if dp is not None else 1)
         self.scale = scale
         eng.set_hyper(eng.hyper_rows(lr=lr, grad_scale=scale, **adam))  # the captured AdamW reads them from device memory
-        rec = self.recorder = Recorder(eng)
+        rec = self.recorder = Recorder(eng, split_lanes=lane_graphs)   # None: MMFN_LANE_GRAPHS decides (default: forks inside the graphs)
 
         def body():
             from . import ops

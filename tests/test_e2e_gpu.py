@@ -276,6 +276,29 @@ def test_batched_transformer_weight_gradients_equal_per_block_ones(monkeypatch):
         assert (a - b).abs().max().item() <= 1e-5 * max(a.abs().max().item(), 1e-6), k
 
 
+def test_lane_graph_replay_equals_eager_steps():
+    """graphs.Recorder in lane-graph mode (every branch lane and every piece of transformer side work its own linear hipGraph,
+    stitched with eager events - MMFN_LANE_GRAPHS=1) replays to exactly the parameters eager train steps produce."""
+    from mmfn_amd.parallel import GraphedStep
+    _, net_a, batch, args = _setup("vec", dropout=0.1)
+    _, net_b, _, _ = _setup("vec", dropout=0.1)
+    dargs = _dev_args(args)
+    gt = batch["gt_wp"].to(DEV)
+    net_a.train(), net_b.train()
+    inp_a, inp_b = net_a._pack(*dargs), net_b._pack(*dargs)
+    for _ in range(3):
+        loss_a = net_a.train_step(inp_a, gt)
+    step = GraphedStep(net_b._engine_for(), None, inp_b, gt, warm=1, lane_graphs=True)
+    assert step.recorder.split_lanes and step.recorder.n_graphs > 20
+    for _ in range(2):
+        loss_b = step()
+    torch.cuda.synchronize()
+    assert loss_a.item() == loss_b.item()
+    sa, sb = net_a.state_dict(), net_b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+
+
 def test_segmented_graph_step_equals_eager_steps():
     """parallel.GraphedStep (linear hipGraphs per branch lane, cut at the gradient-bucket boundaries under data parallelism) replays to exactly the
     parameters the eager train_step produces, dropout included (counter RNG advances on the device)."""
