@@ -137,10 +137,10 @@ class GraphedStep(object):
             eng.backward_begin()
             for i in range(4):
                 eng.backward_scale(3 - i)
-                if dp is not None:
+                if dp is not None and i < 3:
                     rec.cut(lambda i=i: dp.on_stage(i))
-            if dp is not None:
-                rec.cut(dp.finish)
+            if dp is not None:   # last bucket and the wait for all of them in one cut (nothing is launched in between)
+                rec.cut(lambda: (dp.on_stage(3), dp.finish()))
             eng.optimizer_step(lr=lr, grad_scale=scale, **adam)
 
         rec.capture(body)
