@@ -885,6 +885,9 @@ def _in_precision(fn):
     return wrapped
 
 
+LANE_TAIL_ADJOINT = os.environ.get("MMFN_LANE_TAIL_ADJOINT", "1") == "1"   # A/B switch, see Engine.backward_scale
+
+
 class Engine(object):
     """Forward / backward / optimizer step of one MMFN replica on one GPU.
 
@@ -1107,6 +1110,7 @@ class Engine(object):
         """Head backward + gradient of the global-average-pool/sum: seeds the per-branch gradients."""
         ctx, B = self._last
         bufs = ctx.bufs
+        self._adj_done = False
         g_fused = self.head.bwd(ctx, dpred, gscale)
         shapes = [f.shape for f in self.pre_add[3]]
         self._G = [bufs.get("G3.%d" % m, shp) for m, shp in enumerate(shapes)]
@@ -1123,17 +1127,27 @@ class Engine(object):
         gpt = self.gpts[s]
         gtok = bufs.get("gtok%d" % s, (B, gpt.T, gpt.C))
         for m, g in enumerate(G):
-            ops.upsample_adj(g, gtok, m)
+            if not (self._adj_done and m < 3):   # the three branch lanes of the previous scale already spread their gradient
+                ops.upsample_adj(g, gtok, m)
         gin = gpt.bwd(ctx, gtok)
         if s == 3 and self.rad is not None:
             dF3 = ops.pool_bcast_add(G[3], gin, bufs.get("dF3.3", G[3].shape), 3)
             self.rad.bwd(ctx, dF3)
         if s > 0:
+            nxt = self.gpts[s - 1]
+            gtok_next = bufs.get("gtok%d" % (s - 1), (B, nxt.T, nxt.C))
+
             def stage(m):
                 d = ops.pool_bcast_add(G[m], gin, bufs.get("dF%d.%d" % (s, m), G[m].shape), m)
-                return trunks[m].layer_bwd(ctx, s + 1, d)
+                g = trunks[m].layer_bwd(ctx, s + 1, d)
+                if LANE_TAIL_ADJOINT:
+                    # the adjoint of the next scale's upsample-add for this branch (its own 64 token rows of gtok) at the tail of
+                    # the lane, beside the other lanes, instead of three launches on the main stream ahead of the transformer
+                    ops.upsample_adj(g, gtok_next, m)
+                return g
 
             self._G = self._branches([lambda m=m: stage(m) for m in range(3)])
+            self._adj_done = LANE_TAIL_ADJOINT
             return
 
         def img_tail():
