@@ -391,6 +391,9 @@ def main():
             "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
             "kernel_ms_per_step": round(ms / steps_p, 3),
             "whole_step_algorithmic_tflops": round(ALGO_GFLOP_PER_SAMPLE.get("image-only" if image_only else args.variant, 0) * B / ms_per_step, 2),
+            "accounting": "achieved / frac count ALGORITHMIC FLOPs (SURVEY 8d: output pixels x taps x Cin x Cout of a convolution) over the "
+                          "time of the launches that implement them; the Winograd F(4x4,3x3) path executes 4x fewer on the MFMA units "
+                          "(executed_gflop_per_step, executed_tflops), so a convolution-only workload can exceed 1.0 here",
         }
         if args.dtype != "f32":
             # bf16 mode: the dominant kernel is the bf16-operand GEMM; price ITS launches against the dense bf16 MFMA peak.
