@@ -197,6 +197,117 @@ def loss_vs_oracle(net, eng, inp, gt, variant):
             "note": "benched batch, current weights, train-mode BatchNorm, dropout off on both sides"}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without an outer launcher: start the N ranks ourselves, one process per GPU, through
+    torch.distributed.run on this node (what the driver's own multi-GPU command line does), and pass the ranks' output and
+    exit code through.  Rank 0 prints the one JSON line."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, usable_cores() // n))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def numa_cpus_of_gpu(index):
+    """CPUs of the NUMA node the GPU's PCIe function hangs off, or None when the platform does not say."""
+    try:
+        props = torch.cuda.get_device_properties(index)
+        bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        return cpus
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
+
+
+def pin_rank(local_rank, world, gpu_index):
+    """One disjoint slice of the usable cores per rank, taken from the GPU's own NUMA node when that is known: the replay
+    thread, RCCL's proxy thread and the launcher's OpenMP workers of eight ranks otherwise migrate over the whole host and share
+    cores.  Returns a description for the JSON line.  MMFN_BENCH_PIN=0 switches it off."""
+    if os.environ.get("MMFN_BENCH_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    allowed = sorted(os.sched_getaffinity(0))
+    near = numa_cpus_of_gpu(gpu_index)
+    pool = [c for c in allowed if near is None or c in near]
+    same_node_ranks = world
+    if near is not None and len(pool) >= 2:
+        # ranks whose GPUs share this NUMA node split ITS cores; without topology every rank splits the whole mask
+        peers = [r for r in range(world) if numa_cpus_of_gpu(r if not os.environ.get("MMFN_BENCH_SINGLE_DEVICE") else 0) == near]
+        same_node_ranks, slot = max(1, len(peers)), (peers.index(local_rank) if local_rank in peers else local_rank % max(1, len(peers)))
+    else:
+        pool, slot = allowed, local_rank
+    per = max(1, len(pool) // same_node_ranks)
+    mine = pool[slot * per:(slot + 1) * per] or pool
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return {"cpus": len(mine), "first": mine[0], "numa_aware": near is not None}
+
+
+def all_ranks_agree(dist, dev, ok):
+    """Logical AND of `ok` over the ranks (through the launcher's process group)."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def open_capi_transport(rank, world, dist, dev, required=False, timeout_s=120.0):
+    """RCCL communicator through the C ABI + a self-test (sum of rank ids over a 1 MiB bucket on a side stream); every rank
+    must pass, else all of them use torch.distributed.  The init runs in a helper thread so that a communicator that never
+    comes up costs `timeout_s`, not the run.  Returns (RcclComm or None, note)."""
+    import threading
+    box = {}
+
+    def attempt():
+        try:
+            from mmfn_amd.comm import RcclComm
+            torch.cuda.set_device(dev)
+            c = RcclComm(rank, world, dist=dist)
+            x = torch.full((1 << 18,), float(rank + 1), dtype=torch.float32, device=dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            c.all_reduce_sum_(x, stream=side)
+            side.synchronize()
+            expect = world * (world + 1) / 2.0
+            if float(x.min().item()) != expect or float(x.max().item()) != expect or c.ranks() != (world, rank):
+                raise RuntimeError("self-test all-reduce returned %r..%r, expected %r" % (float(x.min()), float(x.max()), expect))
+            box["comm"] = c
+        except BaseException as exc:   # a missing library, an RCCL error code, a wrong sum: all mean "use torch.distributed"
+            box["error"] = "%s: %s" % (type(exc).__name__, exc)
+
+    th = threading.Thread(target=attempt, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        box.setdefault("error", "communicator did not come up within %.0f s" % timeout_s)
+    ok = "comm" in box
+    if not all_ranks_agree(dist, dev, ok):
+        if required:
+            raise SystemExit("MMFN_DP_TRANSPORT=capi: C-ABI transport unavailable on rank %d: %s" % (rank, box.get("error", "another rank failed")))
+        if rank == 0:
+            sys.stderr.write("C-ABI RCCL transport not used (%s); falling back to torch.distributed\n" % box.get("error", "another rank failed"))
+        return None, "fallback: " + box.get("error", "another rank failed")
+    return box["comm"], None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,6 +331,12 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps for the roofline block")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no outer launcher: start the ranks ourselves (the same command line works under torch.distributed.run too)
+        single = bool(os.environ.get("MMFN_BENCH_SINGLE_DEVICE"))
+        if not single and torch.cuda.device_count() < args.gpus:
+            raise SystemExit("--gpus %d: only %d GPU(s) visible on this node" % (args.gpus, torch.cuda.device_count()))
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -227,17 +344,20 @@ def main():
     # every rank: under a cgroup quota the spinning OpenMP workers get the whole process throttled
     torch.set_num_threads(max(1, min(8, usable_cores() // max(1, world))))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
+    gpu_index = local_rank
     if os.environ.get("MMFN_BENCH_SINGLE_DEVICE"):  # CI on a 1-GPU box: all ranks share cuda:0 (with gloo, see below)
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        gpu_index = 0
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
+    pinned = pin_rank(local_rank, world, gpu_index) if world > 1 else None
+    local_rank = gpu_index
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MMFN_DIST_BACKEND", "nccl")  # nccl == RCCL over xGMI on ROCm
-        if backend == "nccl":
+        backend = os.environ.get("MMFN_DIST_BACKEND", "gloo" if os.environ.get("MMFN_BENCH_SINGLE_DEVICE") else "nccl")
+        if backend == "nccl":   # nccl == RCCL over xGMI on ROCm
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
@@ -252,11 +372,16 @@ def main():
     net.train()
     B = args.batch
     inp, gt = synth_inputs(B, dev, seed=42 + rank, n_lidar=args.n_lidar, variant=args.variant, lane_format=args.lane_format)
-    comm_capi = None
-    if world > 1 and os.environ.get("MMFN_DP_TRANSPORT") == "capi":
-        # gradient buckets through the C ABI (libmmfn_comm.so -> RCCL on our own stream) instead of torch's ProcessGroup
-        from mmfn_amd.comm import RcclComm
-        comm_capi = RcclComm(rank, world, dist=dist)
+    comm_capi, transport_note = None, None
+    want = os.environ.get("MMFN_DP_TRANSPORT", "auto")   # auto | capi | torch
+    if world > 1 and want != "torch":
+        # gradient buckets through the C ABI (libmmfn_comm.so -> RCCL on our own stream: capturable, so the whole data-parallel
+        # step is ONE hipGraph) whenever the library loads and its communicator passes a self-test on every rank; otherwise
+        # torch's ProcessGroup with the step cut at the bucket boundaries
+        if want == "auto" and os.environ.get("MMFN_BENCH_SINGLE_DEVICE"):
+            transport_note = "single-device CI run: RCCL refuses two ranks on one GPU, torch.distributed (gloo) instead"
+        else:
+            comm_capi, transport_note = open_capi_transport(rank, world, dist, dev, required=(want == "capi"))
     dp = DataParallel(net, dist, comm=comm_capi) if world > 1 else None
     if dp is not None:
         dp.broadcast_parameters()
@@ -273,9 +398,42 @@ def main():
         def step():
             return eng.train_step(inp, gt, lr=1e-4, dp=dp)
 
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def lock_step():
+        """True when the trained parameters are bit-identical on every rank - i.e. every gradient all-reduce so far delivered
+        the same sum everywhere (all ranks start from rank 0's broadcast and apply the same AdamW)."""
+        if dist is None:
+            return True
+        L = net._layout
+        chk = torch.sum(L.params[:L.tail].view(torch.int32), dtype=torch.int64).reshape(1)
+        if dist.get_backend() != "nccl":
+            chk = chk.cpu()
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return bool((lo == hi).item())
+
+    def to_torch_transport(why):
+        """Give up on the C-ABI transport (wrong sums, failed capture): fresh DataParallel over torch.distributed, parameters
+        re-broadcast from rank 0."""
+        nonlocal dp, comm_capi, transport_note
+        if rank == 0:
+            sys.stderr.write("C-ABI RCCL transport dropped (%s); continuing on torch.distributed\n" % why)
+        comm_capi, transport_note = None, "fallback: " + why
+        dp = DataParallel(net, dist)
+        dp.broadcast_parameters()
+
     # two eager steps size every buffer, then (optionally) capture one step into a hipGraph
     step(); step()
     torch.cuda.synchronize()
+    if comm_capi is not None and not lock_step():
+        to_torch_transport("ranks diverged after two eager steps")
+        step(); step()
+        torch.cuda.synchronize()
     runner = step
     graph = None
     if not args.no_graph and image_only:
@@ -284,23 +442,39 @@ def main():
             loss_buf = step()
         runner = graph.replay
     elif not args.no_graph:
-        # linear hipGraphs per branch lane (and, multi-GPU, per gradient bucket with the RCCL all-reduces in between)
+        # single GPU: one hipGraph.  Data parallel: one hipGraph with the RCCL all-reduces captured inside (C-ABI transport), or
+        # four graphs cut at the backward-stage boundaries with the bucket all-reduces in between (torch.distributed)
         from mmfn_amd.parallel import GraphedStep
-        try:
-            graph = GraphedStep(eng, dp, inp, gt, lr=1e-4, warm=0)
+
+        def try_capture():
+            try:
+                g, err = GraphedStep(eng, dp, inp, gt, lr=1e-4, warm=0), None
+            except Exception as exc:
+                g, err = None, "%s: %s" % (type(exc).__name__, exc)
+                torch.cuda.synchronize()
+            if dist is not None and not all_ranks_agree(dist, dev, g is not None):
+                g, err = None, err or "capture failed on another rank"
+            return g, err
+
+        graph, err = try_capture()
+        if graph is not None and comm_capi is not None:
+            for _ in range(2):
+                graph()
+            torch.cuda.synchronize()
+            if not lock_step():
+                graph, err = None, "ranks diverged after replaying the single-graph step"
+        if graph is None and comm_capi is not None:
+            to_torch_transport(err)
+            step()
+            torch.cuda.synchronize()
+            graph, err = try_capture()
+        if graph is not None:
             runner = graph
-        except Exception as exc:  # keep the run alive: eager launches give the same numbers' meaning, only slower
-            sys.stderr.write("rank %d: hipGraph capture failed (%s: %s); falling back to eager launches\n"
-                             % (rank, type(exc).__name__, exc))
-            graph = None
+        else:  # keep the run alive: eager launches give the same numbers' meaning, only slower
+            sys.stderr.write("rank %d: hipGraph capture failed (%s); falling back to eager launches\n" % (rank, err))
             torch.cuda.synchronize()
             step()
             torch.cuda.synchronize()
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         runner()
@@ -311,26 +485,49 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     comm = None
     if dp is not None:
-        # exposed communication: time the compute stream waits for the gradient all-reduces at the end of the backward
-        # (what the overlap does not hide), over a few extra steps outside the timed region; max over ranks
-        dp.measure_exposed = True
-        for _ in range(3):
-            runner()
-        ex = torch.tensor([dp.exposed_ms() or 0.0], device=dev, dtype=torch.float64)
-        dp.measure_exposed = False
-        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        in_step = lock_step()
+        single_graph = graph is not None and getattr(graph, "single_graph", False)
+        if single_graph:
+            # the collectives live inside the graph, so the exposed communication is measured as the difference to the same
+            # step without them: a second capture with dp=None (outside the timed region; the ranks drift apart from here on,
+            # nothing after this needs them in lock step)
+            n_probe = max(3, min(10, args.steps))
+            ref = GraphedStep(eng, None, inp, gt, lr=1e-4, warm=0)
+            for _ in range(2):
+                ref()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(n_probe):
+                ref()
+            torch.cuda.synchronize()
+            alone = (time.perf_counter() - t1) / n_probe * 1e3
+            ex_val, ex_how = max(0.0, ms_per_step - alone), "ms_per_step minus the same captured step without collectives (%.3f ms)" % alone
+        else:
+            # time the compute stream waits for the gradient all-reduces at the end of the backward (what the overlap does not
+            # hide), over a few extra steps outside the timed region
+            dp.measure_exposed = True
+            for _ in range(3):
+                runner()
+            ex_val, ex_how = dp.exposed_ms() or 0.0, "HIP events around the wait for the reductions before AdamW"
+            dp.measure_exposed = False
+        ex = torch.tensor([ex_val], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)   # max over ranks
         nbytes = 4 * sum(e - b for chunks in dp.buckets for b, e in chunks)
         comm = {"backend": dist.get_backend(), "library": "RCCL over xGMI" if dist.get_backend() == "nccl" else dist.get_backend(),
-                "transport": "mmfn_allreduce_sum_f32 (C ABI)" if comm_capi is not None else "torch.distributed",
-                "ranks": dist.get_world_size(), "allreduce_bytes_per_step": nbytes, "buckets": sum(len(c) for c in dp.buckets),
-                "exposed_ms_per_step": round(float(ex.item()), 3)}
+                "transport": "mmfn_allreduce_sum_f32 (C ABI, libmmfn_comm.so)" if comm_capi is not None else "torch.distributed",
+                "ranks": dist.get_world_size(), "allreduce_bytes_per_step": nbytes, "buckets": dp.n_buckets(),
+                "graphs_per_step": (1 if single_graph else graph.recorder.n_graphs) if graph is not None else 0,
+                "exposed_ms_per_step": round(float(ex.item()), 3), "exposed_method": ex_how,
+                "ranks_in_lock_step": in_step, "cpu_pinning": pinned}
+        if transport_note:
+            comm["note"] = transport_note
     loss_val = None if image_only else float(eng._bufs_for(B).get("head.loss", (1,)).item())
     workload = ("full MMFN %s (ResNet34 img + ResNet18 LiDAR-BEV + %s -> 4 GPT fusion -> GRU), train step fwd+L1+bwd+AdamW, "
                 "batch %d/GPU, 400x300x3 u8 RGB + %d-pt LiDAR + %s"
@@ -415,7 +612,7 @@ def main():
                 r.pop(k, None)
         if not image_only and args.dtype == "f32" and not args.no_oracle_check:
             result["loss_vs_oracle"] = loss_vs_oracle(net, eng, inp, gt, args.variant)
-        if not args.no_cpu_baseline and not image_only and args.variant == "vec":
+        if not args.no_cpu_baseline and not image_only and args.variant == "vec" and world == 1:   # rank 0 at N=1 only
             result["cpu_baseline"] = cpu_baseline()
         print(json.dumps(result))
     if dist is not None:

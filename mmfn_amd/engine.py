@@ -50,6 +50,7 @@ class Ctx(object):
         self.bufs = bufs
         self.engine = engine
         self.wino_ready = False   # True: the filters of the registered Winograd layers were transformed by the grouped launch
+        self.wino_names = frozenset()   # ... and the layers that launch covered
         self.training = training
         self.drop = drop_p if training else (0.0, 0.0, 0.0)  # (embd, attn, resid)
         self.rng_state = rng_state
@@ -65,8 +66,13 @@ class Ctx(object):
                 raise RuntimeError("Winograd filter buffer %s first used during graph capture; run one eager step first" % name)
             u = (w, torch.empty(36 * w.shape[0] * w.shape[3], dtype=torch.float32, device=w.device))
             eng.wino_layers[name] = u
-            eng.wino_table = None   # rebuilt before the next forward
+            eng.wino_table = None   # rebuilt before the next forward; THIS forward transforms the new layer's filter itself
         return u[1]
+
+    def wino_in_table(self, name):
+        """True when the grouped launch at the head of this forward transformed this layer's filter (the layer was registered
+        when the table was built - a layer that registers later, e.g. for a new image size, is not)."""
+        return self.wino_ready and name in self.wino_names
 
     def offload(self, fn):
         """Run fn (launches that only produce parameter gradients) on the side stream, ordered after everything
@@ -166,7 +172,7 @@ class ConvBN(object):
         if ctx.training:
             ops.conv2d_fwd_bn_stats(x, self.w, self.stride, self.pad, co, mean, rstd, self.bn.running_mean, self.bn.running_var,
                                     self.bn.num_batches_tracked, self.bn.eps, self.bn.momentum, keep_v=keep_v, keep_u=keep_u,
-                                    u_ready=keep_u is not None and ctx.wino_ready)
+                                    u_ready=keep_u is not None and ctx.wino_in_table(self.name))
         else:
             ops.conv2d_fwd(x, self.w, self.stride, self.pad, out=co)
             ops.bn_eval_prepare(self.bn.running_mean, self.bn.running_var, mean, rstd, self.bn.eps)
@@ -940,6 +946,7 @@ class Engine(object):
         self.opt_group_of = None
         self.opt_hyper = torch.zeros(16, 8, dtype=torch.float32, device=dev)
         self._hyper_host = None
+        self._hyper_pinned, self._hyper_slot = None, 0
         self.n_lanes = int(os.environ.get("MMFN_BRANCH_LANES", "3"))
         self.offload_wgrad = os.environ.get("MMFN_OFFLOAD_WGRAD", "1") == "1"
 
@@ -1056,14 +1063,19 @@ class Engine(object):
                 early = [v for k, v in self.wino_layers.items() if ".l1." in k]
                 late = [v for k, v in self.wino_layers.items() if ".l1." not in k]
                 self.wino_table = (ops.make_wino_group_table(early, self.device) if early else None,
-                                   ops.make_wino_group_table(late, self.device) if late else None)
-            ctx.wino_ready = self.wino_table is not None
-            if ctx.wino_ready and self.wino_table[0] is not None:
-                ops.wino_weight_group(*self.wino_table[0])
+                                   ops.make_wino_group_table(late, self.device) if late else None, frozenset(self.wino_layers))
+            table = self.wino_table   # a layer registering during this forward resets self.wino_table: keep using this one
+            ctx.wino_ready = table is not None
+            if ctx.wino_ready:
+                ctx.wino_names = table[2]
+                if table[0] is not None:
+                    ops.wino_weight_group(*table[0])
+        else:
+            table = None
 
         def map_stage1():
-            if ctx.wino_ready and self.wino_table[1] is not None:
-                ops.wino_weight_group(*self.wino_table[1])
+            if ctx.wino_ready and table[1] is not None:
+                ops.wino_weight_group(*table[1])
             if self.variant == "img":
                 return self.map.layer_fwd(ctx, 1, self.map.stem_fwd(ctx, mp))
             return self.vec.fwd(ctx, inp["lane"], inp["lane_num"])
@@ -1095,32 +1107,43 @@ class Engine(object):
         pred, loss = self.head.fwd(ctx, fused, inp["target_point"], gt)
         return pred, loss
 
-    def backward(self, dpred=None, gscale=None, on_stage=None):
+    def backward(self, dpred=None, gscale=None, on_stage=None, on_ready=None):
         """Backward of the last training forward.  dpred None => gradient of the fused L1 loss.
         on_stage(i) is called as soon as every gradient of backward stage i (params.FlatLayout.stage_of)
-        has been written, so a data-parallel wrapper can start reducing that bucket."""
-        self.backward_begin(dpred, gscale)
+        has been written, so a data-parallel wrapper can start reducing that bucket.
+        on_ready((stage, group)) is the finer hook: called - ON THE STREAM THAT WROTE THEM, which inside the branch lanes is a
+        side stream - as soon as the gradients of one readiness group of a stage (params.FlatLayout.group_ranges: "head",
+        "gpt", "vec", "img", "lid", "map") are complete."""
+        self.backward_begin(dpred, gscale, on_ready=on_ready)
         for s in range(3, -1, -1):
-            self.backward_scale(s)
+            self.backward_scale(s, on_ready=on_ready)
             if on_stage is not None:
                 on_stage(3 - s)
 
+    def _ready(self, hook, stage, group):
+        if hook is not None and (stage, group) in self.layout.group_ranges:
+            hook((stage, group))
+
     @_in_precision
-    def backward_begin(self, dpred=None, gscale=None):
+    def backward_begin(self, dpred=None, gscale=None, on_ready=None):
         """Head backward + gradient of the global-average-pool/sum: seeds the per-branch gradients."""
         ctx, B = self._last
         bufs = ctx.bufs
         self._adj_done = False
         g_fused = self.head.bwd(ctx, dpred, gscale)
+        if self.rad is None:   # (rad: the "head" group also holds the radar encoder, complete after the deepest transformer)
+            self._ready(on_ready, 0, "head")
         shapes = [f.shape for f in self.pre_add[3]]
         self._G = [bufs.get("G3.%d" % m, shp) for m, shp in enumerate(shapes)]
         ops.gap_sum_bwd(g_fused, self._G)
 
     @_in_precision
-    def backward_scale(self, s):
+    def backward_scale(self, s, on_ready=None):
         """Backward of fusion scale s (3 = deepest): GPT_s, then ResNet stage s+1 of the three branches
         (s = 0: layer1 + stems + VectorNet).  After it returns (enqueues), backward stage 3-s is complete."""
         ctx, B = self._last
+        st = 3 - s
+        names = ("img", "lid", "map")
         bufs = ctx.bufs
         trunks = [self.img, self.lid, self.map]
         G = self._G
@@ -1130,9 +1153,13 @@ class Engine(object):
             if not (self._adj_done and m < 3):   # the three branch lanes of the previous scale already spread their gradient
                 ops.upsample_adj(g, gtok, m)
         gin = gpt.bwd(ctx, gtok)
+        self._ready(on_ready, st, "gpt")
         if s == 3 and self.rad is not None:
             dF3 = ops.pool_bcast_add(G[3], gin, bufs.get("dF3.3", G[3].shape), 3)
             self.rad.bwd(ctx, dF3)
+            self._ready(on_ready, 0, "head")
+        # inside lane graphs (graphs.Recorder split mode) a lane is a linear graph of its own: the hooks run after the join
+        in_lane_ok = not (self._recorder is not None and self._recorder.split_lanes)
         if s > 0:
             nxt = self.gpts[s - 1]
             gtok_next = bufs.get("gtok%d" % (s - 1), (B, nxt.T, nxt.C))
@@ -1140,6 +1167,8 @@ class Engine(object):
             def stage(m):
                 d = ops.pool_bcast_add(G[m], gin, bufs.get("dF%d.%d" % (s, m), G[m].shape), m)
                 g = trunks[m].layer_bwd(ctx, s + 1, d)
+                if in_lane_ok:
+                    self._ready(on_ready, st, names[m])
                 if LANE_TAIL_ADJOINT:
                     # the adjoint of the next scale's upsample-add for this branch (its own 64 token rows of gtok) at the tail of
                     # the lane, beside the other lanes, instead of three launches on the main stream ahead of the transformer
@@ -1148,15 +1177,22 @@ class Engine(object):
 
             self._G = self._branches([lambda m=m: stage(m) for m in range(3)])
             self._adj_done = LANE_TAIL_ADJOINT
+            if not in_lane_ok:
+                for m in range(3):
+                    self._ready(on_ready, st, names[m])
             return
 
         def img_tail():
             d = ops.pool_bcast_add(G[0], gin, bufs.get("dF0.0", G[0].shape), 0)
             self.img.stem_bwd(ctx, self.img.layer_bwd(ctx, 1, d))
+            if in_lane_ok:
+                self._ready(on_ready, st, "img")
 
         def lid_tail():
             d = ops.pool_bcast_add(G[1], gin, bufs.get("dF0.1", G[1].shape), 1)
             self.lid.stem_bwd(ctx, self.lid.layer_bwd(ctx, 1, d))
+            if in_lane_ok:
+                self._ready(on_ready, st, "lid")
 
         def map_tail():
             d = ops.pool_bcast_add(G[2], gin, bufs.get("dF0.2", G[2].shape), 2)
@@ -1164,8 +1200,13 @@ class Engine(object):
                 self.map.stem_bwd(ctx, self.map.layer_bwd(ctx, 1, d))
             else:
                 self.vec.bwd(ctx, d)
+            if in_lane_ok:
+                self._ready(on_ready, st, "map" if self.variant == "img" else "vec")
 
         self._branches([img_tail, lid_tail, map_tail])
+        if not in_lane_ok:
+            for grp in ("img", "lid", "map" if self.variant == "img" else "vec"):
+                self._ready(on_ready, st, grp)
 
     # ------------------------------------------------------------------ optimizer
     def set_param_groups(self, group_of):
@@ -1184,10 +1225,22 @@ class Engine(object):
             raise RuntimeError("optimizer hyper-parameters changed inside a hipGraph capture; call Engine.set_hyper() before it")
         if len(rows) > 16:
             raise ValueError("at most 16 optimizer groups")
-        host = torch.zeros(16, 8, dtype=torch.float32)
+        # two pinned staging slots used alternately: the copy is asynchronous on the compute stream (a per-iteration LR schedule
+        # must not block the host until the previous step has drained), and a slot is only rewritten two updates later
+        if self._hyper_pinned is None:
+            self._hyper_pinned = [torch.zeros(16, 8, dtype=torch.float32).pin_memory() for _ in range(2)]
+            self._hyper_events = [None, None]
+        slot = self._hyper_slot = (self._hyper_slot + 1) % 2
+        if self._hyper_events[slot] is not None:
+            self._hyper_events[slot].synchronize()   # the copy issued two updates ago has long finished
+        host = self._hyper_pinned[slot]
+        host.zero_()
         for i, r in enumerate(rows):
             host[i, :6] = torch.tensor(r, dtype=torch.float32)
-        self.opt_hyper.copy_(host.to(self.device, non_blocking=False))
+        self.opt_hyper.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._hyper_events[slot] = ev
         self._hyper_host = rows
 
     @staticmethod
@@ -1202,6 +1255,7 @@ class Engine(object):
         L = self.layout
         groups = self.hyper_rows(lr, betas, eps, weight_decay, grad_scale, groups)
         self.set_hyper(groups)
+        self.module.weights_changed()
         ops.step_advance(self.step_count)
         ops.adamw_groups(L.params, L.grads, L.exp_avg, L.exp_avg_sq, self.step_count, self.opt_hyper, len(groups),
                          group_of=self.opt_group_of if len(groups) > 1 else None, n=L.tail)
@@ -1217,7 +1271,7 @@ class Engine(object):
             self.backward()
             self.optimizer_step(lr=lr, **adam)
         else:
-            self.backward(on_stage=dp.on_stage)
+            self.backward(on_ready=dp.reduce)
             dp.finish()
             self.optimizer_step(lr=lr, grad_scale=1.0 / dp.world, **adam)
         return loss

@@ -65,13 +65,45 @@ class Recorder(object):
         try:
             with torch.cuda.stream(self._stream):
                 self._begin()
-                out = fn()
-                self._end()
+                try:
+                    out = fn()
+                    self._end()
+                except BaseException:
+                    # leave capture mode before the exception travels on: a stream (and the allocator's capture pool) left
+                    # capturing makes every later synchronize() illegal, so the callers' eager fallbacks would die too
+                    self._abort()
+                    raise
         finally:
             eng._recorder = None
             self._g = None
         torch.cuda.current_stream().wait_stream(self._stream)
         torch.cuda.synchronize()
+        return out
+
+    def _abort(self):
+        """End whatever capture is in flight on the current stream and drop the half-recorded step."""
+        g, self._g = self._g, None
+        if g is not None:
+            try:
+                g.capture_end()
+            except Exception:   # the capture may already have been invalidated by the failing call
+                pass
+        self.ops = []
+        self.n_graphs = 0
+
+    @staticmethod
+    def _captured(graph, fn):
+        """fn() captured into `graph` on the current stream; the capture is ended even when fn raises."""
+        graph.capture_begin(capture_error_mode="thread_local")
+        try:
+            out = fn()
+        except BaseException:
+            try:
+                graph.capture_end()
+            except Exception:
+                pass
+            raise
+        graph.capture_end()
         return out
 
     def cut(self, fn):
@@ -91,9 +123,7 @@ class Recorder(object):
         for lane_id, (st, fns) in enumerate(groups[1:], start=1):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.stream(st), ops.lane(lane_id):
-                g.capture_begin(capture_error_mode="thread_local")
-                side_outs.append([f() for f in fns])
-                g.capture_end()
+                side_outs.append(self._captured(g, lambda fns=fns: [f() for f in fns]))
             lanes.append((st, g, torch.cuda.Event()))
             self.n_graphs += 1
         self.ops.append(("lanes", fork, lanes))
@@ -116,9 +146,7 @@ class Recorder(object):
         self._end()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(stream), ops.lane(lane_id):
-            g.capture_begin(capture_error_mode="thread_local")
-            fn()
-            g.capture_end()
+            self._captured(g, fn)
         self.n_graphs += 1
         self.ops.append(("side", torch.cuda.Event(), stream, g))
         self._begin()

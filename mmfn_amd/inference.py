@@ -50,6 +50,7 @@ class DrivingSession(object):
                 # eval-mode BatchNorm folded into the filters: convolution + shift + skip + ReLU is one launch instead of
                 # transform / GEMM / transform / prepare / apply (85 convolutions: ~700 -> ~330 dependent kernels per tick)
                 self.eng.fold_batchnorm()
+            self._folded_version = getattr(net, "_weights_version", 0)
             self.pred, _ = self.eng.forward(self.inp, False, None, folded=self.fold)  # sizes every buffer
             torch.cuda.synchronize()
             if use_graph:
@@ -64,6 +65,7 @@ class DrivingSession(object):
         if self.fold:
             with torch.no_grad():
                 self.eng.fold_batchnorm()
+            self._folded_version = getattr(self.net, "_weights_version", 0)
 
     # ------------------------------------------------------------------ one tick
     def _load(self, rgb, sweep, lanes, target_point, speed):
@@ -111,6 +113,11 @@ class DrivingSession(object):
         if merge_previous_sweep and self.prev_sweep is not None:  # half-rate LiDAR: two ticks make one revolution (:249)
             sweep = np.append(lidar, self.prev_sweep, axis=0)
         self.prev_sweep = lidar
+        if self.fold and getattr(self.net, "_weights_version", 0) != self._folded_version:
+            # load_state_dict / further training since the filters were folded: the convolutions would run on stale
+            # weights beside fresh transformers.  Re-fold in place (one launch per convolution; the captured graph stays valid).
+            # Weights modified behind the module's back (raw writes into p.data) still need an explicit refresh().
+            self.refresh()
         self._load(rgb, sweep, lanes, target_point, speed)
         if self.graph is not None:
             self.graph.replay()

@@ -58,6 +58,7 @@ class _AutogradBridge(torch.autograd.Function):
         m = ctx.module
         m._engine_for().backward(dpred.contiguous(), 1.0)
         m._layout.attach_grads()
+        m.weights_changed()   # an optimizer step on p.grad follows
         return None, None, None
 
 
@@ -93,6 +94,17 @@ class MMFN(nn.Module):
         object.__setattr__(self, "_engine", None)
         self.device = dev
         return self
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.weights_changed()
+        return out
+
+    def weights_changed(self):
+        """Note that parameters / BatchNorm statistics changed (the engine's optimizer step, a graph replay of it, the autograd
+        bridge's backward and load_state_dict call this): consumers of tensors derived from the weights - the BatchNorm-folded
+        filters of inference.DrivingSession - compare the counter and re-derive."""
+        object.__setattr__(self, "_weights_version", getattr(self, "_weights_version", 0) + 1)
 
     def _engine_for(self):
         if self._engine is None:

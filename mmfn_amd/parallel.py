@@ -17,31 +17,50 @@ import torch
 
 
 class DataParallel(object):
-    def __init__(self, module, dist, max_bucket_bytes=256 << 20, comm=None):
+    def __init__(self, module, dist, max_bucket_bytes=64 << 20, comm=None):
         """dist: torch.distributed (process group already initialised).  comm: optional mmfn_amd.comm.RcclComm - the
         gradient buckets then go through the C ABI (mmfn_allreduce_sum_f32) on a side HIP stream owned by this object
-        instead of through torch's ProcessGroup; everything else (broadcasts, barriers) stays on `dist`."""
+        instead of through torch's ProcessGroup; everything else (broadcasts, barriers) stays on `dist`.
+
+        Buckets: one per (backward stage, readiness group) of the flat gradient buffer (params.FlatLayout.group_ranges: the
+        fusion transformer of a scale, then each trunk's ResNet stage, VectorNet, ... - 17 ranges for the vec variant), cut
+        into chunks of at most max_bucket_bytes; the engine reports each group complete on the stream that wrote it
+        (Engine.backward(on_ready=dp.reduce)), so e.g. VectorNet's 66 MB leave while the camera trunk's layer1 is still
+        back-propagating and what is exposed after the last backward kernel is < 1 MB."""
         self.module = module
         self.dist = dist
         self.comm = comm
         self.comm_stream = None
         self.world = dist.get_world_size()
         self.layout = module._layout
-        self.buckets = []
-        lim = max_bucket_bytes // 4
-        for st, (b, e) in enumerate(self.layout.stage_ranges):
-            e = min(e, self.layout.tail)
-            chunks = []
+        lim = max(1, max_bucket_bytes // 4)
+        L = self.layout
+
+        def chunks_of(b, e):
+            e = min(e, L.tail)
+            out = []
             while b < e:
                 n = min(lim, e - b)
-                chunks.append((b, b + n))
+                out.append((b, b + n))
                 b += n
-            self.buckets.append(chunks)
+            return out
+
+        self.groups = {}         # (stage, group name) -> [(begin, end), ...]
+        self.group_order = []    # storage order == readiness order inside a stage
+        for key, (b, e) in sorted(L.group_ranges.items(), key=lambda kv: kv[1][0]):
+            self.groups[key] = chunks_of(b, e)
+            self.group_order.append(key)
+        # per-stage view (on_stage(), bench.py's byte count): all chunks of the stage's groups
+        self.buckets = [[c for key in self.group_order if key[0] == st for c in self.groups[key]] for st in range(4)]
         self.pending = []
+        self.reduced = set()     # groups reduced since the last finish(): a group is reduced at most once per step
         # exposed-communication probe: when enabled, finish() brackets its waits with events on the compute stream; the
         # elapsed time between them is what the collectives did NOT hide behind the backward (bench.py --gpus N reports it)
         self.measure_exposed = False
         self.exposed = []
+
+    def n_buckets(self):
+        return sum(len(c) for c in self.groups.values())
 
     def broadcast_parameters(self, src=0):
         L = self.layout
@@ -57,28 +76,48 @@ class DataParallel(object):
             self.dist.broadcast(eng.rng_state, src)
             eng.rng_state[0] += self.dist.get_rank()  # per-rank dropout streams
 
-    def on_stage(self, stage):
-        """Called by Engine.backward when every gradient of `stage` has been written (enqueued)."""
+    def _reduce_chunks(self, chunks):
         g = self.layout.grads
+        if not chunks:
+            return
         if self.comm is not None:
-            # C-ABI transport: the bucket's reduction is ordered after the backward so far by an event, runs on our own
-            # side stream (overlapping the rest of the backward), and finish() makes the compute stream wait for it.
+            # C-ABI transport: the reduction is ordered after the work enqueued so far on the CURRENT stream (the stream that
+            # wrote these gradients - inside the engine's branch lanes a side stream) by an event, runs on our own
+            # communication stream (overlapping the rest of the backward), and finish() makes the compute stream wait for it.
             # Plain stream work, no host wait: capturable into the same hipGraph as the kernels.
             if self.comm_stream is None:
                 self.comm_stream = torch.cuda.Stream(device=self.layout.device)
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
-            for b, e in self.buckets[stage]:
+            for b, e in chunks:
                 self.comm.all_reduce_sum_(g[b:e], stream=self.comm_stream)
             self.pending.append(None)
             return
-        for b, e in self.buckets[stage]:
+        for b, e in chunks:
             self.pending.append(self.dist.all_reduce(g[b:e], op=self.dist.ReduceOp.SUM, async_op=True))
+
+    def reduce(self, key):
+        """Engine hook (Engine.backward(on_ready=...)): every gradient of readiness group `key` = (stage, name) has been
+        enqueued on the current stream.  Every rank calls this in the same program order, so the collectives match up."""
+        if key in self.reduced or key not in self.groups:
+            return
+        self.reduced.add(key)
+        self._reduce_chunks(self.groups[key])
+
+    def on_stage(self, stage):
+        """Coarse hook: every gradient of backward `stage` has been written (enqueued): reduces whatever groups of the
+        stage reduce() has not been called for yet."""
+        for key in self.group_order:
+            if key[0] == stage:
+                self.reduce(key)
 
     def finish(self):
         """Make the compute stream wait for all outstanding reductions (before the optimizer)."""
-        probe = self.measure_exposed and self.layout.device.type == "cuda"
+        for key in self.group_order:   # nothing may be left behind (a variant whose engine does not report some group)
+            self.reduce(key)
+        self.reduced = set()
+        probe = self.measure_exposed and self.layout.device.type == "cuda" and not torch.cuda.is_current_stream_capturing()
         if probe:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -106,19 +145,21 @@ class DataParallel(object):
 
 
 class GraphedStep(object):
-    """One training step as a replayable sequence of linear hipGraphs (mmfn_amd.graphs.Recorder).
+    """One training step as a replayable hipGraph (or a short sequence of them; mmfn_amd.graphs.Recorder).
 
-    The step is cut (a) wherever the engine forks into its branch lanes - every lane is its own linear graph on its own
-    stream, stitched with eager events, because replaying a graph with cross-stream edges costs the host ~5 us per kernel
-    node against ~0.4 us for a linear graph (graphs.py) - and (b), under data parallelism, at the backward-stage
-    boundaries, where the gradient-bucket all-reduces are issued (through torch.distributed they cannot be captured):
-        RNG advance + forward + loss + head backward + backward of fusion scale 4   -> all-reduce bucket 0
-        backward of scale 3 -> bucket 1;  scale 2 -> bucket 2;  scale 1 + stems -> bucket 3
-        fused AdamW (after every reduction has been waited on)
-    An eager step is ~2200 Python-issued launches, which makes the host the bottleneck; a replay is ~35 host calls and the
-    reductions still overlap the later backward graphs."""
+    Single GPU: one graph, the branch lanes and the side work forked inside it.  Data parallel, by transport:
+      * C ABI (DataParallel(comm=RcclComm)): the bucket all-reduces are plain work on a HIP stream of ours
+        (mmfn_allreduce_sum_f32), so they are CAPTURED - the whole data-parallel step, collectives included, is ONE graph: a
+        replay is one host call, which is what eight ranks sharing one host's cores need;
+      * torch.distributed: a ProcessGroup collective cannot be captured, so the step is cut at the four backward-stage
+        boundaries and the buckets of the stage (one per readiness group, DataParallel.groups) are issued between the replays:
+            RNG advance + forward + loss + head backward + backward of fusion scale 4   -> buckets of stage 0
+            backward of scale 3 -> stage 1;  scale 2 -> stage 2;  scale 1 + stems + VectorNet -> stage 3, wait for all
+            fused AdamW
+    MMFN_LANE_GRAPHS=1 additionally cuts wherever the engine forks into its branch lanes (graphs.py).
+    An eager step is ~2200 Python-issued launches, which makes the host the bottleneck."""
 
-    def __init__(self, engine, dp, inp, gt, lr=1e-4, warm=2, lane_graphs=None, **adam):
+    def __init__(self, engine, dp, inp, gt, lr=1e-4, warm=2, lane_graphs=None, single_graph=None, **adam):
         from .graphs import Recorder
         self.engine, self.dp = engine, dp
         eng = engine
@@ -129,18 +170,33 @@ class GraphedStep(object):
         self.scale = scale
         eng.set_hyper(eng.hyper_rows(lr=lr, grad_scale=scale, **adam))  # the captured AdamW reads them from device memory
         rec = self.recorder = Recorder(eng, split_lanes=lane_graphs)   # None: MMFN_LANE_GRAPHS decides (default: forks inside the graphs)
+        if single_graph is None:
+            single_graph = dp is not None and dp.comm is not None and not rec.split_lanes
+        if single_graph and (dp is None or dp.comm is None):
+            raise ValueError("a single-graph data-parallel step needs the C-ABI transport (DataParallel(comm=...))")
+        self.single_graph = bool(single_graph) or dp is None
 
         def body():
             from . import ops
             ops.rng_advance(eng.rng_state)
             eng.forward(inp, True, gt)
-            eng.backward_begin()
-            for i in range(4):
-                eng.backward_scale(3 - i)
-                if dp is not None and i < 3:
-                    rec.cut(lambda i=i: dp.on_stage(i))
-            if dp is not None:   # last bucket and the wait for all of them in one cut (nothing is launched in between)
-                rec.cut(lambda: (dp.on_stage(3), dp.finish()))
+            if dp is None:
+                eng.backward()
+            elif single_graph:
+                # collectives captured on the communication stream: forked from the stream that wrote each bucket, joined by
+                # finish() before the optimizer - no cut, one replay call per step
+                eng.backward(on_ready=dp.reduce)
+                dp.finish()
+            else:
+                tags = []
+                eng.backward_begin(on_ready=tags.append)
+                for i in range(4):
+                    eng.backward_scale(3 - i, on_ready=tags.append)
+                    mine, tags[:] = list(tags), []
+                    if i < 3:
+                        rec.cut(lambda mine=mine, i=i: ([dp.reduce(t) for t in mine], dp.on_stage(i)))
+                    else:   # last buckets and the wait for all of them in one cut (nothing is launched in between)
+                        rec.cut(lambda mine=mine: ([dp.reduce(t) for t in mine], dp.finish()))
             eng.optimizer_step(lr=lr, grad_scale=scale, **adam)
 
         rec.capture(body)
@@ -152,6 +208,7 @@ class GraphedStep(object):
 
     def __call__(self):
         self.recorder.replay()
+        self.engine.module.weights_changed()   # the replayed AdamW does not pass through Engine.optimizer_step
         return self.loss
 
 

@@ -198,6 +198,15 @@ class FlatLayout(object):
                 self.stage_ranges.append((min(o for o, _ in offs), max((o + (k + 3) // 4 * 4) for o, k in offs)))
             else:
                 self.stage_ranges.append((0, 0))
+        # [begin, end) of every non-empty (stage, readiness group) inside the trained range, in storage order
+        self.group_ranges = {}
+        for n, _ in order:
+            if n in unused:
+                continue
+            key = (self.stage_of(n), self.GROUPS[self.group_of(n)])
+            o, k = self.offsets[n]
+            b, e = self.group_ranges.get(key, (o, o))
+            self.group_ranges[key] = (min(b, o), max(e, o + (k + 3) // 4 * 4))
         self.unused = unused
         self.device = None
         self.params = self.grads = self.exp_avg = self.exp_avg_sq = None
@@ -217,10 +226,25 @@ class FlatLayout(object):
             return 0
         return 3
 
+    # readiness order of the gradients inside one backward stage (Engine.backward_scale): head / radar, then the fusion
+    # transformer, then - in parallel lanes - VectorNet and the three ResNet trunks
+    GROUPS = ("head", "gpt", "vec", "img", "lid", "map", "other")
+
+    @classmethod
+    def group_of(cls, name):
+        """Readiness group of a parameter inside its backward stage (index into GROUPS): the data-parallel buckets are the
+        (stage, group) ranges of the flat buffer, each reduced as soon as the engine reports it complete."""
+        if name.startswith(("join.", "decoder.", "output.")) or "radar_encoder" in name:
+            return 0
+        for key, g in (("transformer", 1), ("vectornet_encoder", 2), ("image_encoder", 3), ("lidar_encoder", 4), ("img_map_encoder", 5)):
+            if key in name:
+                return g
+        return 6
+
     def _storage_order(self, named, unused):
-        """Storage order != registration order: sort by backward stage, pack k/q/v of each attention
+        """Storage order != registration order: sort by backward stage and readiness group, pack k/q/v of each attention
         block adjacently (weights, then biases) and push never-trained tensors to the tail."""
-        used = sorted([(n, p) for n, p in named if n not in unused], key=lambda np_: self.stage_of(np_[0]))
+        used = sorted([(n, p) for n, p in named if n not in unused], key=lambda np_: (self.stage_of(np_[0]), self.group_of(np_[0])))
         tail = [(n, p) for n, p in named if n in unused]
         by_name = dict(used)
         taken = set()

@@ -25,6 +25,17 @@ from . import ops
 from .parallel import StaticBatchStep, StaticEvalStep
 
 
+def _release(state):
+    """Free an evicted capture (hipGraph exec + its private pool + the static input copies): nothing may still be replaying
+    it, so wait for the device first; the "seen" / "eager" placeholders hold nothing."""
+    if isinstance(state, str) or state is None:
+        return
+    import gc
+    torch.cuda.synchronize()
+    del state
+    gc.collect()
+
+
 class Trainer(object):
     def __init__(self, device, log_dir, cur_epoch=0, cur_iter=0):
         self.cur_epoch = cur_epoch
@@ -49,7 +60,6 @@ class Trainer(object):
         eng = model._engine_for()
         if not hasattr(self, "_static_steps"):
             self._static_steps = {}      # input-shape signature -> "seen" | "eager" | StaticBatchStep, in LRU order
-            self._retired_steps = []
         total = torch.zeros(1, dtype=torch.float32, device=model._layout.device)
         window = torch.zeros_like(total)
         num_batches = 0
@@ -79,8 +89,7 @@ class Trainer(object):
                         loss = eng.train_step(inp, gt, lr=lr, dp=dp, **adam) if state == "eager" else state(inp, gt, lr=lr, **adam)
                     self._static_steps[sig] = state  # re-inserted last: the dict is the LRU order
                     while len(self._static_steps) > self.max_captured_shapes:
-                        old_sig = next(iter(self._static_steps))
-                        self._retired_steps.append(self._static_steps.pop(old_sig))  # graphs are kept alive, never replayed again
+                        _release(self._static_steps.pop(next(iter(self._static_steps))))  # least recently used
                 else:
                     loss = eng.train_step(inp, gt, lr=lr, dp=dp, **adam)
             else:
@@ -114,7 +123,6 @@ class Trainer(object):
         eng = model._engine_for()
         if not hasattr(self, "_static_evals"):
             self._static_evals = {}      # input-shape signature -> "seen" | "eager" | StaticEvalStep, in LRU order
-            self._retired_evals = []
         total = torch.zeros(1, dtype=torch.float32, device=model._layout.device)
         num_batches = 0
         with torch.no_grad():
@@ -139,7 +147,7 @@ class Trainer(object):
                         loss = eng.forward(inp, False, gt)[1] if state == "eager" else state(inp, gt)
                     self._static_evals[sig] = state
                     while len(self._static_evals) > self.max_captured_shapes:
-                        self._retired_evals.append(self._static_evals.pop(next(iter(self._static_evals))))
+                        _release(self._static_evals.pop(next(iter(self._static_evals))))
                 else:
                     _, loss = eng.forward(inp, False, gt)
                 total += loss
@@ -163,16 +171,21 @@ class Trainer(object):
             self.bestval_epoch = self.cur_epoch
         weights = _plain_state_dict(model)
         opt_state = optimizer.state_dict()
-        # every file goes to a temporary name first and is renamed into place; recent.log is written LAST, so a crash
-        # mid-save leaves the previous consistent (model, optimizer, log) triple behind, never a mixed one
+        # every file goes to a temporary name first and is renamed into place, so no file is ever torn; recent.log is written
+        # LAST and records size + mtime of the files it belongs to: a crash between the renames can leave model.pth one save
+        # newer than recent_optim.pth, and resume() then SAYS so (the files stay plain state_dicts the reference can load, so
+        # the pairing cannot be stored inside them)
         if best:
             _atomic_save(weights, os.path.join(logdir, "best_model.pth"))
             _atomic_save(opt_state, os.path.join(logdir, "best_optim.pth"))
         _atomic_save(weights, os.path.join(logdir, "model.pth"))
         _atomic_save(opt_state, os.path.join(logdir, "recent_optim.pth"))
         tmp = os.path.join(logdir, "recent.log.tmp")
+        table = self._log_table()
+        table["files"] = {n: _stamp(os.path.join(logdir, n)) for n in ("model.pth", "recent_optim.pth", "best_model.pth", "best_optim.pth")
+                          if os.path.isfile(os.path.join(logdir, n))}
         with open(tmp, "w") as f:
-            f.write(json.dumps(self._log_table()))
+            f.write(json.dumps(table))
             f.flush()
             os.fsync(f.fileno())
         os.replace(tmp, os.path.join(logdir, "recent.log"))
@@ -196,6 +209,11 @@ class Trainer(object):
         if not all(os.path.isfile(os.path.join(logdir, n)) for n in names):
             # no validation set / no improvement yet: save() never wrote the best_* pair - continue from the recent one
             names = ("model.pth", "recent_optim.pth")
+        stale = [n for n in names if n in table.get("files", {}) and table["files"][n] != _stamp(os.path.join(logdir, n))]
+        if stale:
+            import warnings
+            warnings.warn("checkpoint file(s) %s were written after recent.log (interrupted save?): model, optimizer state and "
+                          "counters may come from different saves" % ", ".join(stale))
         weights = torch.load(os.path.join(logdir, names[0]), map_location="cpu")
         model.load_state_dict({k[7:] if k.startswith("module.") else k: v for k, v in weights.items()})
         optimizer.load_state_dict(torch.load(os.path.join(logdir, names[1]), map_location="cpu"))
@@ -210,6 +228,11 @@ def _bucket_lanes(inp, bucket):
     out = dict(inp)
     out["lane"] = torch.nn.functional.pad(lane, (0, 0, 0, 0, 0, pad))
     return out
+
+
+def _stamp(path):
+    st = os.stat(path)
+    return [st.st_size, st.st_mtime_ns]
 
 
 def _atomic_save(obj, path):

@@ -46,7 +46,7 @@ def test_eval_forward_matches_oracle(variant):
     assert err <= 1e-4, "waypoint max abs err %g" % err
 
 
-@pytest.mark.parametrize("variant", ["vec", "rad"])
+@pytest.mark.parametrize("variant", ["vec", "rad", "img"])
 def test_golden_eval_waypoints(golden_dir, variant):
     """Same check against the committed vectors produced by the reference itself."""
     from oracle import harness
@@ -58,6 +58,13 @@ def test_golden_eval_waypoints(golden_dir, variant):
     with torch.no_grad():
         got = net(*_dev_args(args)).cpu().numpy()
     assert np.abs(got - g["eval_pred_wp"]).max() <= 1e-4
+    if variant == "img":   # the image agent has no vector map: its batch-1 call is the plain forward signature
+        if "eval_pred_wp_b1_agent" in g.files:
+            with torch.no_grad():
+                d = _dev_args(args)
+                got1 = net([d[0][0][:1]], [d[1][0][:1]], [d[2][0][:1]], None, None, None, d[6][:1], d[7][:1]).cpu().numpy()
+            assert np.abs(got1 - g["eval_pred_wp_b1_agent"]).max() <= 1e-4
+        return
     # agent-style call: batch 1, vectormap lane count passed as tensors (mmfn_vectornet.py:287-297)
     one = [[batch["lane"][:1][None].to(DEV)], [batch["lane_num"][:1].int().view(1, 1).to(DEV)],
            batch["lane_num"][:1].int().view(1, 1).to(DEV)]
@@ -319,6 +326,52 @@ def test_segmented_graph_step_equals_eager_steps():
     sa, sb = net_a.state_dict(), net_b.state_dict()
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
+
+
+def test_failed_capture_leaves_the_stream_usable(monkeypatch):
+    """a capture that raises (here: inside a branch lane, and inside the main graph) must END the
+    stream capture before the exception travels on - otherwise the callers' eager fallback dies in synchronize()."""
+    from mmfn_amd import engine as E
+    from mmfn_amd.parallel import GraphedStep
+    _, net, batch, args = _setup("vec", dropout=0.1)
+    dargs = _dev_args(args)
+    gt = batch["gt_wp"].to(DEV)
+    net.train()
+    inp = net._pack(*dargs)
+    net.train_step(inp, gt)
+    torch.cuda.synchronize()
+    real_vec, real_opt = E.VectorNet.bwd, E.Engine.optimizer_step
+
+    def boom(*a, **k):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("injected capture failure")
+        return real_vec(*a, **k)
+
+    for lane_graphs in (True, False):
+        monkeypatch.setattr(E.VectorNet, "bwd", boom)    # fails inside a lane (its own graph in lane-graph mode)
+        with pytest.raises(RuntimeError, match="injected"):
+            GraphedStep(net._engine_for(), None, inp, gt, warm=0, lane_graphs=lane_graphs)
+        monkeypatch.setattr(E.VectorNet, "bwd", real_vec)
+        assert not torch.cuda.is_current_stream_capturing()
+        torch.cuda.synchronize()                         # illegal while any stream of this thread is still capturing
+        loss = net.train_step(inp, gt)                   # the eager fallback the trainer / bench.py take
+        torch.cuda.synchronize()
+        assert torch.isfinite(loss).all()
+
+    def boom_opt(self, *a, **k):
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("injected capture failure")
+        return real_opt(self, *a, **k)
+
+    monkeypatch.setattr(E.Engine, "optimizer_step", boom_opt)
+    with pytest.raises(RuntimeError, match="injected"):
+        GraphedStep(net._engine_for(), None, inp, gt, warm=0)
+    monkeypatch.setattr(E.Engine, "optimizer_step", real_opt)
+    torch.cuda.synchronize()
+    step = GraphedStep(net._engine_for(), None, inp, gt, warm=0)   # and a later capture works
+    step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(step.loss).all()
 
 
 def test_driving_session_equals_reference_pipeline(golden_dir):

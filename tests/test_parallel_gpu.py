@@ -30,10 +30,11 @@ def test_two_ranks_over_rccl():
     if torch.cuda.device_count() < 2:
         pytest.skip("RCCL PATH NOT EXERCISED: %d GPU visible, two ranks need two devices (RCCL refuses two ranks per device)"
                     % torch.cuda.device_count())
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", MMFN_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4", MMFN_DIST_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               DP_CHECK_BATCH="32")   # the benched per-GPU batch
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29534", os.path.join(ROOT, "tools", "dp_check.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=3000)
     tail = (r.stdout + r.stderr)[-2000:]
     assert r.returncode == 0, tail
     assert "backend: nccl" in r.stdout and "reduced gradient == mean of per-rank oracle gradients: True" in r.stdout, tail
@@ -68,3 +69,83 @@ def test_rccl_c_abi_single_rank_communicator():
     torch.cuda.synchronize()
     assert float(y[0]) in (4.0, 8.0)    # capture itself may or may not execute the work once; replays double twice
     c.destroy()
+
+
+class _OneRank(object):
+    """torch.distributed stand-in for a 1-rank world (the C-ABI transport carries the collectives)."""
+
+    class ReduceOp(object):
+        SUM = 0
+
+    @staticmethod
+    def get_world_size():
+        return 1
+
+    @staticmethod
+    def get_rank():
+        return 0
+
+    @staticmethod
+    def broadcast(t, src):
+        return None
+
+
+def test_single_graph_data_parallel_step_with_captured_collectives():
+    """The step the C-ABI transport enables: forward + backward + 17 gradient-bucket all-reduces (issued from the branch lanes'
+    own streams onto the communication stream) + AdamW captured into ONE hipGraph.  One GPU -> a 1-rank communicator (the sum
+    over one rank is the identity), so the replayed step must equal the plain single-GPU graph bit for bit - which it only
+    does if every bucket's dependency (wait for its lane, rejoin before AdamW) was captured correctly."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from mmfn_amd.comm import RcclComm
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd.model import MMFN
+    from mmfn_amd.parallel import DataParallel, GraphedStep
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    inp, gt = bench.synth_inputs(2, dev, seed=3, lanes=16, n_lidar=4096)
+    outs = []
+    for use_dp in (False, True):
+        torch.manual_seed(5)
+        net = MMFN(GlobalConfig(), dev)
+        net.train()
+        eng = net._engine_for()
+        dp = None
+        if use_dp:
+            comm = RcclComm(0, 1)
+            dp = DataParallel(net, _OneRank, comm=comm, max_bucket_bytes=16 << 20)
+            assert dp.n_buckets() >= 17
+        eng.train_step(inp, gt, dp=dp)
+        step = GraphedStep(eng, dp, inp, gt, warm=0)
+        if use_dp:
+            assert step.single_graph and step.recorder.n_graphs == 1
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        outs.append((net._layout.params.clone(), float(step.loss.item())))
+        if use_dp:
+            comm.destroy()
+    assert outs[0][1] == outs[1][1]
+    assert torch.equal(outs[0][0], outs[1][0])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no outer launcher (how the driver starts the single-GPU bench): bench.py starts the two
+    ranks itself and rank 0 prints the JSON line with the `comm` block.  One GPU here, so both ranks share cuda:0 over gloo
+    (MMFN_BENCH_SINGLE_DEVICE); on a multi-GPU node the same command runs one rank per GPU over RCCL."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MMFN_BENCH_SINGLE_DEVICE="1", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--no-oracle-check", "--profile-steps", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, tail
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 64 and rec["value"] > 0 and rec["scaling"] == "weak"
+    c = rec["comm"]
+    assert c["ranks"] == 2 and c["buckets"] >= 10 and c["ranks_in_lock_step"] is True and c["exposed_ms_per_step"] >= 0.0
+    assert c["allreduce_bytes_per_step"] > 400e6 and rec["config"]["hipgraph"] is True

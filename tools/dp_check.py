@@ -58,11 +58,13 @@ def main():
     if rank == 0:
         net.load_state_dict(oracle.state_dict(), strict=True)
     comm = None
-    if os.environ.get("MMFN_DP_TRANSPORT") == "capi" and backend == "nccl":   # buckets through libmmfn_comm.so (C ABI over RCCL)
-        from mmfn_amd.comm import RcclComm
-        comm = RcclComm(rank, world, dist=dist)
+    if os.environ.get("MMFN_DP_TRANSPORT", "auto") != "torch" and backend == "nccl":
+        # buckets through libmmfn_comm.so (C ABI over RCCL; the step is then ONE hipGraph with the collectives inside) - the
+        # transport bench.py selects by itself when the library's communicator comes up
+        comm, _ = bench.open_capi_transport(rank, world, dist, dev, required=os.environ.get("MMFN_DP_TRANSPORT") == "capi")
     dp = DataParallel(net, dist, comm=comm); dp.broadcast_parameters()
-    inp, gt = bench.synth_inputs(2, dev, seed=7 + rank, lanes=16, n_lidar=4096)
+    batch = int(os.environ.get("DP_CHECK_BATCH", "2"))   # per rank; the nccl test runs the benched 32
+    inp, gt = bench.synth_inputs(batch, dev, seed=7 + rank, lanes=16 if batch <= 2 else 64, n_lidar=4096 if batch <= 2 else 16384)
     L = net._layout
     eng = net._engine_for()
     p0 = L.params.clone()
@@ -155,7 +157,8 @@ def main():
     dist.all_reduce(flags, group=cpu_pg)
     if rank == 0:
         print("backend:", backend, "| ranks:", world, "| devices:", ndev, "| gradient transport:",
-              "C ABI (mmfn_allreduce_sum_f32)" if comm is not None else "torch.distributed")
+              "C ABI (mmfn_allreduce_sum_f32)" if comm is not None else "torch.distributed", "| batch/rank:", batch,
+              "| buckets:", dp.n_buckets(), "| graphs per step:", seg.recorder.n_graphs)
         print("params identical across ranks:", same, "| reduced grads identical:", same_g, "| max |dp|: %.3e" % moved,
               "| loss %.6f (oracle %.6f)" % (loss.item(), loss32.item()), "| segmented graphs == eager:", same_seg)
         print("reduced gradient == mean of per-rank oracle gradients:", value_ok, "| median error ratio %.2f" % ratios[len(ratios) // 2],
