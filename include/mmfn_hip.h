@@ -135,6 +135,52 @@ typedef struct mmfn_gemm_desc {
   int64_t strideA, strideB, strideC;
 } mmfn_gemm_desc;
 
+/* ---- bf16 training mode (BASELINE configs[2]): GEMM / implicit-GEMM convolution with bf16 operands in HBM ------------- */
+/* forms of mmfn_gemm_bf16 */
+enum {
+  MMFN_G16_NT = 0,        /* C[M,N] = A[M,K] . B[N,K]^T, both k-contiguous (Linear forward; Linear dX over the W^T shadow) */
+  MMFN_G16_CONV_FWD = 1,  /* A = implicit im2col of x [B,H,W,Cin] (m = output pixel, k = (kh,kw,ci)), B = w [Cout][KH][KW][Cin] */
+  MMFN_G16_CONV_DGRAD = 2,/* A = transposed-conv gather of dY [B,OH,OW,Cout] (m = input pixel, k = (kh,kw,co)), any stride,
+                             B = the [Cin][KH][KW][Cout] weight shadow (mmfn_shadow_transpose_bf16); C = dx [B,H,W,Cin] */
+  MMFN_G16_TN = 3,        /* C[M,N] = sum_k A[k,M] . B[k,N] (Linear dW = dY^T X), fp32 output */
+  MMFN_G16_CONV_WGRAD = 4 /* A = dY [pixels][Cout], B = implicit im2col of x with k = output pixel, n = (kh,kw,ci): dw [Cout][KH][KW][Cin] fp32 */
+};
+#define MMFN_EPI16_OUT_F32 1024 /* C (and the MMFN_EPI_ACCUM read of it) is fp32 instead of bf16; res / aux stay bf16 */
+
+typedef struct mmfn_gemm16_desc {
+  const void* A;   /* bf16 */
+  const void* B;   /* bf16 */
+  void* C;         /* bf16, or fp32 with MMFN_EPI16_OUT_F32 (always for the TN forms) */
+  const float* bias;
+  const void* res; /* bf16 [M, ldr] */
+  const void* aux; /* bf16 [M, ldaux] (MMFN_EPI_MASK_AUX) */
+  const uint64_t* rng_state;
+  float* workspace; /* TN forms: split slabs, mmfn_gemm_bf16_workspace_bytes() */
+  double* stats;    /* NT forms, optional: BatchNorm batch-statistics partial rows of the raw output, [2 * ceil(M / tile rows)][2][N]
+                       doubles (sum, sum of squares), to be finished by mmfn_bn_finalize_stats_f32 */
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc, ldr, ldaux; /* in elements */
+  int32_t form;
+  int32_t H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
+  int32_t flags;       /* MMFN_EPI_* (BIAS RELU GELU MASK_AUX DROPOUT RESIDUAL ACCUM RELU_LAST) | MMFN_EPI16_OUT_F32 */
+  int32_t splitk;      /* TN forms: 0 auto, >= 1 forced number of contraction slices */
+  int32_t tile;        /* 0 auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128 */
+  uint32_t rng_stream;
+  float drop_p;
+  int32_t reserved;
+} mmfn_gemm16_desc;
+
+int mmfn_sizeof_gemm16_desc(void);
+int64_t mmfn_gemm_bf16_workspace_bytes(const mmfn_gemm16_desc* d);
+/* rows of d->stats a launch writes: 2 * ceil(M / tile rows) */
+int mmfn_gemm_bf16_stats_rows(const mmfn_gemm16_desc* d);
+/* Replaces, in the bf16 mode, the same aten addmm / cuDNN convolution forward / backward-data / backward-filter dispatches as
+ * mmfn_gemm_f32 (model_vec.py:82-89,121-123 Linear; :509-593 ResNet convolutions) with torch.autocast(bfloat16)-style arithmetic:
+ * bf16 operands, fp32 accumulation (v_mfma_f32_32x32x16_bf16), bf16 activations out, fp32 weight gradients out.
+ * Requirements: K % 64 == 0 and N % 8 == 0 (NT forms; conv: channel counts multiples of 64), leading dimensions multiples
+ * of 8, 16-byte aligned pointers; conv wgrad needs OW and OH*OW powers of two. */
+int mmfn_gemm_bf16(const mmfn_gemm16_desc* d, void* stream);
+
 /* C = epilogue(A*B).  Replaces aten addmm / cudnn convolution fwd, dgrad, wgrad dispatched by
  * nn.Linear (model_vec.py:82-89,121-123,...) and torchvision ResNet convs (model_vec.py:509-575). */
 int mmfn_gemm_f32(const mmfn_gemm_desc* d, void* stream);

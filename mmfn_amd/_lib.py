@@ -37,6 +37,25 @@ class GemmDesc(ctypes.Structure):
     ]
 
 
+class Gemm16Desc(ctypes.Structure):
+    """mmfn_gemm16_desc (include/mmfn_hip.h): the bf16-operand GEMM / convolution of the bf16 training mode."""
+    _fields_ = [
+        ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("res", _vp), ("aux", _vp), ("rng_state", _vp), ("workspace", _vp),
+        ("stats", _vp),
+        ("M", _i32), ("N", _i32), ("K", _i32),
+        ("lda", _i32), ("ldb", _i32), ("ldc", _i32), ("ldr", _i32), ("ldaux", _i32),
+        ("form", _i32),
+        ("H", _i32), ("W", _i32), ("Cin", _i32), ("OH", _i32), ("OW", _i32), ("Cout", _i32),
+        ("KH", _i32), ("KW", _i32), ("stride", _i32), ("pad", _i32),
+        ("flags", _i32), ("splitk", _i32), ("tile", _i32),
+        ("rng_stream", ctypes.c_uint32), ("drop_p", _f32), ("reserved", _i32),
+    ]
+
+
+G16_NT, G16_CONV_FWD, G16_CONV_DGRAD, G16_TN, G16_CONV_WGRAD = 0, 1, 2, 3, 4
+EPI16_OUT_F32 = 1024
+
+
 class MMFNLibraryError(RuntimeError):
     pass
 
@@ -62,7 +81,8 @@ def _parse_header(path=HEADER_PATH):
             for a in args.split(","):
                 a = a.strip()
                 if "*" in a:
-                    argtypes.append(ctypes.POINTER(GemmDesc) if "mmfn_gemm_desc" in a else _vp)
+                    argtypes.append(ctypes.POINTER(GemmDesc) if "mmfn_gemm_desc" in a else
+                                    (ctypes.POINTER(Gemm16Desc) if "mmfn_gemm16_desc" in a else _vp))
                 else:
                     base = a.replace("const", "").split()[0]
                     argtypes.append(_CTYPES[base])
@@ -88,6 +108,8 @@ def lib():
             fn.argtypes = args
         if handle.mmfn_sizeof_gemm_desc() != ctypes.sizeof(GemmDesc):
             raise MMFNLibraryError("mmfn_gemm_desc layout mismatch between C and ctypes")
+        if handle.mmfn_sizeof_gemm16_desc() != ctypes.sizeof(Gemm16Desc):
+            raise MMFNLibraryError("mmfn_gemm16_desc layout mismatch between C and ctypes")
         _lib = handle
     return _lib
 

@@ -38,6 +38,7 @@ class Recorder(object):
         self.ops = []           # ("graph", g) | ("lanes", fork, [(stream, g, done), ...]) | ("join", [events]) | ("side", ev, stream, g) | ("wait", ev, stream) | ("call", fn)
         self._g = None
         self.n_graphs = 0
+        self.extra_streams = []   # streams besides the engine's side streams that fork into the capture (DataParallel.comm_stream)
 
     # ------------------------------------------------------------------ capture
     def _begin(self):
@@ -84,6 +85,20 @@ class Recorder(object):
         """End whatever capture is in flight on the current stream and drop the half-recorded step."""
         g, self._g = self._g, None
         if g is not None:
+            # streams that were forked into this capture (branch lanes, side work, the data-parallel communication stream) and not
+            # joined yet when the exception struck: join them first - ending a capture with unjoined forks fails and leaves
+            # those streams in capture mode
+            cur = torch.cuda.current_stream()
+            for st in list(getattr(self.engine, "side", [])) + [s for s in self.extra_streams if s is not None]:
+                try:
+                    with torch.cuda.stream(st):
+                        forked = torch.cuda.is_current_stream_capturing()
+                    if forked:
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                        cur.wait_event(ev)
+                except Exception:
+                    pass
             try:
                 g.capture_end()
             except Exception:   # the capture may already have been invalidated by the failing call

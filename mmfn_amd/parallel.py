@@ -33,6 +33,8 @@ class DataParallel(object):
         self.comm_stream = None
         self.world = dist.get_world_size()
         self.layout = module._layout
+        if comm is not None and self.layout.device is not None and self.layout.device.type == "cuda":
+            self.comm_stream = torch.cuda.Stream(device=self.layout.device)
         lim = max(1, max_bucket_bytes // 4)
         L = self.layout
 
@@ -170,6 +172,8 @@ class GraphedStep(object):
         self.scale = scale
         eng.set_hyper(eng.hyper_rows(lr=lr, grad_scale=scale, **adam))  # the captured AdamW reads them from device memory
         rec = self.recorder = Recorder(eng, split_lanes=lane_graphs)   # None: MMFN_LANE_GRAPHS decides (default: forks inside the graphs)
+        if dp is not None:
+            rec.extra_streams.append(dp.comm_stream)
         if single_graph is None:
             single_graph = dp is not None and dp.comm is not None and not rec.split_lanes
         if single_graph and (dp is None or dp.comm is None):

@@ -1,0 +1,103 @@
+"""mmfn_gemm_bf16 (bf16 operands in HBM, v_mfma_f32_32x32x16_bf16, fp32 accumulate) against torch on the same bf16-rounded
+inputs: every form (Linear forward / data gradient / weight gradient, convolution forward / data gradient of stride 1 and 2 /
+weight gradient), every tile shape, the epilogue flags, the BatchNorm statistics by-product."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(torch.bfloat16)
+
+
+def _close(got, ref, tol=1.5e-2):
+    got, ref = got.float(), ref.float()
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= tol * scale + 1e-6, "max err %g vs scale %g" % (err, scale)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(6144, 512, 512), (200, 64, 64), (6144, 192, 256), (2048, 2048, 512)])
+def test_linear_forward_and_dx(M, N, K, tile):
+    from mmfn_amd import ops16
+    x, w = _rnd(M, K, seed=1), _rnd(N, K, scale=0.05, seed=2)
+    bias = torch.randn(N, device=DEV)
+    res = _rnd(M, N, seed=3)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops16.linear_fwd(x, w, bias, out=out, res=res, ldr=N, relu=True, tile=tile)
+    ref = torch.relu(x.float() @ w.float().t() + bias) + res.float()
+    _close(out, ref)
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops16.linear_fwd(x, w, None, out=out32, tile=tile)
+    _close(out32, x.float() @ w.float().t(), tol=2e-3)
+    # data gradient over the transposed shadow, ReLU mask of the layer below in the epilogue
+    dy = _rnd(M, N, seed=4)
+    wt = w.t().contiguous()                      # [K, N]
+    aux = _rnd(M, K, seed=5)
+    dx = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
+    ops16.linear_dx(dy, wt, out=dx, aux=aux, ldaux=K, tile=tile)
+    ref = (dy.float() @ w.float()) * (aux.float() > 0)
+    _close(dx, ref)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(6144, 512, 2048), (6144, 1536, 512), (520, 64, 256), (64, 128, 64)])
+def test_linear_weight_gradient_transpose_reads(M, N, K, tile):
+    """dW = dY^T X through ds_read_b64_tr_b16 (both operands contraction-major): asymmetric operands, ragged contraction."""
+    from mmfn_amd import ops16
+    dy, x = _rnd(M, N, seed=6), _rnd(M, K, seed=7)
+    dw = torch.empty(N, K, dtype=torch.float32, device=DEV)
+    ops16.linear_dw(dy, x, dw, tile=tile)
+    _close(dw, dy.float().t() @ x.float(), tol=2e-3)
+    for sk in (1, 3):
+        ops16.linear_dw(dy, x, dw, tile=tile, splitk=sk)
+        _close(dw, dy.float().t() @ x.float(), tol=2e-3)
+
+
+def test_dropout_epilogue_matches_the_f32_kernels_mask():
+    from mmfn_amd import ops, ops16
+    M, N, K = 512, 256, 128
+    x, w = _rnd(M, K, seed=1), _rnd(N, K, scale=0.1, seed=2)
+    rng = torch.tensor([1234, 7], dtype=torch.int64, device=DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops16.linear_fwd(x, w, None, out=out, drop_p=0.25, rng_state=rng, rng_stream=11)
+    ones = torch.ones(M, N, device=DEV)
+    mask = ops.dropout_apply(ones, torch.empty_like(ones), 0.25, rng, 11)   # the fp32 path's mask for the same (state, stream)
+    _close(out, (x.float() @ w.float().t()) * mask)
+
+
+CONVS = [(2, 32, 32, 64, 64, 3, 1, 1), (2, 16, 16, 128, 256, 3, 2, 1), (3, 16, 16, 128, 256, 1, 2, 0), (2, 8, 8, 512, 512, 3, 1, 1),
+         (2, 64, 64, 64, 128, 3, 2, 1), (4, 16, 16, 256, 256, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,k,s,p", CONVS)
+def test_convolution_forward_dgrad_wgrad(B, H, W, Ci, Co, k, s, p):
+    from mmfn_amd import ops, ops16
+    x = _rnd(B, H, W, Ci, seed=1)
+    w = _rnd(Co, k, k, Ci, scale=0.05, seed=2)
+    g, oshape = ops.conv_geom(x.shape, w.shape, s, p)
+    xt, wt = x.float().permute(0, 3, 1, 2).requires_grad_(True), w.float().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.conv2d(xt, wt, stride=s, padding=p)
+    y = torch.empty(oshape, dtype=torch.bfloat16, device=DEV)
+    rows = ops16.stats_rows(oshape[0] * oshape[1] * oshape[2], Co, k * k * Ci)
+    stats = torch.zeros(rows, 2, Co, dtype=torch.float64, device=DEV)
+    ops16.conv2d_fwd(x, w, s, p, y, stats=stats)
+    _close(y, ref.permute(0, 2, 3, 1))
+    # BatchNorm statistics by-product: sums of the fp32 accumulators over all output pixels
+    ref2 = ref.detach().permute(0, 2, 3, 1).reshape(-1, Co).double()
+    assert torch.allclose(stats[:, 0].sum(0), ref2.sum(0), rtol=2e-3, atol=2e-3 * ref2.abs().sum(0).max().item())
+    assert torch.allclose(stats[:, 1].sum(0), (ref2 * ref2).sum(0), rtol=2e-3)
+    dy = _rnd(*oshape, seed=3)
+    ref.backward(dy.float().permute(0, 3, 1, 2))
+    w_t = w.permute(3, 1, 2, 0).contiguous()      # [Ci, kh, kw, Co] shadow
+    dx = torch.empty_like(x)
+    ops16.conv2d_dgrad(dy, w_t, tuple(x.shape), tuple(w.shape), s, p, dx)
+    _close(dx, xt.grad.permute(0, 2, 3, 1))
+    dw = torch.empty(Co, k, k, Ci, dtype=torch.float32, device=DEV)
+    ops16.conv2d_wgrad(dy, x, tuple(w.shape), s, p, dw)
+    _close(dw, wt.grad.permute(0, 2, 3, 1), tol=3e-3)
