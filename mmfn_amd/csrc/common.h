@@ -8,6 +8,64 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- element-type-generic accessors (fp32 path: T = float; bf16 training mode: T = bf16_t, stored as raw 16-bit words).
+// Every streaming kernel moves 4 consecutive elements per access: 16 bytes of fp32 or 8 bytes of bf16; arithmetic is fp32.
+typedef __bf16 bf16_t;
+__device__ __forceinline__ unsigned short mmfn_f2bf(float f) {   // round to nearest even; NaN stays NaN
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40u);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ f32x4 ldx4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ldx4(const bf16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  f32x4 r;
+  r[0] = __uint_as_float(u.x << 16); r[1] = __uint_as_float(u.x & 0xFFFF0000u);
+  r[2] = __uint_as_float(u.y << 16); r[3] = __uint_as_float(u.y & 0xFFFF0000u);
+  return r;
+}
+__device__ __forceinline__ void stx4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void stx4(bf16_t* p, f32x4 v) {
+  uint2 u;
+  u.x = (unsigned)mmfn_f2bf(v[0]) | ((unsigned)mmfn_f2bf(v[1]) << 16);
+  u.y = (unsigned)mmfn_f2bf(v[2]) | ((unsigned)mmfn_f2bf(v[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ float ldx1(const float* p) { return *p; }
+__device__ __forceinline__ float ldx1(const bf16_t* p) { return __uint_as_float((unsigned)(*reinterpret_cast<const unsigned short*>(p)) << 16); }
+__device__ __forceinline__ void stx1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stx1(bf16_t* p, float v) { *reinterpret_cast<unsigned short*>(p) = mmfn_f2bf(v); }
+// N consecutive elements (N = 1, 2, 4) as floats
+template <int N, typename T> struct VecIO;
+template <typename T> struct VecIO<4, T> {
+  typedef f32x4 vec;
+  static __device__ __forceinline__ vec ld(const T* p) { return ldx4(p); }
+  static __device__ __forceinline__ void st(T* p, vec v) { stx4(p, v); }
+};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <> struct VecIO<2, float> {
+  typedef f32x2 vec;
+  static __device__ __forceinline__ vec ld(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+  static __device__ __forceinline__ void st(float* p, vec v) { *reinterpret_cast<f32x2*>(p) = v; }
+};
+template <> struct VecIO<2, bf16_t> {
+  typedef f32x2 vec;
+  static __device__ __forceinline__ vec ld(const bf16_t* p) {
+    const unsigned u = *reinterpret_cast<const unsigned*>(p);
+    vec r; r[0] = __uint_as_float(u << 16); r[1] = __uint_as_float(u & 0xFFFF0000u); return r;
+  }
+  static __device__ __forceinline__ void st(bf16_t* p, vec v) {
+    *reinterpret_cast<unsigned*>(p) = (unsigned)mmfn_f2bf(v[0]) | ((unsigned)mmfn_f2bf(v[1]) << 16);
+  }
+};
+typedef float f32x1 __attribute__((ext_vector_type(1)));
+template <typename T> struct VecIO<1, T> {
+  typedef f32x1 vec;
+  static __device__ __forceinline__ vec ld(const T* p) { vec r; r[0] = ldx1(p); return r; }
+  static __device__ __forceinline__ void st(T* p, vec v) { stx1(p, v[0]); }
+};
+
 #define MMFN_LAUNCH_CHECK()                        \
   do {                                             \
     hipError_t e__ = hipGetLastError();            \

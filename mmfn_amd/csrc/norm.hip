@@ -18,9 +18,11 @@ constexpr int NT = 256;
 // MODE 0: s1 = sum x,        s2 = sum x^2                      (BN forward statistics)
 // MODE 1: s1 = sum ge,       s2 = sum ge * xhat                (BN backward reductions)
 //         ge = g * (y > 0) when y != null else g;  xhat = (x - mean) * rstd
-template <int MODE>
-__global__ __launch_bounds__(NT) void col_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                         const float* __restrict__ y, const float* __restrict__ mean,
+// TX: element type of x (the convolution output), TA: of the activation-side tensors g, y (fp32 path: both float; bf16 mode:
+// both bf16, except the fp32 stems whose convolution output stays fp32)
+template <int MODE, typename TX, typename TA>
+__global__ __launch_bounds__(NT) void col_partial_kernel(const TX* __restrict__ x, const TA* __restrict__ g,
+                                                         const TA* __restrict__ y, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, int64_t M, int C,
                                                          int64_t rows_per_block, double* __restrict__ partials) {
   const int cq = C >> 2;           // float4 columns
@@ -38,14 +40,14 @@ __global__ __launch_bounds__(NT) void col_partial_kernel(const float* __restrict
   }
   for (int64_t r = r0 + rl; r < r1; r += RL) {
     const size_t off = (size_t)r * C + col4 * 4;
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+    const f32x4 xv = ldx4(x + off);
     if (MODE == 0) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) { const double v = xv[e]; s1[e] += v; s2[e] += v * v; }
     } else {
-      f32x4 gv = *reinterpret_cast<const f32x4*>(g + off);
+      f32x4 gv = ldx4(g + off);
       if (y) {
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + off);
+        const f32x4 yv = ldx4(y + off);
 #pragma unroll
         for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.0f ? gv[e] : 0.0f;
       }
@@ -167,14 +169,15 @@ __global__ __launch_bounds__(NT) void bn_fold_kernel(const float* __restrict__ w
 }
 
 // y = [relu]( x * alpha + beta [+ res] ), alpha = w * rstd, beta = b - mean * alpha
-__global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res,
-                                                      float* __restrict__ y, int64_t total4, int C,
+template <typename TX, typename TA>
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const TX* __restrict__ x, const TA* __restrict__ res,
+                                                      TA* __restrict__ y, int64_t total4, int C,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       const float* __restrict__ w, const float* __restrict__ b, int relu) {
   const int cq = C >> 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % cq) * 4;
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+    const f32x4 xv = ldx4(x + i * 4);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
       o[e] = xv[e] * alpha + beta;
     }
     if (res) {
-      const f32x4 rv = *reinterpret_cast<const f32x4*>(res + i * 4);
+      const f32x4 rv = ldx4(res + i * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] += rv[e];
     }
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.0f);
     }
-    *reinterpret_cast<f32x4*>(y + i * 4) = o;
+    stx4(y + i * 4, o);
   }
 }
 
@@ -212,21 +215,22 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int 
 }
 
 // dx = w * rstd * (ge - mean(ge) - xhat * mean(ge * xhat));  optionally ge_out = ge
-__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
-                                                          const float* __restrict__ x, float* __restrict__ dx,
-                                                          float* __restrict__ ge_out, int64_t total4, int C,
+template <typename TX, typename TA>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const TA* __restrict__ g, const TA* __restrict__ y,
+                                                          const TX* __restrict__ x, TX* __restrict__ dx,
+                                                          TA* __restrict__ ge_out, int64_t total4, int C,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           const float* __restrict__ w, const float* __restrict__ means) {
   const int cq = C >> 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % cq) * 4;
-    f32x4 gv = *reinterpret_cast<const f32x4*>(g + i * 4);
+    f32x4 gv = ldx4(g + i * 4);
     if (y) {
-      const f32x4 yv = *reinterpret_cast<const f32x4*>(y + i * 4);
+      const f32x4 yv = ldx4(y + i * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.0f ? gv[e] : 0.0f;
     }
-    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+    const f32x4 xv = ldx4(x + i * 4);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -234,8 +238,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restric
       const float xh = (xv[e] - mean[c4 + e]) * rs;
       o[e] = (gv[e] - means[c4 + e] - xh * means[C + c4 + e]) * (w[c4 + e] * rs);
     }
-    *reinterpret_cast<f32x4*>(dx + i * 4) = o;
-    if (ge_out) *reinterpret_cast<f32x4*>(ge_out + i * 4) = gv;
+    stx4(dx + i * 4, o);
+    if (ge_out) stx4(ge_out + i * 4, gv);
   }
 }
 
@@ -248,9 +252,9 @@ int bn_grid(int64_t M, int C, int64_t* rows_per_block) {
 
 // ------------------------------------------------------------------ LayerNorm
 // One wave per row, lane owns columns lane, lane+64, ... (C <= 512 -> <= 8 per lane).
-template <int MAXPL>
-__global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           const float* __restrict__ b, float* __restrict__ y,
+template <int MAXPL, typename TA>
+__global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const TA* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, TA* __restrict__ y,
                                                            float* __restrict__ mean, float* __restrict__ rstd, int M, int C,
                                                            float eps, int act) {
   const int lane = threadIdx.x & 63;
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const float* __restri
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXPL; ++i)
-    if (i < pl) { v[i] = x[(size_t)row * C + lane + 64 * i]; s += v[i]; }
+    if (i < pl) { v[i] = ldx1(x + (size_t)row * C + lane + 64 * i); s += v[i]; }
   const float mu = wave_sum(s) / (float)C;
   float q = 0.f;
 #pragma unroll
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const float* __restri
       float o = (v[i] - mu) * rs * w[c] + b[c];
       if (act == 1) o = fmaxf(o, 0.f);
       else if (act == 2) o = mmfn_gelu(o);
-      y[(size_t)row * C + c] = o;
+      stx1(y + (size_t)row * C + c, o);
     }
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
@@ -283,16 +287,17 @@ __global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const float* __restri
 // One row per wave iteration; lane l owns VW consecutive columns per 64*VW-column chunk (4/8/16-byte accesses),
 // NCH chunks per row (C = 64 * VW * NCH).  Blocks are small (8 rows at M = 6144 -> 768 blocks) so the whole chip
 // streams rows; the per-block dweight / dbias partial rows are combined by colsum_finalize_kernel in fp64.
-template <int VW, int NCH>
-__global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x,
+template <int VW, int NCH, typename TA>
+__global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const TA* __restrict__ g, const TA* __restrict__ x,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ dres, float* __restrict__ dx,
+                                                           const TA* __restrict__ dres, TA* __restrict__ dx,
                                                            float* __restrict__ partials /* [grid][2][C] */, int M,
-                                                           int act, int rows_per_block, float* __restrict__ dxd, float drop_p,
+                                                           int act, int rows_per_block, TA* __restrict__ dxd, float drop_p,
                                                            const uint64_t* __restrict__ rng_state, uint32_t rng_stream,
                                                            int want_sum) {
   typedef float vec __attribute__((ext_vector_type(VW)));
+  typedef VecIO<VW, TA> IO;
   constexpr int C = 64 * VW * NCH;
   // optional second output dxd = dx * dropout keep-scale(row * C + col): the gradient entering the residual branch whose
   // forward applied that dropout in a GEMM epilogue (same counter RNG index) - saves a separate elementwise pass
@@ -320,8 +325,8 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restri
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const size_t off = (size_t)row * C + (i * 64 + lane) * VW;
-      const vec xv = *reinterpret_cast<const vec*>(x + off);
-      vec gg = *reinterpret_cast<const vec*>(g + off);
+      const vec xv = IO::ld(x + off);
+      vec gg = IO::ld(g + off);
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
         const float xhat = (xv[j] - mu) * rs;
@@ -348,13 +353,13 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restri
       vec o;
 #pragma unroll
       for (int j = 0; j < VW; ++j) o[j] = rs * (a[i][j] - c1 - xh[i][j] * c2);
-      if (dres) o += *reinterpret_cast<const vec*>(dres + off);
-      *reinterpret_cast<vec*>(dx + off) = o;
+      if (dres) o += IO::ld(dres + off);
+      IO::st(dx + off, o);
       if (dxd) {
         vec od;
 #pragma unroll
         for (int j = 0; j < VW; ++j) od[j] = o[j] * mmfn_dropout_scale(dkey, (uint64_t)off + j, drop_p, inv_keep);
-        *reinterpret_cast<vec*>(dxd + off) = od;
+        IO::st(dxd + off, od);
         o = od;
       }
       if (want_sum) ds[i] += o;
@@ -398,7 +403,8 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ partials, int n
 }
 
 // generic column sum: out[c] = sum_r in[r, c]   (bias gradients)
-__global__ __launch_bounds__(NT) void colsum_partial_kernel(const float* __restrict__ in, int64_t M, int C, int ld,
+template <typename TA>
+__global__ __launch_bounds__(NT) void colsum_partial_kernel(const TA* __restrict__ in, int64_t M, int C, int ld,
                                                             int64_t rows_per_block, float* __restrict__ partials,
                                                             int64_t stride_in) {
   in += (size_t)blockIdx.z * stride_in;                       // batch entry (blockIdx.z): its matrix, its partial rows
@@ -409,12 +415,12 @@ __global__ __launch_bounds__(NT) void colsum_partial_kernel(const float* __restr
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int64_t r = r0;
     for (; r + 3 < r1; r += 4) {
-      s0 += in[(size_t)r * ld + c];
-      s1 += in[(size_t)(r + 1) * ld + c];
-      s2 += in[(size_t)(r + 2) * ld + c];
-      s3 += in[(size_t)(r + 3) * ld + c];
+      s0 += ldx1(in + (size_t)r * ld + c);
+      s1 += ldx1(in + (size_t)(r + 1) * ld + c);
+      s2 += ldx1(in + (size_t)(r + 2) * ld + c);
+      s3 += ldx1(in + (size_t)(r + 3) * ld + c);
     }
-    for (; r < r1; ++r) s0 += in[(size_t)r * ld + c];
+    for (; r < r1; ++r) s0 += ldx1(in + (size_t)r * ld + c);
     partials[(size_t)blockIdx.x * C + c] = (s0 + s1) + (s2 + s3);
   }
 }
@@ -437,20 +443,34 @@ __global__ void colsum_finalize1_kernel(const float* __restrict__ partials, int 
 
 extern "C" int64_t mmfn_norm_workspace_bytes(int C) { return (int64_t)1024 * 2 * C * (int64_t)sizeof(double); }
 
-extern "C" int mmfn_bn_train_stats_f32(const float* x, int64_t M, int C, float eps, float momentum, float* mean,
-                                       float* rstd, float* running_mean, float* running_var,
-                                       int64_t* num_batches_tracked, void* workspace, void* stream) {
+namespace {
+template <typename TX>
+int bn_train_stats_launch(const TX* x, int64_t M, int C, float eps, float momentum, float* mean, float* rstd, float* running_mean,
+                          float* running_var, int64_t* num_batches_tracked, void* workspace, void* stream) {
   if (C % 4 || C > 1024 || (NT % (C / 4)) || M <= 0 || !workspace) return MMFN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   int64_t rpb;
   const int nblk = bn_grid(M, C, &rpb);
-  hipLaunchKernelGGL(col_partial_kernel<0>, dim3(nblk), dim3(NT), 0, s, x, nullptr, nullptr, nullptr, nullptr, M, C, rpb,
-                     (double*)workspace);
+  hipLaunchKernelGGL((col_partial_kernel<0, TX, TX>), dim3(nblk), dim3(NT), 0, s, x, (const TX*)nullptr, (const TX*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, M, C, rpb, (double*)workspace);
   MMFN_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, (const double*)workspace, nblk, M, C,
                      eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked);
   MMFN_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace
+
+extern "C" int mmfn_bn_train_stats_f32(const float* x, int64_t M, int C, float eps, float momentum, float* mean,
+                                       float* rstd, float* running_mean, float* running_var,
+                                       int64_t* num_batches_tracked, void* workspace, void* stream) {
+  return bn_train_stats_launch(x, M, C, eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked, workspace, stream);
+}
+extern "C" int mmfn_bn_train_stats_bf16(const void* x, int64_t M, int C, float eps, float momentum, float* mean,
+                                        float* rstd, float* running_mean, float* running_var,
+                                        int64_t* num_batches_tracked, void* workspace, void* stream) {
+  return bn_train_stats_launch((const bf16_t*)x, M, C, eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked,
+                               workspace, stream);
 }
 
 // Second half of mmfn_bn_train_stats_f32 for producers that emit the per-block (sum, sum of squares) rows themselves
@@ -482,37 +502,71 @@ extern "C" int mmfn_bn_fold_f32(const float* w, int Cout, int K, const float* ga
   return 0;
 }
 
-extern "C" int mmfn_bn_apply_f32(const float* x, const float* res, float* y, int64_t M, int C, const float* mean,
-                                 const float* rstd, const float* weight, const float* bias, int relu, void* stream) {
+namespace {
+template <typename TX, typename TA>
+int bn_apply_launch(const TX* x, const TA* res, TA* y, int64_t M, int C, const float* mean, const float* rstd, const float* weight,
+                    const float* bias, int relu, void* stream) {
   if (C % 4 || M <= 0) return MMFN_EINVAL;
   const int64_t total4 = M * (C / 4);
   const int blocks = (int)std::min<int64_t>(ceil_div64(total4, NT), 8192);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, res, y, total4, C, mean, rstd,
+  hipLaunchKernelGGL((bn_apply_kernel<TX, TA>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, res, y, total4, C, mean, rstd,
                      weight, bias, relu);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
-
-extern "C" int mmfn_bn_bwd_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean,
-                               const float* rstd, const float* weight, float* dx, float* ge_out, float* dweight,
-                               float* dbias, void* workspace, void* stream) {
+// reduce != 0: the two reductions (dweight, dbias, means);  apply != 0: the elementwise pass (dx, ge_out) from `means`
+template <typename TX, typename TA>
+int bn_bwd_launch(const TA* g, const TA* y, const TX* x, int64_t M, int C, const float* mean, const float* rstd, const float* weight,
+                  TX* dx, TA* ge_out, float* dweight, float* dbias, float* means, void* workspace, int reduce, int apply, void* stream) {
   if (C % 4 || C > 1024 || (NT % (C / 4)) || M <= 0 || !workspace) return MMFN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   int64_t rpb;
   const int nblk = bn_grid(M, C, &rpb);
   double* partials = (double*)workspace;
-  float* means = (float*)(partials + (size_t)nblk * 2 * C);
-  hipLaunchKernelGGL(col_partial_kernel<1>, dim3(nblk), dim3(NT), 0, s, x, g, y, mean, rstd, M, C, rpb, partials);
-  MMFN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, partials, nblk, M, C, dweight, dbias,
-                     means);
-  MMFN_LAUNCH_CHECK();
-  const int64_t total4 = M * (C / 4);
-  const int blocks = (int)std::min<int64_t>(ceil_div64(total4, NT), 8192);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(NT), 0, s, g, y, x, dx, ge_out, total4, C, mean, rstd, weight,
-                     means);
-  MMFN_LAUNCH_CHECK();
+  if (!means) means = (float*)(partials + (size_t)nblk * 2 * C);
+  if (reduce) {
+    hipLaunchKernelGGL((col_partial_kernel<1, TX, TA>), dim3(nblk), dim3(NT), 0, s, x, g, y, mean, rstd, M, C, rpb, partials);
+    MMFN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, partials, nblk, M, C, dweight, dbias,
+                       means);
+    MMFN_LAUNCH_CHECK();
+  }
+  if (apply) {
+    const int64_t total4 = M * (C / 4);
+    const int blocks = (int)std::min<int64_t>(ceil_div64(total4, NT), 8192);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<TX, TA>), dim3(blocks), dim3(NT), 0, s, g, y, x, dx, ge_out, total4, C, mean, rstd, weight,
+                       means);
+    MMFN_LAUNCH_CHECK();
+  }
   return 0;
+}
+}  // namespace
+
+extern "C" int mmfn_bn_apply_f32(const float* x, const float* res, float* y, int64_t M, int C, const float* mean,
+                                 const float* rstd, const float* weight, const float* bias, int relu, void* stream) {
+  return bn_apply_launch(x, res, y, M, C, mean, rstd, weight, bias, relu, stream);
+}
+/* bf16 mode: y / res bf16; x (the convolution output) bf16, or fp32 when x_is_f32 (the 7x7 stems, whose convolution stays fp32) */
+extern "C" int mmfn_bn_apply_bf16(const void* x, int x_is_f32, const void* res, void* y, int64_t M, int C, const float* mean,
+                                  const float* rstd, const float* weight, const float* bias, int relu, void* stream) {
+  if (x_is_f32) return bn_apply_launch((const float*)x, (const bf16_t*)res, (bf16_t*)y, M, C, mean, rstd, weight, bias, relu, stream);
+  return bn_apply_launch((const bf16_t*)x, (const bf16_t*)res, (bf16_t*)y, M, C, mean, rstd, weight, bias, relu, stream);
+}
+
+extern "C" int mmfn_bn_bwd_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean,
+                               const float* rstd, const float* weight, float* dx, float* ge_out, float* dweight,
+                               float* dbias, void* workspace, void* stream) {
+  return bn_bwd_launch(g, y, x, M, C, mean, rstd, weight, dx, ge_out, dweight, dbias, (float*)nullptr, workspace, 1, 1, stream);
+}
+/* bf16 mode: g, y, ge_out bf16; x and dx (the convolution output and its gradient) bf16, or both fp32 when x_is_f32 (stems) */
+extern "C" int mmfn_bn_bwd_bf16(const void* g, const void* y, const void* x, int x_is_f32, int64_t M, int C, const float* mean,
+                                const float* rstd, const float* weight, void* dx, void* ge_out, float* dweight, float* dbias,
+                                void* workspace, void* stream) {
+  if (x_is_f32)
+    return bn_bwd_launch((const bf16_t*)g, (const bf16_t*)y, (const float*)x, M, C, mean, rstd, weight, (float*)dx, (bf16_t*)ge_out,
+                         dweight, dbias, (float*)nullptr, workspace, 1, 1, stream);
+  return bn_bwd_launch((const bf16_t*)g, (const bf16_t*)y, (const bf16_t*)x, M, C, mean, rstd, weight, (bf16_t*)dx, (bf16_t*)ge_out,
+                       dweight, dbias, (float*)nullptr, workspace, 1, 1, stream);
 }
 
 // First two launches of mmfn_bn_bwd_f32 only: dweight, dbias and means[2][C] = (mean(ge), mean(ge * xhat)); the caller
@@ -520,26 +574,30 @@ extern "C" int mmfn_bn_bwd_f32(const float* g, const float* y, const float* x, i
 extern "C" int mmfn_bn_bwd_reduce_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean,
                                       const float* rstd, float* dweight, float* dbias, float* means, void* workspace,
                                       void* stream) {
-  if (C % 4 || C > 1024 || (NT % (C / 4)) || M <= 0 || !workspace || !means) return MMFN_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  int64_t rpb;
-  const int nblk = bn_grid(M, C, &rpb);
-  double* partials = (double*)workspace;
-  hipLaunchKernelGGL(col_partial_kernel<1>, dim3(nblk), dim3(NT), 0, s, x, g, y, mean, rstd, M, C, rpb, partials);
-  MMFN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, partials, nblk, M, C, dweight, dbias,
-                     means);
-  MMFN_LAUNCH_CHECK();
-  return 0;
+  if (!means) return MMFN_EINVAL;
+  return bn_bwd_launch(g, y, x, M, C, mean, rstd, (const float*)nullptr, (float*)nullptr, (float*)nullptr, dweight, dbias, means,
+                       workspace, 1, 0, stream);
 }
 
-extern "C" int mmfn_layernorm_fwd_f32(const float* x, const float* weight, const float* bias, float* y, float* mean,
-                                      float* rstd, int M, int C, float eps, int act, void* stream) {
+namespace {
+template <typename TA>
+int layernorm_fwd_launch(const TA* x, const float* weight, const float* bias, TA* y, float* mean, float* rstd, int M, int C, float eps,
+                         int act, void* stream) {
   if (C % 64 || C > 512 || M <= 0) return MMFN_EINVAL;
-  hipLaunchKernelGGL(layernorm_fwd_kernel<8>, dim3(ceil_div(M, NT / 64)), dim3(NT), 0, (hipStream_t)stream, x, weight, bias, y,
+  hipLaunchKernelGGL((layernorm_fwd_kernel<8, TA>), dim3(ceil_div(M, NT / 64)), dim3(NT), 0, (hipStream_t)stream, x, weight, bias, y,
                      mean, rstd, M, C, eps, act);
   MMFN_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace
+
+extern "C" int mmfn_layernorm_fwd_f32(const float* x, const float* weight, const float* bias, float* y, float* mean,
+                                      float* rstd, int M, int C, float eps, int act, void* stream) {
+  return layernorm_fwd_launch(x, weight, bias, y, mean, rstd, M, C, eps, act, stream);
+}
+extern "C" int mmfn_layernorm_fwd_bf16(const void* x, const float* weight, const float* bias, void* y, float* mean,
+                                       float* rstd, int M, int C, float eps, int act, void* stream) {
+  return layernorm_fwd_launch((const bf16_t*)x, weight, bias, (bf16_t*)y, mean, rstd, M, C, eps, act, stream);
 }
 
 extern "C" int mmfn_layernorm_bwd_f32(const float* g, const float* x, const float* weight, const float* bias,
@@ -555,17 +613,18 @@ static int ln_bwd_rows_per_block(int M) { return std::max(8, ceil_div(M, 384)); 
 
 extern "C" int mmfn_layernorm_bwd_rows(int M) { return M > 0 ? ceil_div(M, ln_bwd_rows_per_block(M)) : 0; }
 
-extern "C" int mmfn_layernorm_bwd_partial_f32(const float* g, const float* x, const float* weight, const float* bias,
-                                              const float* mean, const float* rstd, const float* dres, float* dx, int M, int C,
-                                              int act, float* dx_dropped, float drop_p, const uint64_t* rng_state,
-                                              uint32_t rng_stream, int want_colsum, float* partials, void* stream) {
+namespace {
+template <typename TA>
+int layernorm_bwd_partial_launch(const TA* g, const TA* x, const float* weight, const float* bias, const float* mean, const float* rstd,
+                                 const TA* dres, TA* dx, int M, int C, int act, TA* dx_dropped, float drop_p,
+                                 const uint64_t* rng_state, uint32_t rng_stream, int want_colsum, float* partials, void* stream) {
   if (M <= 0 || !partials) return MMFN_EINVAL;
   if (dx_dropped && (!rng_state || drop_p <= 0.f || drop_p >= 1.f)) return MMFN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int rpb = ln_bwd_rows_per_block(M);
   const int nblk = ceil_div(M, rpb);
 #define MMFN_LN_BWD(VW, NCH) \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<VW, NCH>), dim3(nblk), dim3(NT), 0, s, g, x, weight, bias, mean, rstd, dres, dx, \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<VW, NCH, TA>), dim3(nblk), dim3(NT), 0, s, g, x, weight, bias, mean, rstd, dres, dx, \
                      partials, M, act, rpb, dx_dropped, drop_p, rng_state, rng_stream, want_colsum ? 1 : 0)
   switch (C) {
     case 64: MMFN_LN_BWD(1, 1); break;
@@ -577,6 +636,22 @@ extern "C" int mmfn_layernorm_bwd_partial_f32(const float* g, const float* x, co
 #undef MMFN_LN_BWD
   MMFN_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace
+
+extern "C" int mmfn_layernorm_bwd_partial_f32(const float* g, const float* x, const float* weight, const float* bias,
+                                              const float* mean, const float* rstd, const float* dres, float* dx, int M, int C,
+                                              int act, float* dx_dropped, float drop_p, const uint64_t* rng_state,
+                                              uint32_t rng_stream, int want_colsum, float* partials, void* stream) {
+  return layernorm_bwd_partial_launch(g, x, weight, bias, mean, rstd, dres, dx, M, C, act, dx_dropped, drop_p, rng_state, rng_stream,
+                                      want_colsum, partials, stream);
+}
+extern "C" int mmfn_layernorm_bwd_partial_bf16(const void* g, const void* x, const float* weight, const float* bias,
+                                               const float* mean, const float* rstd, const void* dres, void* dx, int M, int C,
+                                               int act, void* dx_dropped, float drop_p, const uint64_t* rng_state,
+                                               uint32_t rng_stream, int want_colsum, float* partials, void* stream) {
+  return layernorm_bwd_partial_launch((const bf16_t*)g, (const bf16_t*)x, weight, bias, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M,
+                                      C, act, (bf16_t*)dx_dropped, drop_p, rng_state, rng_stream, want_colsum, partials, stream);
 }
 
 extern "C" int mmfn_layernorm_bwd_finalize_f32(const float* partials, int rows, int C, float* dweight, float* dbias,
@@ -610,14 +685,16 @@ extern "C" int64_t mmfn_colsum_workspace_bytes(int64_t M, int C) {
   return (int64_t)colsum_blocks(M, &rpb) * C * (int64_t)sizeof(float);
 }
 
-extern "C" int mmfn_colsum_batched_f32(const float* in, int batch, int64_t stride_in, int64_t M, int C, int ld, float* out,
-                                       int64_t stride_out, void* workspace, void* stream) {
+namespace {
+template <typename TA>
+int colsum_batched_launch(const TA* in, int batch, int64_t stride_in, int64_t M, int C, int ld, float* out, int64_t stride_out,
+                          void* workspace, void* stream) {
   if (M <= 0 || C <= 0 || batch <= 0 || batch > 65535 || !workspace) return MMFN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   int64_t rpb;
   const int nblk = colsum_blocks(M, &rpb);
   float* partials = (float*)workspace;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, std::min(ceil_div(C, NT), 1024), batch), dim3(NT), 0, s, in, M, C, ld, rpb,
+  hipLaunchKernelGGL(colsum_partial_kernel<TA>, dim3(nblk, std::min(ceil_div(C, NT), 1024), batch), dim3(NT), 0, s, in, M, C, ld, rpb,
                      partials, stride_in);
   MMFN_LAUNCH_CHECK();
   hipLaunchKernelGGL(colsum_finalize1_kernel, dim3(ceil_div(C, FIN_COLS), batch), dim3(FIN_COLS * FIN_LANES), 0, s, partials, nblk, C,
@@ -625,7 +702,17 @@ extern "C" int mmfn_colsum_batched_f32(const float* in, int batch, int64_t strid
   MMFN_LAUNCH_CHECK();
   return 0;
 }
+}  // namespace
+
+extern "C" int mmfn_colsum_batched_f32(const float* in, int batch, int64_t stride_in, int64_t M, int C, int ld, float* out,
+                                       int64_t stride_out, void* workspace, void* stream) {
+  return colsum_batched_launch(in, batch, stride_in, M, C, ld, out, stride_out, workspace, stream);
+}
 
 extern "C" int mmfn_colsum_f32(const float* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream) {
   return mmfn_colsum_batched_f32(in, 1, 0, M, C, ld, out, 0, workspace, stream);
+}
+/* column sums of a bf16 [M, C] matrix (row stride ld elements) into fp32: bias gradients in the bf16 mode */
+extern "C" int mmfn_colsum_bf16(const void* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream) {
+  return colsum_batched_launch((const bf16_t*)in, 1, 0, M, C, ld, out, 0, workspace, stream);
 }

@@ -14,7 +14,8 @@ namespace {
 constexpr int NT = 256;
 
 // ---------------------------------------------------------------- maxpool 3x3 s2 p1
-__global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                          uint8_t* __restrict__ idx, int B, int H, int W, int C, int OH,
                                                          int OW) {
   const int cq = C >> 2;
@@ -36,14 +37,14 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const float* __restrict
       for (int kw = 0; kw < 3; ++kw) {
         const int iw = ow * 2 - 1 + kw;
         if ((unsigned)iw >= (unsigned)W) continue;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)(b * H + ih) * W + iw) * C + c4);
+        const f32x4 v = ldx4(x + ((size_t)(b * H + ih) * W + iw) * C + c4);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (first || v[e] > best[e] || v[e] != v[e]) { best[e] = v[e]; bi[e] = kh * 3 + kw; }
         first = false;
       }
     }
-    *reinterpret_cast<f32x4*>(y + (size_t)(i / cq) * C + c4) = best;
+    stx4(y + (size_t)(i / cq) * C + c4, best);
     uchar4 o;
     o.x = (uint8_t)bi[0]; o.y = (uint8_t)bi[1]; o.z = (uint8_t)bi[2]; o.w = (uint8_t)bi[3];
     *reinterpret_cast<uchar4*>(idx + (size_t)(i / cq) * C + c4) = o;
@@ -51,8 +52,9 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const float* __restrict
 }
 
 // gather form: input pixel collects from the <=4 windows that contain it and whose argmax is it
-__global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const float* __restrict__ gy, const uint8_t* __restrict__ idx,
-                                                         float* __restrict__ gx, int B, int H, int W, int C, int OH, int OW) {
+template <typename T>
+__global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ gy, const uint8_t* __restrict__ idx,
+                                                         T* __restrict__ gx, int B, int H, int W, int C, int OH, int OW) {
   const int cq = C >> 2;
   const int64_t total = (int64_t)B * H * W * cq;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -71,25 +73,28 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const float* __restrict
         const int me = kh * 3 + kw;
         const size_t off = ((size_t)(b * OH + oh) * OW + ow) * C + c4;
         const uchar4 a = *reinterpret_cast<const uchar4*>(idx + off);
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gy + off);
+        const f32x4 g = ldx4(gy + off);
         if (a.x == me) acc[0] += g[0];
         if (a.y == me) acc[1] += g[1];
         if (a.z == me) acc[2] += g[2];
         if (a.w == me) acc[3] += g[3];
       }
-    *reinterpret_cast<f32x4*>(gx + (size_t)(i / cq) * C + c4) = acc;
+    stx4(gx + (size_t)(i / cq) * C + c4, acc);
   }
 }
 
 // ---------------------------------------------------------------- token assembly
-struct FeatPtrs { const float* p[4]; };
-struct GradPtrs { float* p[4]; };
+template <typename T> struct FeatPtrsT { const T* p[4]; };
+template <typename T> struct GradPtrsT { T* p[4]; };
+typedef FeatPtrsT<float> FeatPtrs;
+typedef GradPtrsT<float> GradPtrs;
 
 // tok[b, m*64 + ay*8+ax, c] = drop( pos[t,c] + mean_{kxk}(F_m[b, ay*k.., ax*k.., c]) + vel_w[c]*v[b] + vel_b[c] )
-__global__ __launch_bounds__(NT) void tokens_fwd_kernel(FeatPtrs feats, int n_modal, int B, int S, int C,
+template <typename TT>
+__global__ __launch_bounds__(NT) void tokens_fwd_kernel(FeatPtrsT<TT> feats, int n_modal, int B, int S, int C,
                                                         const float* __restrict__ pos, const float* __restrict__ vel_w,
                                                         const float* __restrict__ vel_b, const float* __restrict__ velocity,
-                                                        float* __restrict__ tok, float drop_p,
+                                                        TT* __restrict__ tok, float drop_p,
                                                         const uint64_t* __restrict__ rng_state, uint32_t rng_stream) {
   const int cq = C >> 2;
   const int k = S >> 3;
@@ -103,11 +108,11 @@ __global__ __launch_bounds__(NT) void tokens_fwd_kernel(FeatPtrs feats, int n_mo
     const int64_t row = i / cq;  // b*T + t
     const int t = (int)(row % T), b = (int)(row / T);
     const int m = t >> 6, a = t & 63, ay = a >> 3, ax = a & 7;
-    const float* f = feats.p[m] + ((size_t)(b * S + ay * k) * S + ax * k) * C + c4;
+    const TT* f = feats.p[m] + ((size_t)(b * S + ay * k) * S + ax * k) * C + c4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int dy = 0; dy < k; ++dy)
       for (int dx = 0; dx < k; ++dx) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(f + ((size_t)dy * S + dx) * C);
+        const f32x4 v = ldx4(f + ((size_t)dy * S + dx) * C);
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[e] += v[e];
       }
@@ -120,14 +125,15 @@ __global__ __launch_bounds__(NT) void tokens_fwd_kernel(FeatPtrs feats, int n_mo
       o[e] = (pe[e] + pooled) + (vel_w[c4 + e] * vb + vel_b[c4 + e]);
       if (drop_p > 0.f) o[e] *= mmfn_dropout_scale(key, (uint64_t)row * C + c4 + e, drop_p, 1.0f / (1.0f - drop_p));
     }
-    *reinterpret_cast<f32x4*>(tok + (size_t)row * C + c4) = o;
+    stx4(tok + (size_t)row * C + c4, o);
   }
 }
 
 // gm = g * dropmask (in place into gtok), plus per-(b) partial sums for pos/vel gradients:
 //   dpos[t,c]  = sum_b gm[b,t,c];  dvel_w[c] = sum_{b,t} gm*v[b];  dvel_b[c] = sum_{b,t} gm
 // one block per token index t (all b): deterministic, no atomics; vel partials [T][2][C].
-__global__ __launch_bounds__(NT) void tokens_bwd_kernel(float* __restrict__ gtok, int B, int T, int C,
+template <typename TT>
+__global__ __launch_bounds__(NT) void tokens_bwd_kernel(TT* __restrict__ gtok, int B, int T, int C,
                                                         const float* __restrict__ velocity, float* __restrict__ dpos,
                                                         float* __restrict__ vel_partials, float drop_p,
                                                         const uint64_t* __restrict__ rng_state, uint32_t rng_stream) {
@@ -138,10 +144,10 @@ __global__ __launch_bounds__(NT) void tokens_bwd_kernel(float* __restrict__ gtok
     float sp = 0.f, sw = 0.f;
     for (int b = 0; b < B; ++b) {
       const size_t off = ((size_t)b * T + t) * C + c;
-      float g = gtok[off];
+      float g = ldx1(gtok + off);
       if (drop_p > 0.f) {
         g *= mmfn_dropout_scale(key, (uint64_t)off, drop_p, 1.0f / (1.0f - drop_p));
-        gtok[off] = g;
+        stx1(gtok + off, g);
       }
       sp += g;
       sw += g * velocity[b];
@@ -179,8 +185,9 @@ __global__ __launch_bounds__(TF_COLS * TF_LANES) void tokens_bwd_finalize_kernel
 
 // ---------------------------------------------------------------- bilinear upsample (align_corners) + add
 // out[b,y,x,c] = F[b,y,x,c] + bilinear(tok[b, m*64 + 8x8 grid, c])   (tok row stride = C)
-__global__ __launch_bounds__(NT) void upsample_add_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ tok,
-                                                              float* __restrict__ out, int B, int S, int C, int T, int m) {
+template <typename TT>
+__global__ __launch_bounds__(NT) void upsample_add_fwd_kernel(const TT* __restrict__ feat, const TT* __restrict__ tok,
+                                                              TT* __restrict__ out, int B, int S, int C, int T, int m) {
   const int cq = C >> 2;
   const int64_t total = (int64_t)B * S * S * cq;
   const float r = (S > 1) ? (float)(8 - 1) / (float)(S - 1) : 0.f;
@@ -190,10 +197,10 @@ __global__ __launch_bounds__(NT) void upsample_add_fwd_kernel(const float* __res
     const int x = (int)(p % S); p /= S;
     const int y = (int)(p % S);
     const int b = (int)(p / S);
-    const f32x4 f = *reinterpret_cast<const f32x4*>(feat + (size_t)(i / cq) * C + c4);
+    const f32x4 f = ldx4(feat + (size_t)(i / cq) * C + c4);
     f32x4 o;
     if (S == 8) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(tok + ((size_t)b * T + m * 64 + y * 8 + x) * C + c4);
+      const f32x4 t = ldx4(tok + ((size_t)b * T + m * 64 + y * 8 + x) * C + c4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = f[e] + t[e];
     } else {
@@ -202,24 +209,24 @@ __global__ __launch_bounds__(NT) void upsample_add_fwd_kernel(const float* __res
       const int h1p = (h1 < 7) ? 1 : 0, w1p = (w1 < 7) ? 1 : 0;
       const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
       const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
-      const float* base = tok + ((size_t)b * T + m * 64 + h1 * 8 + w1) * C + c4;
-      const f32x4 v00 = *reinterpret_cast<const f32x4*>(base);
-      const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + (size_t)w1p * C);
-      const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + (size_t)h1p * 8 * C);
-      const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + (size_t)(h1p * 8 + w1p) * C);
+      const TT* base = tok + ((size_t)b * T + m * 64 + h1 * 8 + w1) * C + c4;
+      const f32x4 v00 = ldx4(base);
+      const f32x4 v01 = ldx4(base + (size_t)w1p * C);
+      const f32x4 v10 = ldx4(base + (size_t)h1p * 8 * C);
+      const f32x4 v11 = ldx4(base + (size_t)(h1p * 8 + w1p) * C);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
         o[e] = f[e] + (h0l * (w0l * v00[e] + w1l * v01[e]) + h1l * (w0l * v10[e] + w1l * v11[e]));
     }
-    *reinterpret_cast<f32x4*>(out + (size_t)(i / cq) * C + c4) = o;
+    stx4(out + (size_t)(i / cq) * C + c4, o);
   }
 }
 
 // adjoint: gtok[b, m*64 + a, c] = sum_{pixels} weight(a, pixel) * G[b, pixel, c]
 // YS threads per (b, anchor, c4) share the rows of the anchor's bilinear footprint (consecutive lanes, combined with
 // xor shuffles in a fixed order); with one thread per output the 64x64 maps ran 128 blocks of ~300 serial loads each.
-template <int YS>
-__global__ __launch_bounds__(NT) void upsample_adj_kernel(const float* __restrict__ G, float* __restrict__ gtok, int B, int S,
+template <int YS, typename TT>
+__global__ __launch_bounds__(NT) void upsample_adj_kernel(const TT* __restrict__ G, TT* __restrict__ gtok, int B, int S,
                                                           int C, int T, int m) {
   const int cq = C >> 2;
   const int64_t total = (int64_t)B * 64 * cq * YS;
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(NT) void upsample_adj_kernel(const float* __restric
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   if (live) {
     if (S == 8) {
-      if (ys == 0) acc = *reinterpret_cast<const f32x4*>(G + ((size_t)(b * 8 + ay) * 8 + ax) * C + c4);
+      if (ys == 0) acc = ldx4(G + ((size_t)(b * 8 + ay) * 8 + ax) * C + c4);
     } else {
       // pixels y with floor(r*y) in {ay-1, ay}
       const int step = (S - 1) / 7 + 2;
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(NT) void upsample_adj_kernel(const float* __restric
           if (w1 == ax) wx += 1.f - w1l;
           if (w1 + w1p == ax) wx += w1l;
           if (wx == 0.f) continue;
-          const f32x4 g = *reinterpret_cast<const f32x4*>(G + ((size_t)(b * S + y) * S + x) * C + c4);
+          const f32x4 g = ldx4(G + ((size_t)(b * S + y) * S + x) * C + c4);
           const float wgt = wy * wx;
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[e] += wgt * g[e];
@@ -271,12 +278,13 @@ __global__ __launch_bounds__(NT) void upsample_adj_kernel(const float* __restric
   for (int d = 1; d < YS; d <<= 1)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], d, 64);
-  if (live && ys == 0) *reinterpret_cast<f32x4*>(gtok + ((size_t)b * T + m * 64 + a) * C + c4) = acc;
+  if (live && ys == 0) stx4(gtok + ((size_t)b * T + m * 64 + a) * C + c4, acc);
 }
 
 // dF[b,y,x,c] = G[b,y,x,c] + gtok[b, m*64 + (y/k)*8 + x/k, c] / k^2      (avgpool adjoint + identity)
-__global__ __launch_bounds__(NT) void pool_bcast_add_kernel(const float* __restrict__ G, const float* __restrict__ gtok,
-                                                            float* __restrict__ dF, int B, int S, int C, int T, int m) {
+template <typename TT>
+__global__ __launch_bounds__(NT) void pool_bcast_add_kernel(const TT* __restrict__ G, const TT* __restrict__ gtok,
+                                                            TT* __restrict__ dF, int B, int S, int C, int T, int m) {
   const int cq = C >> 2;
   const int k = S >> 3;
   const float inv = 1.0f / (float)(k * k);
@@ -287,17 +295,18 @@ __global__ __launch_bounds__(NT) void pool_bcast_add_kernel(const float* __restr
     const int x = (int)(p % S); p /= S;
     const int y = (int)(p % S);
     const int b = (int)(p / S);
-    const f32x4 g = *reinterpret_cast<const f32x4*>(G + (size_t)(i / cq) * C + c4);
-    const f32x4 t = *reinterpret_cast<const f32x4*>(gtok + ((size_t)b * T + m * 64 + (y / k) * 8 + x / k) * C + c4);
+    const f32x4 g = ldx4(G + (size_t)(i / cq) * C + c4);
+    const f32x4 t = ldx4(gtok + ((size_t)b * T + m * 64 + (y / k) * 8 + x / k) * C + c4);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = g[e] + t[e] * inv;
-    *reinterpret_cast<f32x4*>(dF + (size_t)(i / cq) * C + c4) = o;
+    stx4(dF + (size_t)(i / cq) * C + c4, o);
   }
 }
 
 // ---------------------------------------------------------------- global avgpool + branch sum
-__global__ __launch_bounds__(NT) void gap_sum_fwd_kernel(FeatPtrs feats, int n, int B, int P, int C, float* __restrict__ out) {
+template <typename T>
+__global__ __launch_bounds__(NT) void gap_sum_fwd_kernel(FeatPtrsT<T> feats, int n, int B, int P, int C, float* __restrict__ out) {
   const int64_t total = (int64_t)B * C;
   const float inv = 1.0f / (float)P;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -305,75 +314,174 @@ __global__ __launch_bounds__(NT) void gap_sum_fwd_kernel(FeatPtrs feats, int n, 
     float tot = 0.f;
     for (int m = 0; m < n; ++m) {
       float s = 0.f;
-      const float* f = feats.p[m] + (size_t)b * P * C + c;
-      for (int p = 0; p < P; ++p) s += f[(size_t)p * C];
+      const T* f = feats.p[m] + (size_t)b * P * C + c;
+      for (int p = 0; p < P; ++p) s += ldx1(f + (size_t)p * C);
       tot += s * inv;
     }
     out[i] = tot;
   }
 }
 
-__global__ __launch_bounds__(NT) void gap_sum_bwd_kernel(const float* __restrict__ g, GradPtrs outs, int n, int B, int P, int C) {
+template <typename T>
+__global__ __launch_bounds__(NT) void gap_sum_bwd_kernel(const float* __restrict__ g, GradPtrsT<T> outs, int n, int B, int P, int C) {
   const int64_t total = (int64_t)B * P * C;
   const float inv = 1.0f / (float)P;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C), b = (int)(i / ((int64_t)P * C));
     const float v = g[(size_t)b * C + c] * inv;
-    for (int m = 0; m < n; ++m) outs.p[m][i] = v;
+    for (int m = 0; m < n; ++m) stx1(outs.p[m] + i, v);
   }
 }
 
 // ---------------------------------------------------------------- layout transposes (LDS tiled)
 // in [B, R, Cc] -> out [B, Cc, R]   (NCHW->NHWC with R = C, Cc = H*W; NHWC->NCHW with R = H*W, Cc = C)
-__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+template <typename TI, typename TO>
+__global__ void transpose_kernel(const TI* __restrict__ in, TO* __restrict__ out, int R, int Cc) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z;
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  const float* src = in + (size_t)b * R * Cc;
-  float* dst = out + (size_t)b * R * Cc;
+  const TI* src = in + (size_t)b * R * Cc;
+  TO* dst = out + (size_t)b * R * Cc;
   for (int j = threadIdx.y; j < 32; j += 8) {
     const int r = r0 + j, c = c0 + threadIdx.x;
-    if (r < R && c < Cc) tile[j][threadIdx.x] = src[(size_t)r * Cc + c];
+    if (r < R && c < Cc) tile[j][threadIdx.x] = ldx1(src + (size_t)r * Cc + c);
   }
   __syncthreads();
   for (int j = threadIdx.y; j < 32; j += 8) {
     const int c = c0 + j, r = r0 + threadIdx.x;
-    if (r < R && c < Cc) dst[(size_t)c * R + r] = tile[threadIdx.x][j];
+    if (r < R && c < Cc) stx1(dst + (size_t)c * R + r, tile[threadIdx.x][j]);
   }
 }
 
 int grid_for(int64_t total) { return (int)std::min<int64_t>(ceil_div64(total, NT), 16384); }
 }  // namespace
 
-extern "C" int mmfn_maxpool3x3s2_fwd_f32(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, void* stream) {
+namespace {
+template <typename T>
+int maxpool_fwd_launch(const T* x, T* y, uint8_t* idx, int B, int H, int W, int C, void* stream) {
   if (C % 4) return MMFN_EINVAL;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((int64_t)B * OH * OW * (C / 4))), dim3(NT), 0, (hipStream_t)stream, x, y,
+  hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(grid_for((int64_t)B * OH * OW * (C / 4))), dim3(NT), 0, (hipStream_t)stream, x, y,
                      idx, B, H, W, C, OH, OW);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
-
-extern "C" int mmfn_maxpool3x3s2_bwd_f32(const float* gy, const uint8_t* idx, float* gx, int B, int H, int W, int C,
-                                         void* stream) {
+template <typename T>
+int maxpool_bwd_launch(const T* gy, const uint8_t* idx, T* gx, int B, int H, int W, int C, void* stream) {
   if (C % 4) return MMFN_EINVAL;
   const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(NT), 0, (hipStream_t)stream, gy, idx,
+  hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for((int64_t)B * H * W * (C / 4))), dim3(NT), 0, (hipStream_t)stream, gy, idx,
                      gx, B, H, W, C, OH, OW);
   MMFN_LAUNCH_CHECK();
   return 0;
+}
+template <typename T>
+int tokens_fwd_launch(const T* const* feats, int n_modal, int B, int S, int C, const float* pos, const float* vel_w,
+                      const float* vel_b, const float* velocity, T* tok, float drop_p, const uint64_t* rng_state,
+                      uint32_t rng_stream, void* stream) {
+  if (C % 4 || S % 8 || n_modal < 1 || n_modal > 4) return MMFN_EINVAL;
+  FeatPtrsT<T> fp;
+  for (int i = 0; i < 4; ++i) fp.p[i] = i < n_modal ? feats[i] : nullptr;
+  hipLaunchKernelGGL(tokens_fwd_kernel<T>, dim3(grid_for((int64_t)B * n_modal * 64 * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
+                     fp, n_modal, B, S, C, pos, vel_w, vel_b, velocity, tok, drop_p, rng_state, rng_stream);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T>
+int tokens_bwd_launch(T* gtok, int B, int Tn, int C, const float* velocity, float* dpos, float* dvel_w, float* dvel_b, float drop_p,
+                      const uint64_t* rng_state, uint32_t rng_stream, void* workspace, void* stream) {
+  if (!workspace) return MMFN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(tokens_bwd_kernel<T>, dim3(Tn), dim3(NT), 0, s, gtok, B, Tn, C, velocity, dpos, (float*)workspace, drop_p,
+                     rng_state, rng_stream);
+  MMFN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(tokens_bwd_finalize_kernel, dim3(ceil_div(C, TF_COLS)), dim3(TF_COLS * TF_LANES), 0, s, (const float*)workspace, Tn, C, dvel_w,
+                     dvel_b);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T>
+int upsample_add_fwd_launch(const T* feat, const T* tok, T* out, int B, int S, int C, int Tn, int m, void* stream) {
+  if (C % 4) return MMFN_EINVAL;
+  hipLaunchKernelGGL(upsample_add_fwd_kernel<T>, dim3(grid_for((int64_t)B * S * S * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
+                     feat, tok, out, B, S, C, Tn, m);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T>
+int upsample_adj_launch(const T* G, T* gtok, int B, int S, int C, int Tn, int m, void* stream) {
+  if (C % 4) return MMFN_EINVAL;
+  const int64_t outs = (int64_t)B * 64 * (C / 4);
+  if (S >= 32)
+    hipLaunchKernelGGL((upsample_adj_kernel<8, T>), dim3((unsigned)((outs * 8 + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, G, gtok,
+                       B, S, C, Tn, m);
+  else
+    hipLaunchKernelGGL((upsample_adj_kernel<1, T>), dim3((unsigned)((outs + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, G, gtok, B,
+                       S, C, Tn, m);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T>
+int pool_bcast_add_launch(const T* G, const T* gtok, T* dF, int B, int S, int C, int Tn, int m, void* stream) {
+  if (C % 4 || S % 8) return MMFN_EINVAL;
+  hipLaunchKernelGGL(pool_bcast_add_kernel<T>, dim3(grid_for((int64_t)B * S * S * (C / 4))), dim3(NT), 0, (hipStream_t)stream, G,
+                     gtok, dF, B, S, C, Tn, m);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T>
+int gap_sum_fwd_launch(const T* const* feats, int n, int B, int P, int C, float* out, void* stream) {
+  if (n < 1 || n > 4) return MMFN_EINVAL;
+  FeatPtrsT<T> fp;
+  for (int i = 0; i < 4; ++i) fp.p[i] = i < n ? feats[i] : nullptr;
+  hipLaunchKernelGGL(gap_sum_fwd_kernel<T>, dim3(grid_for((int64_t)B * C)), dim3(NT), 0, (hipStream_t)stream, fp, n, B, P, C, out);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T>
+int gap_sum_bwd_launch(const float* g, T* const* outs, int n, int B, int P, int C, void* stream) {
+  if (n < 1 || n > 4) return MMFN_EINVAL;
+  GradPtrsT<T> gp;
+  for (int i = 0; i < 4; ++i) gp.p[i] = i < n ? outs[i] : nullptr;
+  hipLaunchKernelGGL(gap_sum_bwd_kernel<T>, dim3(grid_for((int64_t)B * P * C)), dim3(NT), 0, (hipStream_t)stream, g, gp, n, B, P, C);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+template <typename TI, typename TO>
+int transpose_launch(const TI* in, TO* out, int B, int R, int Cc, void* stream) {
+  dim3 grid(ceil_div(Cc, 32), ceil_div(R, 32), B);
+  hipLaunchKernelGGL((transpose_kernel<TI, TO>), grid, dim3(32, 8), 0, (hipStream_t)stream, in, out, R, Cc);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+typedef const bf16_t* cbf;
+typedef bf16_t* mbf;
+}  // namespace
+
+extern "C" int mmfn_maxpool3x3s2_fwd_f32(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, void* stream) {
+  return maxpool_fwd_launch(x, y, idx, B, H, W, C, stream);
+}
+extern "C" int mmfn_maxpool3x3s2_fwd_bf16(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream) {
+  return maxpool_fwd_launch((cbf)x, (mbf)y, idx, B, H, W, C, stream);
+}
+extern "C" int mmfn_maxpool3x3s2_bwd_f32(const float* gy, const uint8_t* idx, float* gx, int B, int H, int W, int C,
+                                         void* stream) {
+  return maxpool_bwd_launch(gy, idx, gx, B, H, W, C, stream);
+}
+extern "C" int mmfn_maxpool3x3s2_bwd_bf16(const void* gy, const uint8_t* idx, void* gx, int B, int H, int W, int C, void* stream) {
+  return maxpool_bwd_launch((cbf)gy, idx, (mbf)gx, B, H, W, C, stream);
 }
 
 extern "C" int mmfn_tokens_fwd_f32(const float* const* feats, int n_modal, int B, int S, int C, const float* pos,
                                    const float* vel_w, const float* vel_b, const float* velocity, float* tok, float drop_p,
                                    const uint64_t* rng_state, uint32_t rng_stream, void* stream) {
-  if (C % 4 || S % 8 || n_modal < 1 || n_modal > 4) return MMFN_EINVAL;
-  FeatPtrs fp;
-  for (int i = 0; i < 4; ++i) fp.p[i] = i < n_modal ? feats[i] : nullptr;
-  hipLaunchKernelGGL(tokens_fwd_kernel, dim3(grid_for((int64_t)B * n_modal * 64 * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
-                     fp, n_modal, B, S, C, pos, vel_w, vel_b, velocity, tok, drop_p, rng_state, rng_stream);
-  MMFN_LAUNCH_CHECK();
-  return 0;
+  return tokens_fwd_launch(feats, n_modal, B, S, C, pos, vel_w, vel_b, velocity, tok, drop_p, rng_state, rng_stream, stream);
+}
+extern "C" int mmfn_tokens_fwd_bf16(const void* const* feats, int n_modal, int B, int S, int C, const float* pos,
+                                    const float* vel_w, const float* vel_b, const float* velocity, void* tok, float drop_p,
+                                    const uint64_t* rng_state, uint32_t rng_stream, void* stream) {
+  return tokens_fwd_launch((const bf16_t* const*)feats, n_modal, B, S, C, pos, vel_w, vel_b, velocity, (mbf)tok, drop_p, rng_state,
+                           rng_stream, stream);
 }
 
 extern "C" int64_t mmfn_tokens_bwd_workspace_bytes(int T, int C) { return (int64_t)T * 2 * C * (int64_t)sizeof(float); }
@@ -381,69 +489,60 @@ extern "C" int64_t mmfn_tokens_bwd_workspace_bytes(int T, int C) { return (int64
 extern "C" int mmfn_tokens_bwd_f32(float* gtok, int B, int T, int C, const float* velocity, float* dpos, float* dvel_w,
                                    float* dvel_b, float drop_p, const uint64_t* rng_state, uint32_t rng_stream,
                                    void* workspace, void* stream) {
-  if (!workspace) return MMFN_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(tokens_bwd_kernel, dim3(T), dim3(NT), 0, s, gtok, B, T, C, velocity, dpos, (float*)workspace, drop_p,
-                     rng_state, rng_stream);
-  MMFN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(tokens_bwd_finalize_kernel, dim3(ceil_div(C, TF_COLS)), dim3(TF_COLS * TF_LANES), 0, s, (const float*)workspace, T, C, dvel_w,
-                     dvel_b);
-  MMFN_LAUNCH_CHECK();
-  return 0;
+  return tokens_bwd_launch(gtok, B, T, C, velocity, dpos, dvel_w, dvel_b, drop_p, rng_state, rng_stream, workspace, stream);
+}
+extern "C" int mmfn_tokens_bwd_bf16(void* gtok, int B, int T, int C, const float* velocity, float* dpos, float* dvel_w,
+                                    float* dvel_b, float drop_p, const uint64_t* rng_state, uint32_t rng_stream,
+                                    void* workspace, void* stream) {
+  return tokens_bwd_launch((mbf)gtok, B, T, C, velocity, dpos, dvel_w, dvel_b, drop_p, rng_state, rng_stream, workspace, stream);
 }
 
 extern "C" int mmfn_upsample_add_fwd_f32(const float* feat, const float* tok, float* out, int B, int S, int C, int T, int m,
                                          void* stream) {
-  if (C % 4) return MMFN_EINVAL;
-  hipLaunchKernelGGL(upsample_add_fwd_kernel, dim3(grid_for((int64_t)B * S * S * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
-                     feat, tok, out, B, S, C, T, m);
-  MMFN_LAUNCH_CHECK();
-  return 0;
+  return upsample_add_fwd_launch(feat, tok, out, B, S, C, T, m, stream);
+}
+extern "C" int mmfn_upsample_add_fwd_bf16(const void* feat, const void* tok, void* out, int B, int S, int C, int T, int m,
+                                          void* stream) {
+  return upsample_add_fwd_launch((cbf)feat, (cbf)tok, (mbf)out, B, S, C, T, m, stream);
 }
 
 extern "C" int mmfn_upsample_adj_f32(const float* G, float* gtok, int B, int S, int C, int T, int m, void* stream) {
-  if (C % 4) return MMFN_EINVAL;
-  const int64_t outs = (int64_t)B * 64 * (C / 4);
-  if (S >= 32)
-    hipLaunchKernelGGL(upsample_adj_kernel<8>, dim3((unsigned)((outs * 8 + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, G, gtok,
-                       B, S, C, T, m);
-  else
-    hipLaunchKernelGGL(upsample_adj_kernel<1>, dim3((unsigned)((outs + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, G, gtok, B,
-                       S, C, T, m);
-  MMFN_LAUNCH_CHECK();
-  return 0;
+  return upsample_adj_launch(G, gtok, B, S, C, T, m, stream);
+}
+extern "C" int mmfn_upsample_adj_bf16(const void* G, void* gtok, int B, int S, int C, int T, int m, void* stream) {
+  return upsample_adj_launch((cbf)G, (mbf)gtok, B, S, C, T, m, stream);
 }
 
 extern "C" int mmfn_pool_bcast_add_f32(const float* G, const float* gtok, float* dF, int B, int S, int C, int T, int m,
                                        void* stream) {
-  if (C % 4 || S % 8) return MMFN_EINVAL;
-  hipLaunchKernelGGL(pool_bcast_add_kernel, dim3(grid_for((int64_t)B * S * S * (C / 4))), dim3(NT), 0, (hipStream_t)stream, G,
-                     gtok, dF, B, S, C, T, m);
-  MMFN_LAUNCH_CHECK();
-  return 0;
+  return pool_bcast_add_launch(G, gtok, dF, B, S, C, T, m, stream);
+}
+extern "C" int mmfn_pool_bcast_add_bf16(const void* G, const void* gtok, void* dF, int B, int S, int C, int T, int m,
+                                        void* stream) {
+  return pool_bcast_add_launch((cbf)G, (cbf)gtok, (mbf)dF, B, S, C, T, m, stream);
 }
 
 extern "C" int mmfn_gap_sum_fwd_f32(const float* const* feats, int n, int B, int P, int C, float* out, void* stream) {
-  if (n < 1 || n > 4) return MMFN_EINVAL;
-  FeatPtrs fp;
-  for (int i = 0; i < 4; ++i) fp.p[i] = i < n ? feats[i] : nullptr;
-  hipLaunchKernelGGL(gap_sum_fwd_kernel, dim3(grid_for((int64_t)B * C)), dim3(NT), 0, (hipStream_t)stream, fp, n, B, P, C, out);
-  MMFN_LAUNCH_CHECK();
-  return 0;
+  return gap_sum_fwd_launch(feats, n, B, P, C, out, stream);
+}
+extern "C" int mmfn_gap_sum_fwd_bf16(const void* const* feats, int n, int B, int P, int C, float* out, void* stream) {
+  return gap_sum_fwd_launch((const bf16_t* const*)feats, n, B, P, C, out, stream);
 }
 
 extern "C" int mmfn_gap_sum_bwd_f32(const float* g, float* const* outs, int n, int B, int P, int C, void* stream) {
-  if (n < 1 || n > 4) return MMFN_EINVAL;
-  GradPtrs gp;
-  for (int i = 0; i < 4; ++i) gp.p[i] = i < n ? outs[i] : nullptr;
-  hipLaunchKernelGGL(gap_sum_bwd_kernel, dim3(grid_for((int64_t)B * P * C)), dim3(NT), 0, (hipStream_t)stream, g, gp, n, B, P, C);
-  MMFN_LAUNCH_CHECK();
-  return 0;
+  return gap_sum_bwd_launch(g, outs, n, B, P, C, stream);
+}
+extern "C" int mmfn_gap_sum_bwd_bf16(const float* g, void* const* outs, int n, int B, int P, int C, void* stream) {
+  return gap_sum_bwd_launch(g, (bf16_t* const*)outs, n, B, P, C, stream);
 }
 
 extern "C" int mmfn_transpose_f32(const float* in, float* out, int B, int R, int Cc, void* stream) {
-  dim3 grid(ceil_div(Cc, 32), ceil_div(R, 32), B);
-  hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, in, out, R, Cc);
-  MMFN_LAUNCH_CHECK();
-  return 0;
+  return transpose_launch(in, out, B, R, Cc, stream);
+}
+/* fp32 in -> bf16 out (VectorNet's fp32 output becoming the bf16 map feature) and bf16 in -> fp32 out (its gradient) */
+extern "C" int mmfn_transpose_f32_to_bf16(const float* in, void* out, int B, int R, int Cc, void* stream) {
+  return transpose_launch(in, (mbf)out, B, R, Cc, stream);
+}
+extern "C" int mmfn_transpose_bf16_to_f32(const void* in, float* out, int B, int R, int Cc, void* stream) {
+  return transpose_launch((cbf)in, out, B, R, Cc, stream);
 }
