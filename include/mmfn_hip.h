@@ -352,6 +352,57 @@ int mmfn_gat_softmax_bwd_f32(const float* g_att, const float* p, const float* e_
 int mmfn_log_softmax_fwd_f32(const float* x, float* y, int R, int C, int swap, void* stream);
 int mmfn_log_softmax_bwd_f32(const float* g, const float* y, float* dx, int R, int C, int swap, void* stream);
 
+/* ---- bf16 training mode (BASELINE configs[2]): the same kernels with bf16 activations in HBM ---------------------------
+ * `void*` tensors are bf16 (raw 16-bit words, channels-last / [rows, C] like their fp32 twins); statistics, parameters, their
+ * gradients, lse / delta and every `float*` stay fp32.  Each entry replaces the aten dispatch its _f32 twin cites, as
+ * torch.autocast(bfloat16) would run it - except that the activations never exist in fp32.  Arithmetic is fp32 in registers. */
+/* weight shadows, once per step: the flat fp32 parameter buffer rounded to bf16 at the same offsets ... */
+int mmfn_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+/* ... and transposed copies for the data gradients.  table: DEVICE array of n_entries records
+ * { const float* src; bf16* dst; int32 R, T, C; int32 tiles_c; int64 tile0 } (40 bytes): dst[c][t][r] = src[r][t][c]
+ * (Linear [out,in] -> [in,out] with T = 1; filters [Cout][taps][Cin] -> [Cin][taps][Cout]); tile0 = running sum of
+ * T * ceil(R/32) * ceil(C/32), ascending; total_tiles = the grand total. */
+int mmfn_shadow_transpose_bf16(const void* table, int n_entries, int64_t total_tiles, void* stream);
+int mmfn_bn_train_stats_bf16(const void* x, int64_t M, int C, float eps, float momentum, float* mean, float* rstd,
+                             float* running_mean, float* running_var, int64_t* num_batches_tracked, void* workspace, void* stream);
+/* x_is_f32: the convolution output x (and, in the backward, its gradient dx) is fp32 - the 7x7 stems, whose 3- / 2-channel
+ * convolutions stay on the fp32 kernel */
+int mmfn_bn_apply_bf16(const void* x, int x_is_f32, const void* res, void* y, int64_t M, int C, const float* mean,
+                       const float* rstd, const float* weight, const float* bias, int relu, void* stream);
+int mmfn_bn_bwd_bf16(const void* g, const void* y, const void* x, int x_is_f32, int64_t M, int C, const float* mean,
+                     const float* rstd, const float* weight, void* dx, void* ge_out, float* dweight, float* dbias,
+                     void* workspace, void* stream);
+int mmfn_layernorm_fwd_bf16(const void* x, const float* weight, const float* bias, void* y, float* mean, float* rstd, int M,
+                            int C, float eps, int act, void* stream);
+int mmfn_layernorm_bwd_partial_bf16(const void* g, const void* x, const float* weight, const float* bias, const float* mean,
+                                    const float* rstd, const void* dres, void* dx, int M, int C, int act, void* dx_dropped,
+                                    float drop_p, const uint64_t* rng_state, uint32_t rng_stream, int want_colsum,
+                                    float* partials, void* stream);
+int mmfn_colsum_bf16(const void* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream);
+int mmfn_maxpool3x3s2_fwd_bf16(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
+int mmfn_maxpool3x3s2_bwd_bf16(const void* gy, const uint8_t* idx, void* gx, int B, int H, int W, int C, void* stream);
+int mmfn_tokens_fwd_bf16(const void* const* feats, int n_modal, int B, int S, int C, const float* pos, const float* vel_w,
+                         const float* vel_b, const float* velocity, void* tok, float drop_p, const uint64_t* rng_state,
+                         uint32_t rng_stream, void* stream);
+int mmfn_tokens_bwd_bf16(void* gtok, int B, int T, int C, const float* velocity, float* dpos, float* dvel_w, float* dvel_b,
+                         float drop_p, const uint64_t* rng_state, uint32_t rng_stream, void* workspace, void* stream);
+int mmfn_upsample_add_fwd_bf16(const void* feat, const void* tok, void* out, int B, int S, int C, int T, int m, void* stream);
+int mmfn_upsample_adj_bf16(const void* G, void* gtok, int B, int S, int C, int T, int m, void* stream);
+int mmfn_pool_bcast_add_bf16(const void* G, const void* gtok, void* dF, int B, int S, int C, int T, int m, void* stream);
+int mmfn_gap_sum_fwd_bf16(const void* const* feats, int n, int B, int P, int C, float* out, void* stream);
+int mmfn_gap_sum_bwd_bf16(const float* g, void* const* outs, int n, int B, int P, int C, void* stream);
+/* [B, R, Cc] -> [B, Cc, R] across the precision boundary: VectorNet (fp32 inside) -> the bf16 map feature, and its gradient back */
+int mmfn_transpose_f32_to_bf16(const float* in, void* out, int B, int R, int Cc, void* stream);
+int mmfn_transpose_bf16_to_f32(const void* in, float* out, int B, int R, int Cc, void* stream);
+/* T = 64 / 128 / 192 tokens (the fusion transformers); operands widened to fp32 on their way into LDS */
+int mmfn_attention_fwd_bf16(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse, int B, int T,
+                            int NH, int HS, float scale, const int32_t* kv_len, float drop_p, const uint64_t* rng_state,
+                            uint32_t rng_stream, void* stream);
+int mmfn_attention_bwd_bf16(const void* q, const void* k, const void* v, int ld, const void* o, const void* dO, int ldo,
+                            const float* lse, float* delta, void* dq, void* dk, void* dv, int ldg, int B, int T, int NH, int HS,
+                            float scale, const int32_t* kv_len, float drop_p, const uint64_t* rng_state, uint32_t rng_stream,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,11 @@ class GlobalConfig(object):
     # not in the reference: arithmetic of the Linear / Winograd GEMMs.  "f32" is the parity path; "bf16" rounds their operands
     # to bf16 on the way into the MFMA units (fp32 accumulation, activations and master weights; BASELINE configs[2])
     gemm_dtype = "f32"
+    # not in the reference: the bf16 TRAINING MODE proper (BASELINE configs[2]).  "bf16": activations, saved tensors and the
+    # per-step weight shadows are bf16 in HBM (ResNet trunks, fusion transformers and the glue between them), accumulation /
+    # normalisation statistics / master weights / gradients / optimizer / loss head / VectorNet / the two 7x7 stems are fp32
+    # (mmfn_gemm_bf16 + the *_bf16 entry points).  Supersedes gemm_dtype.  vec and img variants.
+    act_dtype = "f32"
 
     def __init__(self, **kwargs):
         self.train_data, self.val_towns = [], []

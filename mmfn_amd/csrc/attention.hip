@@ -505,11 +505,12 @@ bool tile_kernels_only() {
 int dispatch(int which, int hs, const AttnArgs& a, hipStream_t s) {
   if (a.B <= 0 || a.T <= 0 || a.T > 256 || a.NH <= 0) return MMFN_EINVAL;
   if ((a.ld & 3) || (a.ldo & 3) || ((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.v & 15)) return MMFN_EINVAL;
-  if (!tile_kernels_only() && !(a.ldg & 3)) {
+  if ((!tile_kernels_only() || a.io_bf16) && !(a.ldg & 3)) {
     // T = 64 / 128 / 192 (the fusion transformers: 192 tokens): one workgroup per (sample, head, half), attention_wg.hip
     const int rc = mmfn_attn_wg_launch(which, hs, a, s);
     if (rc >= 0) return rc;
   }
+  if (a.io_bf16) return MMFN_EINVAL;   // bf16 activations: only the workgroup-per-half kernels read them
   switch (hs) {
     case 16: return dispatch_nkt<16>(which, a, s);
     case 32: return dispatch_nkt<32>(which, a, s);
@@ -541,6 +542,37 @@ extern "C" int mmfn_attention_bwd_f32(const float* q, const float* k, const floa
   a.dq = dq; a.dk = dk; a.dv = dv; a.kv_len = kv_len; a.rng_state = rng_state;
   a.B = B; a.T = T; a.NH = NH; a.ld = ld; a.ldo = ldo; a.ldg = ldg;
   a.scale = scale; a.drop_p = drop_p; a.rng_stream = rng_stream;
+  if (drop_p > 0.f && !rng_state) return MMFN_EINVAL;
+  if ((ldg & 3) || !lse || !delta) return MMFN_EINVAL;
+  int rc = dispatch(1, HS, a, (hipStream_t)stream);
+  if (rc) return rc;
+  return dispatch(2, HS, a, (hipStream_t)stream);
+}
+
+/* bf16 mode: q k v o dO dq dk dv are bf16 (strides in elements), lse / delta fp32; T = 64 / 128 / 192 (the workgroup-per-half
+ * kernels: operands are widened to fp32 on their way into LDS, arithmetic as in the fp32 path) */
+extern "C" int mmfn_attention_fwd_bf16(const void* q, const void* k, const void* v, int ld, void* o, int ldo, float* lse,
+                                       int B, int T, int NH, int HS, float scale, const int32_t* kv_len, float drop_p,
+                                       const uint64_t* rng_state, uint32_t rng_stream, void* stream) {
+  AttnArgs a = {};
+  a.q = (const float*)q; a.k = (const float*)k; a.v = (const float*)v; a.o = (float*)o; a.lse = lse; a.kv_len = kv_len;
+  a.rng_state = rng_state;
+  a.B = B; a.T = T; a.NH = NH; a.ld = ld; a.ldo = ldo; a.ldg = ld;
+  a.scale = scale; a.drop_p = drop_p; a.rng_stream = rng_stream; a.io_bf16 = 1;
+  if (drop_p > 0.f && !rng_state) return MMFN_EINVAL;
+  return dispatch(0, HS, a, (hipStream_t)stream);
+}
+
+extern "C" int mmfn_attention_bwd_bf16(const void* q, const void* k, const void* v, int ld, const void* o, const void* dO,
+                                       int ldo, const float* lse, float* delta, void* dq, void* dk, void* dv, int ldg, int B,
+                                       int T, int NH, int HS, float scale, const int32_t* kv_len, float drop_p,
+                                       const uint64_t* rng_state, uint32_t rng_stream, void* stream) {
+  AttnArgs a = {};
+  a.q = (const float*)q; a.k = (const float*)k; a.v = (const float*)v; a.o = (float*)const_cast<void*>(o);
+  a.lse = const_cast<float*>(lse); a.dO = (const float*)dO; a.delta = delta;
+  a.dq = (float*)dq; a.dk = (float*)dk; a.dv = (float*)dv; a.kv_len = kv_len; a.rng_state = rng_state;
+  a.B = B; a.T = T; a.NH = NH; a.ld = ld; a.ldo = ldo; a.ldg = ldg;
+  a.scale = scale; a.drop_p = drop_p; a.rng_stream = rng_stream; a.io_bf16 = 1;
   if (drop_p > 0.f && !rng_state) return MMFN_EINVAL;
   if ((ldg & 3) || !lse || !delta) return MMFN_EINVAL;
   int rc = dispatch(1, HS, a, (hipStream_t)stream);

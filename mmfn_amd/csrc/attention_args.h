@@ -16,6 +16,7 @@ struct AttnArgs {
   float scale, drop_p;
   uint32_t rng_stream;
   long long* dbg;                                   // MMFN_ATTN_DEBUG=1 (dev only): phase time stamps of workgroup 0
+  int io_bf16;                                      // bf16 mode: q k v o dO dq dk dv point at bf16 (row strides in elements); lse / delta stay fp32
 };
 
 // attention_wg.hip.  which: 0 forward, 1 backward dQ (+delta), 2 backward dK/dV.  Returns -1 when the shape is not

@@ -62,11 +62,12 @@ struct Stager {
   static constexpr int UNITS = NROWS * Q;
   static constexpr int PER = (UNITS + NTHR - 1) / NTHR;
   f32x4 r[PER];
-  __device__ __forceinline__ void issue(const float* src, size_t ld, int tid, int col0 = 0) {
+  template <typename TIO>
+  __device__ __forceinline__ void issue(const TIO* src, size_t ld, int tid, int col0 = 0) {   // TIO = float or bf16_t (bf16 mode)
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       const int u = tid + i * NTHR;
-      if (UNITS % NTHR == 0 || u < UNITS) r[i] = ld4(src + (size_t)(u / Q) * ld + col0 + 4 * (u % Q));
+      if (UNITS % NTHR == 0 || u < UNITS) r[i] = ldx4(src + (size_t)(u / Q) * ld + col0 + 4 * (u % Q));
     }
   }
   __device__ __forceinline__ void commit(float* dst, int tid, int col0 = 0) const {
@@ -117,12 +118,12 @@ __device__ __forceinline__ void product_phase(const float* A, const float* B, in
 //   tail() is called right before the last group's MFMAs (the caller issues the next phase's loads there).
 // Every group is one barrier.  With NS >= 2 the group being written (columns of group g+1) was last read NS groups ago, one
 // or more barriers back; with NS == 1 the only group is overwritten, so a barrier separates its last reader from the write.
-template <int HS, int NT, int NPROD, typename Src, typename Prod, typename Tail>
+template <int HS, int NT, int NPROD, typename TIO, typename Src, typename Prod, typename Tail>
 __device__ __forceinline__ void product_chain(float* sFull, float* sHalf, int tid, Src&& src, Prod&& prod, Tail&& tail) {
   constexpr int T = 64 * NT, NS = Groups<HS>::NS, COLS = Groups<HS>::COLS, N = NPROD * NS;
   Stager<HS, T, COLS, NTHR> stF;
   Stager<HS, T / 2, COLS, NTHR> stH;
-  const float* pf; const float* ph; size_t lf, lh;
+  const TIO* pf; const TIO* ph; size_t lf, lh;
   src(0, pf, lf, ph, lh);
   stF.issue(pf, lf, tid, 0);
   stH.issue(ph, lh, tid, 0);
@@ -179,9 +180,9 @@ __device__ __forceinline__ void second_phase(const f32x4 (*Pm)[NT], const float*
 // Partial output tiles of the four slices of a group -> their sum, written to dst (row stride ldd, rows of this group).
 // Slice s owns tiles [s*W, s*W+W) (the first NOWN slices when the head has fewer than four tiles); everybody parks the
 // tiles it does not own in LDS, one barrier, owners add the three foreign copies in slice order (deterministic).
-template <int HS, int NT>
+template <int HS, int NT, typename TIO>
 __device__ __forceinline__ void merge_store(const f32x4 (*acc)[HS / 16], float* sm, int grp, int slice, int lane, int l15,
-                                            int l4, float* dst, size_t ldd) {
+                                            int l4, TIO* dst, size_t ldd) {
   using S = Shape<HS, NT>;
   constexpr int NDT = S::NDT, W = S::W, NOWN = S::NOWN, SLOTS = S::SLOTS;
   // one 16-byte unit per (tile, row tile, lane): the four accumulator rows of a lane sit together, lane-linear across the wave
@@ -229,9 +230,9 @@ __device__ __forceinline__ void merge_store(const f32x4 (*acc)[HS / 16], float* 
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float* p = dst + (size_t)(16 * y + 4 * l4 + r) * ldd + slice * 16 * W + l15 * W;
-        if (W == 2) *reinterpret_cast<f32x2*>(p) = f32x2{t[0][r], t[1][r]};
-        else p[0] = t[0][r];
+        TIO* p = dst + (size_t)(16 * y + 4 * l4 + r) * ldd + slice * 16 * W + l15 * W;
+        if (W == 2) VecIO<2, TIO>::st(p, f32x2{t[0][r], t[1][r]});
+        else stx1(p, t[0][r]);
       }
     }
   }
@@ -278,8 +279,14 @@ __device__ __forceinline__ void stamp(const AttnArgs& a, int idx) {
 }
 
 // ---------------------------------------------------------------------------------------------------------- forward
-template <int HS, int NT>
+template <int HS, int NT, typename TIO>
 __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
+  // activations in the bf16 mode are bf16 in HBM: they are widened to fp32 on their way into LDS, the arithmetic is unchanged
+  const TIO* io_q = reinterpret_cast<const TIO*>(a.q); const TIO* io_k = reinterpret_cast<const TIO*>(a.k);
+  const TIO* io_v = reinterpret_cast<const TIO*>(a.v); const TIO* io_dO = reinterpret_cast<const TIO*>(a.dO);
+  TIO* io_o = reinterpret_cast<TIO*>(a.o); TIO* io_dq = reinterpret_cast<TIO*>(a.dq); TIO* io_dk = reinterpret_cast<TIO*>(a.dk);
+  TIO* io_dv = reinterpret_cast<TIO*>(a.dv);
+  (void)io_q; (void)io_k; (void)io_v; (void)io_dO; (void)io_o; (void)io_dq; (void)io_dk; (void)io_dv;
   using S = Shape<HS, NT>;
   using L = Lds<HS, NT>;
   constexpr int NDT = S::NDT, G = S::G, T = 64 * NT, P = L::P;
@@ -304,14 +311,14 @@ __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
 #pragma unroll
     for (int y = 0; y < NT; ++y) s[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
   Stager<HS, T, HS, NTHR> stV;   // V goes into flight under the last MFMAs of the first product, lands in LDS (over K / Q)
-  product_chain<HS, NT, 1>(
+  product_chain<HS, NT, 1, TIO>(
       sK, sQ, tid,
-      [&](int, const float*& pf, size_t& lf, const float*& ph, size_t& lh) {
-        pf = a.k + rowbase * ld + hd * HS; lf = ld;
-        ph = a.q + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
+      [&](int, const TIO*& pf, size_t& lf, const TIO*& ph, size_t& lh) {
+        pf = io_k + rowbase * ld + hd * HS; lf = ld;
+        ph = io_q + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
       },
       [&](int, int col0) { product_phase<HS, NT, Groups<HS>::COLS>(sK + k0 * P, sQ + qg * G * P, col0, l15, l4, s); },
-      [&]() { stV.issue(a.v + rowbase * ld + hd * HS, ld, tid); });
+      [&]() { stV.issue(io_v + rowbase * ld + hd * HS, ld, tid); });
   stamp(a, 2);
   // ---- softmax over keys, flash-style across the four key slices: every slice normalises by its OWN row maximum, the
   // (max, sum) pairs meet in LDS once, then each slice rescales by exp(m_slice - m) / l
@@ -385,13 +392,19 @@ __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
   second_phase<HS, NT>(s, sm + k0 * P, l15, l4, o);
   stamp(a, 4);
   __syncthreads();   // V no longer read: the area becomes the merge parking space
-  merge_store<HS, NT>(o, sm, qg, ks, lane, l15, l4, a.o + (rowbase + q0) * a.ldo + hd * HS, a.ldo);
+  merge_store<HS, NT, TIO>(o, sm, qg, ks, lane, l15, l4, io_o + (rowbase + q0) * a.ldo + hd * HS, a.ldo);
   stamp(a, 5);
 }
 
 // ---------------------------------------------------------------------------------------- backward, query-owned: dQ, delta
-template <int HS, int NT>
+template <int HS, int NT, typename TIO>
 __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
+  // activations in the bf16 mode are bf16 in HBM: they are widened to fp32 on their way into LDS, the arithmetic is unchanged
+  const TIO* io_q = reinterpret_cast<const TIO*>(a.q); const TIO* io_k = reinterpret_cast<const TIO*>(a.k);
+  const TIO* io_v = reinterpret_cast<const TIO*>(a.v); const TIO* io_dO = reinterpret_cast<const TIO*>(a.dO);
+  TIO* io_o = reinterpret_cast<TIO*>(a.o); TIO* io_dq = reinterpret_cast<TIO*>(a.dq); TIO* io_dk = reinterpret_cast<TIO*>(a.dk);
+  TIO* io_dv = reinterpret_cast<TIO*>(a.dv);
+  (void)io_q; (void)io_k; (void)io_v; (void)io_dO; (void)io_o; (void)io_dq; (void)io_dk; (void)io_dv;
   using S = Shape<HS, NT>;
   using L = Lds<HS, NT>;
   constexpr int NDT = S::NDT, G = S::G, T = 64 * NT, P = L::P;
@@ -421,19 +434,19 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
 #pragma unroll
       for (int y = 0; y < NT; ++y) acc[p][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
   Stager<HS, T, HS, NTHR> stK;   // K again, for dQ = dS K: in flight under the last MFMAs, committed once V is no longer read
-  product_chain<HS, NT, 2>(
+  product_chain<HS, NT, 2, TIO>(
       sA, sB, tid,
-      [&](int i, const float*& pf, size_t& lf, const float*& ph, size_t& lh) {
+      [&](int i, const TIO*& pf, size_t& lf, const TIO*& ph, size_t& lh) {
         if (i == 0) {
-          pf = a.k + rowbase * ld + hd * HS; lf = ld;
-          ph = a.q + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
+          pf = io_k + rowbase * ld + hd * HS; lf = ld;
+          ph = io_q + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
         } else {
-          pf = a.v + rowbase * ld + hd * HS; lf = ld;
-          ph = a.dO + (rowbase + half * 2 * G) * a.ldo + hd * HS; lh = a.ldo;
+          pf = io_v + rowbase * ld + hd * HS; lf = ld;
+          ph = io_dO + (rowbase + half * 2 * G) * a.ldo + hd * HS; lh = a.ldo;
         }
       },
       [&](int i, int col0) { product_phase<HS, NT, Groups<HS>::COLS>(sA + k0 * P, sB + qg * G * P, col0, l15, l4, acc[i]); },
-      [&]() { stK.issue(a.k + rowbase * ld + hd * HS, ld, tid); });
+      [&]() { stK.issue(io_k + rowbase * ld + hd * HS, ld, tid); });
   __syncthreads();
   stK.commit(sA, tid);
   const bool drop = a.drop_p > 0.f;
@@ -487,12 +500,18 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
     for (int j = 0; j < NDT; ++j) dq[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   second_phase<HS, NT>(acc[0], sA + k0 * P, l15, l4, dq);
   __syncthreads();
-  merge_store<HS, NT>(dq, sm, qg, ks, lane, l15, l4, a.dq + (rowbase + q0) * a.ldg + hd * HS, a.ldg);
+  merge_store<HS, NT, TIO>(dq, sm, qg, ks, lane, l15, l4, io_dq + (rowbase + q0) * a.ldg + hd * HS, a.ldg);
 }
 
 // ------------------------------------------------------------------------------------------ backward, key-owned: dK, dV
-template <int HS, int NT>
+template <int HS, int NT, typename TIO>
 __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
+  // activations in the bf16 mode are bf16 in HBM: they are widened to fp32 on their way into LDS, the arithmetic is unchanged
+  const TIO* io_q = reinterpret_cast<const TIO*>(a.q); const TIO* io_k = reinterpret_cast<const TIO*>(a.k);
+  const TIO* io_v = reinterpret_cast<const TIO*>(a.v); const TIO* io_dO = reinterpret_cast<const TIO*>(a.dO);
+  TIO* io_o = reinterpret_cast<TIO*>(a.o); TIO* io_dq = reinterpret_cast<TIO*>(a.dq); TIO* io_dk = reinterpret_cast<TIO*>(a.dk);
+  TIO* io_dv = reinterpret_cast<TIO*>(a.dv);
+  (void)io_q; (void)io_k; (void)io_v; (void)io_dO; (void)io_o; (void)io_dq; (void)io_dk; (void)io_dv;
   using S = Shape<HS, NT>;
   using L = Lds<HS, NT>;
   constexpr int NDT = S::NDT, G = S::G, T = 64 * NT, P = L::P;
@@ -525,15 +544,15 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
 #pragma unroll
       for (int y = 0; y < NT; ++y) acc[p][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
   Stager<HS, T, HS, NTHR> stA;   // Q again (for dK): issued before the dV product, committed after the dV merge
-  product_chain<HS, NT, 2>(
+  product_chain<HS, NT, 2, TIO>(
       sA, sB, tid,
-      [&](int i, const float*& pf, size_t& lf, const float*& ph, size_t& lh) {
+      [&](int i, const TIO*& pf, size_t& lf, const TIO*& ph, size_t& lh) {
         if (i == 0) {
-          pf = a.q + rowbase * ld + hd * HS; lf = ld;
-          ph = a.k + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
+          pf = io_q + rowbase * ld + hd * HS; lf = ld;
+          ph = io_k + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
         } else {
-          pf = a.dO + rowbase * a.ldo + hd * HS; lf = a.ldo;
-          ph = a.v + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
+          pf = io_dO + rowbase * a.ldo + hd * HS; lf = a.ldo;
+          ph = io_v + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
         }
       },
       [&](int i, int col0) { product_phase<HS, NT, Groups<HS>::COLS>(sA + q0 * P, sB + kg * G * P, col0, l15, l4, acc[i]); },
@@ -566,10 +585,10 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
   for (int y = 0; y < NT; ++y)
 #pragma unroll
     for (int j = 0; j < NDT; ++j) g[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  stA.issue(a.q + rowbase * ld + hd * HS, ld, tid);          // Q again (for dK), in flight under the dV product
+  stA.issue(io_q + rowbase * ld + hd * HS, ld, tid);          // Q again (for dK), in flight under the dV product
   second_phase<HS, NT>(acc[0], sA + q0 * P, l15, l4, g);     // dO is still staged
   __syncthreads();
-  merge_store<HS, NT>(g, sm, kg, qs, lane, l15, l4, a.dv + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
+  merge_store<HS, NT, TIO>(g, sm, kg, qs, lane, l15, l4, io_dv + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
   __syncthreads();   // every owner has read the dV copies before the area is reused
   stA.commit(sA, tid);
   __syncthreads();
@@ -579,7 +598,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
     for (int j = 0; j < NDT; ++j) g[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   second_phase<HS, NT>(acc[1], sA + q0 * P, l15, l4, g);
   __syncthreads();
-  merge_store<HS, NT>(g, sm, kg, qs, lane, l15, l4, a.dk + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
+  merge_store<HS, NT, TIO>(g, sm, kg, qs, lane, l15, l4, io_dk + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
 }
 
 long long* debug_buffer() {   // dev only (MMFN_ATTN_DEBUG=1): allocated once, outside any capture
@@ -592,16 +611,21 @@ long long* debug_buffer() {   // dev only (MMFN_ATTN_DEBUG=1): allocated once, o
   return buf;
 }
 
-template <int HS, int NT>
-int launch(int which, const AttnArgs& a_in, hipStream_t s) {
+template <int HS, int NT, typename TIO>
+int launch_io(int which, const AttnArgs& a_in, hipStream_t s) {
   AttnArgs a = a_in;
   a.dbg = which == 0 ? debug_buffer() : nullptr;
   dim3 grid(2 * 8 * ceil_div(a.NH * a.B, 8));
-  if (which == 0) hipLaunchKernelGGL((attn_wg_fwd_kernel<HS, NT>), grid, dim3(NTHR), 0, s, a);
-  else if (which == 1) hipLaunchKernelGGL((attn_wg_dq_kernel<HS, NT>), grid, dim3(NTHR), 0, s, a);
-  else hipLaunchKernelGGL((attn_wg_dkv_kernel<HS, NT>), grid, dim3(NTHR), 0, s, a);
+  if (which == 0) hipLaunchKernelGGL((attn_wg_fwd_kernel<HS, NT, TIO>), grid, dim3(NTHR), 0, s, a);
+  else if (which == 1) hipLaunchKernelGGL((attn_wg_dq_kernel<HS, NT, TIO>), grid, dim3(NTHR), 0, s, a);
+  else hipLaunchKernelGGL((attn_wg_dkv_kernel<HS, NT, TIO>), grid, dim3(NTHR), 0, s, a);
   MMFN_LAUNCH_CHECK();
   return 0;
+}
+
+template <int HS, int NT>
+int launch(int which, const AttnArgs& a, hipStream_t s) {
+  return a.io_bf16 ? launch_io<HS, NT, bf16_t>(which, a, s) : launch_io<HS, NT, float>(which, a, s);
 }
 
 template <int HS>

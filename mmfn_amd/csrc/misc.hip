@@ -107,3 +107,72 @@ extern "C" int mmfn_relu_mask_f32(const float* g, const float* y, float* out, in
   MMFN_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------- bf16 weight shadows (bf16 training mode)
+// The master weights stay fp32 in the flat buffer; once per step (they only change at the optimizer update) the GEMM
+// operands are derived from them: (a) the whole flat buffer rounded to bf16 - same offsets, so every forward weight view
+// ([Cout][KH][KW][Cin] filters, [out, in] Linear weights) is a view of the shadow - and (b) transposed copies for the data
+// gradients, which read the weight with the OTHER index contiguous: w[R][T][C] -> wt[C][T][R] (Linear: T = 1; convolution:
+// [Cout][taps][Cin] -> [Cin][taps][Cout], taps in place).  Replaces the per-call casts torch.autocast inserts in front of
+// every aten::linear / convolution (and their backward) of the reference's training step.
+namespace {
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    stx4(out + i * 4, ldx4(in + i * 4));
+}
+
+struct ShadowEntry {   // 40 bytes
+  const float* src;
+  bf16_t* dst;
+  int32_t R, T, C;
+  int32_t tiles_c;     // ceil(C / 32)
+  int64_t tile0;       // first tile index of this entry (tiles = T * ceil(R/32) * ceil(C/32))
+};
+
+__global__ __launch_bounds__(256) void shadow_transpose_kernel(const ShadowEntry* __restrict__ table, int n) {
+  __shared__ float tile[32][33];
+  // the entry that holds this block's tile: binary search over the ascending tile0
+  int lo = 0, hi = n - 1;
+  const int64_t id = blockIdx.x;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].tile0 <= id) lo = mid; else hi = mid - 1;
+  }
+  const ShadowEntry e = table[lo];
+  int64_t q = id - e.tile0;
+  const int tiles_r = (e.R + 31) >> 5;
+  const int tc = (int)(q % e.tiles_c); q /= e.tiles_c;
+  const int tr = (int)(q % tiles_r);
+  const int t = (int)(q / tiles_r);
+  const int r0 = tr * 32, c0 = tc * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < e.R && c < e.C) ? e.src[((size_t)r * e.T + t) * e.C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < e.C && r < e.R) stx1(e.dst + ((size_t)c * e.T + t) * e.R + r, tile[tx][j]);
+  }
+}
+}  // namespace
+
+extern "C" int mmfn_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  if (n % 4 || !in || !out) return MMFN_EINVAL;
+  const int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256, 4096);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, n / 4);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_shadow_transpose_bf16(const void* table, int n_entries, int64_t total_tiles, void* stream) {
+  if (!table || n_entries <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffff) return MMFN_EINVAL;
+  hipLaunchKernelGGL(shadow_transpose_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                     (const ShadowEntry*)table, n_entries);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}

@@ -55,6 +55,8 @@ class Ctx(object):
         self.drop = drop_p if training else (0.0, 0.0, 0.0)  # (embd, attn, resid)
         self.rng_state = rng_state
         self.side = side  # side stream for work that is off the critical path (weight gradients), or None
+        self.adt = engine.act_dtype if engine is not None else torch.float32   # dtype of activation / activation-gradient buffers
+        self.bf16 = self.adt == torch.bfloat16
         self.folded = False  # eval forward over BatchNorm-folded filters (Engine.fold_batchnorm)
 
     def wino_u(self, name, w):
@@ -140,8 +142,71 @@ class ConvBN(object):
         self.bn = bn_mod
         self.stride, self.pad = stride, pad
         self.cout = self.w.shape[0]
+        self.conv_name = conv_name
+        self.w16 = self.w16t = None   # bf16 shadows [Cout,KH,KW,Cin] / [Cin,KH,KW,Cout] (Engine._build_shadows, bf16 mode)
+
+    def fwd16(self, ctx, x, relu=True, res=None):
+        """bf16 mode.  A trunk convolution (bf16 input): direct implicit GEMM on the bf16 MFMA pipe whose epilogue also emits
+        the BatchNorm batch-statistics partial sums of its fp32 accumulators (no statistics pass over the output); a stem (fp32
+        input from the ingest kernels, 3 / 2 channels): the fp32 convolution, fp32 output, and the BatchNorm apply is where the
+        activation becomes bf16."""
+        from . import ops16
+        _, oshape = ops.conv_geom(x.shape, self.w.shape, self.stride, self.pad)
+        M = oshape[0] * oshape[1] * oshape[2]
+        stem = x.dtype == torch.float32
+        co = ctx.bufs.get(self.name + ".conv", oshape, torch.float32 if stem else ctx.adt)
+        mean = ctx.bufs.get(self.name + ".mean", (self.cout,))
+        rstd = ctx.bufs.get(self.name + ".rstd", (self.cout,))
+        bn = self.bn
+        if stem:
+            if ctx.training:
+                ops.conv2d_fwd_bn_stats(x, self.w, self.stride, self.pad, co, mean, rstd, bn.running_mean, bn.running_var,
+                                        bn.num_batches_tracked, bn.eps, bn.momentum)
+            else:
+                ops.conv2d_fwd(x, self.w, self.stride, self.pad, out=co)
+        elif ctx.training:
+            K = self.w.shape[1] * self.w.shape[2] * self.w.shape[3]
+            rows = ops16.stats_rows(M, self.cout, K)
+            ws = ops.norm_workspace(x.device, rows * 2 * self.cout * 8)
+            ops16.conv2d_fwd(x, self.w16, self.stride, self.pad, co, stats=ws)
+            ops.bn_finalize_stats(ws, rows, M, self.cout, mean, rstd, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                  bn.eps, bn.momentum)
+        else:
+            ops16.conv2d_fwd(x, self.w16, self.stride, self.pad, co)
+        if not ctx.training:
+            ops.bn_eval_prepare(bn.running_mean, bn.running_var, mean, rstd, bn.eps)
+        y = ctx.bufs.get(self.name + ".out", oshape, ctx.adt)
+        ops.bn_apply(co.view(M, self.cout), y.view(M, self.cout), mean, rstd, self.bn_w, self.bn_b, relu,
+                     res=None if res is None else res.view(M, self.cout))
+        self.saved = (x, co, y, mean, rstd, relu)
+        return y
+
+    def bwd16(self, ctx, g, need_dx=True, ge_out=None, dx_res=None, mask_y=None):
+        from . import ops16
+        x, co, y, mean, rstd, relu = self.saved
+        M = co.numel() // self.cout
+        dco = ctx.bufs.get(self.name + ".dconv", co.shape, co.dtype)
+        ymask = (y if mask_y is None else mask_y).view(M, self.cout) if relu else None
+        ops.bn_bwd(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.bn_w, dco.view(M, self.cout),
+                   self.g_bn_w, self.g_bn_b, ge_out=None if ge_out is None else ge_out.view(M, self.cout))
+        if x.dtype == torch.float32:   # stem: fp32 weight gradient, no data gradient
+            ops.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, out=self.gw)
+            return None
+        ops16.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, self.gw)
+        if not need_dx:
+            return None
+        dx = ctx.bufs.get(self.name + ".dx", x.shape, ctx.adt)
+        cin = x.shape[-1]
+        if dx_res is None:
+            ops16.conv2d_dgrad(dco, self.w16t, tuple(x.shape), tuple(self.w.shape), self.stride, self.pad, dx)
+        else:
+            ops16.conv2d_dgrad(dco, self.w16t, tuple(x.shape), tuple(self.w.shape), self.stride, self.pad, dx,
+                               res=dx_res.view(-1, cin), ldr=cin)
+        return dx
 
     def fwd(self, ctx, x, relu=True, res=None):
+        if ctx.bf16:
+            return self.fwd16(ctx, x, relu, res)
         B = x.shape[0]
         _, oshape = ops.conv_geom(x.shape, self.w.shape, self.stride, self.pad)
         co = ctx.bufs.get(self.name + ".conv", oshape)
@@ -188,6 +253,8 @@ class ConvBN(object):
         """g: dL/dy.  ge_out receives the ReLU-masked g (the residual branch's gradient).
         dx_res is added to dx (gradient arriving at x from another branch).
         mask_y overrides the tensor whose sign gates the ReLU (when y was further modified)."""
+        if ctx.bf16:
+            return self.bwd16(ctx, g, need_dx, ge_out, dx_res, mask_y)
         x, co, y, mean, rstd, relu = self.saved
         M = co.numel() // self.cout
         dco = ctx.bufs.get(self.name + ".dconv", co.shape)
@@ -239,7 +306,7 @@ class BasicBlock(object):
         return self.c2.fwd(ctx, y1, relu=True, res=skip)
 
     def bwd(self, ctx, g, mask_y=None):
-        ge = ctx.bufs.get(self.name + ".ge", g.shape)
+        ge = ctx.bufs.get(self.name + ".ge", g.shape, g.dtype)
         g_y1 = self.c2.bwd(ctx, g, ge_out=ge, mask_y=mask_y)
         if self.down is None:
             return self.c1.bwd(ctx, g_y1, dx_res=ge)
@@ -270,7 +337,7 @@ class ResNetTrunk(object):
     def stem_fwd(self, ctx, x):
         y = self.stem.fwd(ctx, x, relu=True)
         B, H, W, C = y.shape
-        p = ctx.bufs.get(self.name + ".pool", (B, (H + 1) // 2, (W + 1) // 2, C))
+        p = ctx.bufs.get(self.name + ".pool", (B, (H + 1) // 2, (W + 1) // 2, C), y.dtype)
         idx = ctx.bufs.get(self.name + ".poolidx", p.shape, torch.uint8)
         ops.maxpool_fwd(y, p, idx)
         self.pool_saved = (y, idx)
@@ -278,7 +345,7 @@ class ResNetTrunk(object):
 
     def stem_bwd(self, ctx, g):
         y, idx = self.pool_saved
-        gy = ctx.bufs.get(self.name + ".dpool", y.shape)
+        gy = ctx.bufs.get(self.name + ".dpool", y.shape, y.dtype)
         ops.maxpool_bwd(g, idx, gy)
         self.stem.bwd(ctx, gy, need_dx=False)
 
@@ -300,6 +367,8 @@ class Linear(object):
         self.w, self.gw = layout.w(prefix + ".weight"), layout.g(prefix + ".weight")
         self.b = layout.w(prefix + ".bias") if bias else None
         self.gb = layout.g(prefix + ".bias") if bias else None
+        self.name = prefix + ".weight"
+        self.w16 = self.w16t = None   # bf16 shadows [out, in] / [in, out] (Engine._build_shadows, bf16 mode)
 
 
 DEFER_LN_REDUCTIONS = os.environ.get("MMFN_DEFER_LN", "1") == "1"   # A/B switch, see LayerNorm.bwd
@@ -313,7 +382,7 @@ class LayerNorm(object):
 
     def fwd(self, ctx, x, act=ACT_NONE, out=None):
         M, C = x.shape
-        y = ctx.bufs.get(self.name + ".y", (M, C)) if out is None else out
+        y = ctx.bufs.get(self.name + ".y", (M, C), x.dtype) if out is None else out
         mean, rstd = ctx.bufs.get(self.name + ".mu", (M,)), ctx.bufs.get(self.name + ".rs", (M,))
         ops.layernorm_fwd(x, self.w, self.b, y, mean, rstd, act)
         self.saved = (x, mean, rstd, act)
@@ -323,7 +392,7 @@ class LayerNorm(object):
         """defer: the caller rejoins the side stream before the gradients are consumed (GPT.bwd).  dropped: buffer that receives dx with the dropout mask (p, stream) of the branch consuming dx applied.
         colsum: [C] gradient buffer that receives the column sums of that tensor (the consuming Linear's bias gradient)."""
         x, mean, rstd, act = self.saved
-        dx = ctx.bufs.get(self.name + ".dx", x.shape) if out is None else out
+        dx = ctx.bufs.get(self.name + ".dx", x.shape, x.dtype) if out is None else out
         rng = ctx.rng_state if dropped is not None else None
         if (defer is True or isinstance(defer, list)) and ctx.side is not None and DEFER_LN_REDUCTIONS:
             # the chain only needs dx: the reduction of the per-block partial rows into the weight / bias gradients (and the
@@ -390,6 +459,8 @@ class GPT(object):
                 "fc2": Linear(layout, bp + ".mlp.2"),
             }
             blk["wqkv"], blk["g_wqkv"] = layout.packed(bp + ".attn.key.weight", 3 * C, C)
+            blk["wqkv_name"] = bp + ".attn.key.weight"
+            blk["wqkv16"] = blk["wqkv16t"] = None   # bf16 shadows (Engine._build_shadows)
             blk["bqkv"], blk["g_bqkv"] = layout.packed(bp + ".attn.key.bias", 3 * C)
             self.blocks.append(blk)
         self.ln_f = LayerNorm(name + ".ln_f", layout, prefix + ".ln_f")
@@ -419,7 +490,9 @@ class GPT(object):
         M = B * T
         bufs, nm = ctx.bufs, self.name
         p_embd, p_attn, p_resid = ctx.drop
-        x = bufs.get(nm + ".x0", (B, T, C))
+        adt = ctx.adt
+        Wf = (lambda lin: lin.w16) if ctx.bf16 else (lambda lin: lin.w)      # forward operand of a Linear
+        x = bufs.get(nm + ".x0", (B, T, C), adt)
         ops.tokens_fwd(feats, self.pos.view(T, C), self.vel.w.view(C), self.vel.b, velocity, x, p_embd, ctx.rng_state,
                        self.stream_base)
         self.velocity = velocity
@@ -428,27 +501,27 @@ class GPT(object):
         scale = 1.0 / math.sqrt(hs)
         nb = len(self.blocks)
         # the activations the weight gradients read again, stacked over the blocks (one batched launch per weight in bwd)
-        S_a, S_a2 = bufs.get(nm + ".S.a", (nb, M, C)), bufs.get(nm + ".S.a2", (nb, M, C))
-        S_o, S_h = bufs.get(nm + ".S.att", (nb, M, C)), bufs.get(nm + ".S.h", (nb, M, 4 * C))
+        S_a, S_a2 = bufs.get(nm + ".S.a", (nb, M, C), adt), bufs.get(nm + ".S.a2", (nb, M, C), adt)
+        S_o, S_h = bufs.get(nm + ".S.att", (nb, M, C), adt), bufs.get(nm + ".S.h", (nb, M, 4 * C), adt)
         self.stacks = (S_a, S_a2, S_o, S_h)
         for i, blk in enumerate(self.blocks):
             sb = self.stream_base + 1 + 3 * i
             a = blk["ln1"].fwd(ctx, x, out=S_a[i])
-            qkv = bufs.get("%s.b%d.qkv" % (nm, i), (M, 3 * C))
-            ops.linear_fwd(a, blk["wqkv"], blk["bqkv"], out=qkv)
+            qkv = bufs.get("%s.b%d.qkv" % (nm, i), (M, 3 * C), adt)
+            ops.linear_fwd(a, blk["wqkv16"] if ctx.bf16 else blk["wqkv"], blk["bqkv"], out=qkv)
             o = S_o[i]
             lse = bufs.get("%s.b%d.lse" % (nm, i), (B, nh, T))
             # packed columns: [key | query | value]  (reference registration order, model_vec.py:82-84)
             ops.attention_fwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, C, lse, B, T, nh, hs, scale, drop_p=p_attn,
                               rng_state=ctx.rng_state, rng_stream=sb)
-            x1 = bufs.get("%s.b%d.x1" % (nm, i), (M, C))
-            ops.linear_fwd(o, blk["proj"].w, blk["proj"].b, out=x1, res=x, ldr=C, drop_p=p_resid, rng_state=ctx.rng_state,
+            x1 = bufs.get("%s.b%d.x1" % (nm, i), (M, C), adt)
+            ops.linear_fwd(o, Wf(blk["proj"]), blk["proj"].b, out=x1, res=x, ldr=C, drop_p=p_resid, rng_state=ctx.rng_state,
                            rng_stream=sb + 1)
             a2 = blk["ln2"].fwd(ctx, x1, out=S_a2[i])
             h = S_h[i]
-            ops.linear_fwd(a2, blk["fc1"].w, blk["fc1"].b, out=h, relu=True)
-            x2 = bufs.get("%s.b%d.x2" % (nm, i), (M, C))
-            ops.linear_fwd(h, blk["fc2"].w, blk["fc2"].b, out=x2, res=x1, ldr=C, drop_p=p_resid, rng_state=ctx.rng_state,
+            ops.linear_fwd(a2, Wf(blk["fc1"]), blk["fc1"].b, out=h, relu=True)
+            x2 = bufs.get("%s.b%d.x2" % (nm, i), (M, C), adt)
+            ops.linear_fwd(h, Wf(blk["fc2"]), blk["fc2"].b, out=x2, res=x1, ldr=C, drop_p=p_resid, rng_state=ctx.rng_state,
                            rng_stream=sb + 2)
             self.acts.append((x, a, qkv, o, lse, x1, a2, h))
             x = x2
@@ -466,7 +539,7 @@ class GPT(object):
         scale = 1.0 / math.sqrt(hs)
         nblk = len(self.blocks)
         drop = p_resid > 0.0
-        grouped = self.grouped and ctx.side is not None
+        grouped = self.grouped and ctx.side is not None and not ctx.bf16
         # the LayerNorm backward that produces a block's incoming gradient also writes its dropped copy (the residual
         # dropouts of the forward sit in GEMM epilogues; their masks are re-applied here without an extra pass)
         sb_of = lambda i: self.stream_base + 1 + 3 * i
@@ -474,12 +547,14 @@ class GPT(object):
         # (what enters the MLP branch), G1 / GD2 the same for the attention branch, GH / DQKV the gradients of the hidden / qkv
         # activations.  The side stream reads them for the weight gradients, so they are per block and it may lag by any number
         # of blocks: one rejoin at the end of the transformer.
-        G = bufs.get(nm + ".S.g", (nblk, M, C))
-        GD = bufs.get(nm + ".S.gdrop", (nblk, M, C)) if drop else None
-        G1 = bufs.get(nm + ".S.g1", (nblk, M, C))
-        GD2 = bufs.get(nm + ".S.gdrop2", (nblk, M, C)) if drop else None
-        GH = bufs.get(nm + ".S.gh", (nblk, M, 4 * C))
-        DQKV = bufs.get(nm + ".S.dqkv", (nblk, M, 3 * C))
+        adt = ctx.adt
+        Wb = (lambda lin: lin.w16t) if ctx.bf16 else (lambda lin: lin.w)     # data-gradient operand of a Linear (bf16: the transposed shadow)
+        G = bufs.get(nm + ".S.g", (nblk, M, C), adt)
+        GD = bufs.get(nm + ".S.gdrop", (nblk, M, C), adt) if drop else None
+        G1 = bufs.get(nm + ".S.g1", (nblk, M, C), adt)
+        GD2 = bufs.get(nm + ".S.gdrop2", (nblk, M, C), adt) if drop else None
+        GH = bufs.get(nm + ".S.gh", (nblk, M, 4 * C), adt)
+        DQKV = bufs.get(nm + ".S.dqkv", (nblk, M, 3 * C), adt)
         # ... and its column sums, which are the bias gradient of the Linear that closes the residual branch (mlp.2 / attn.proj)
         # Side work (everything that only feeds the optimizer) is collected and forked to the side stream ONCE per block: in a
         # replayed graph every fork moves the continuation of the chain to another hardware queue, and each such hop costs
@@ -503,31 +578,31 @@ class GPT(object):
             if not grouped:
                 side.append(lambda gp=gp, blk=blk, h=h: ops.linear_dw(gp, h, out=blk["fc2"].gw))   # fc2.gb: from the LayerNorm backward
             gh = GH[i]
-            ops.linear_dx(gp, blk["fc2"].w, out=gh, aux=h, ldaux=4 * C)
+            ops.linear_dx(gp, Wb(blk["fc2"]), out=gh, aux=h, ldaux=4 * C)
             if pending is not None:
                 ctx.offload_at(pending[0], lambda work=pending[1]: [f() for f in work])
                 pending = None
             if not grouped:
                 side.append(lambda gh=gh, blk=blk, a2=a2: (ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
-            ga2 = bufs.get(nm + ".ga", (M, C))
-            ops.linear_dx(gh, blk["fc1"].w, out=ga2)
+            ga2 = bufs.get(nm + ".ga", (M, C), adt)
+            ops.linear_dx(gh, Wb(blk["fc1"]), out=ga2)
             g1 = blk["ln2"].bwd(ctx, ga2, dres=g, out=G1[i], dropped=GD2[i] if drop else None, drop_p=p_resid,
                                 rng_stream=sb + 1, colsum=blk["proj"].gb, defer=side)
             # ---- attention branch: x1 = x + drop(proj(att(ln1(x))))
             gp = GD2[i] if drop else g1
             if not grouped:
                 side.append(lambda gp=gp, blk=blk, o=o: ops.linear_dw(gp, o, out=blk["proj"].gw))   # proj.gb: from ln2's backward
-            go = bufs.get(nm + ".go", (M, C))
-            ops.linear_dx(gp, blk["proj"].w, out=go)
+            go = bufs.get(nm + ".go", (M, C), adt)
+            ops.linear_dx(gp, Wb(blk["proj"]), out=go)
             dqkv = DQKV[i]
             delta = bufs.get(nm + ".delta", (B, nh, T))
             ops.attention_bwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, go, C, lse, delta, dqkv[:, C:], dqkv, dqkv[:, 2 * C:],
                               3 * C, B, T, nh, hs, scale, drop_p=p_attn, rng_state=ctx.rng_state, rng_stream=sb)
             if not grouped:
                 side.append(lambda dqkv=dqkv, blk=blk, a=a: (ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
-            ga = bufs.get(nm + ".ga2", (M, C))
-            ops.linear_dx(dqkv, blk["wqkv"], out=ga)
-            g = blk["ln1"].bwd(ctx, ga, dres=g1, out=G[i - 1] if i > 0 else bufs.get(nm + ".g_tok", (M, C)),
+            ga = bufs.get(nm + ".ga2", (M, C), adt)
+            ops.linear_dx(dqkv, blk["wqkv16t"] if ctx.bf16 else blk["wqkv"], out=ga)
+            g = blk["ln1"].bwd(ctx, ga, dres=g1, out=G[i - 1] if i > 0 else bufs.get(nm + ".g_tok", (M, C), adt),
                                dropped=GD[i - 1] if (drop and i > 0) else None, drop_p=p_resid,
                                rng_stream=sb_of(i - 1) + 2, colsum=self.blocks[i - 1]["fc2"].gb if i > 0 else None, defer=side)
             if not grouped and not GPT_FORK_EACH:   # this block's side work: one fork, behind everything the chain has enqueued so far
@@ -640,7 +715,7 @@ class VectorNet(object):
         gen_act = self.gen_ln.fwd(ctx, gen_pre, ACT_GELU)
         nchw = bufs.get(nm + ".nchw", (B, 64 * 64 * 64))
         ops.linear_fwd(gen_act, self.gen3.w, self.gen3.b, out=nchw)
-        out = bufs.get(nm + ".out", (B, 64, 64, 64))
+        out = bufs.get(nm + ".out", (B, 64, 64, 64), ctx.adt)   # (bf16 mode: VectorNet is fp32 inside, its map feature is an activation)
         ops.transpose(nchw, out, B, 64, 4096)  # "b (n d a)" -> NHWC [b, d, a, n]
         self.saved = (B, L, V, tok, qkv, att0, prob, lane_num, t0, pe, pe_act, af_act, fused, gen_act)
         return out
@@ -907,6 +982,10 @@ class Engine(object):
             raise NotImplementedError("only seq_len=1, n_views=1 (the reference configuration) is built")
         self.module, self.layout, self.variant, self.cfg = module, layout, variant, cfg
         self.device = layout.device
+        self.act_dtype = {"f32": torch.float32, "bf16": torch.bfloat16}[getattr(cfg, "act_dtype", "f32")]
+        if self.act_dtype == torch.bfloat16 and variant == "rad":
+            raise NotImplementedError("the bf16 training mode covers the vec and img variants (the rad variant's T = 256 attention and "
+                                      "radar GAT have no bf16 kernels)")
         if self.device.type != "cuda":
             raise ops._lib.MMFNLibraryError("the MMFN HIP path needs a GPU device (got %s); there is no CPU fallback" % self.device)
         enc = module.encoder
@@ -941,6 +1020,9 @@ class Engine(object):
         self.folded = {}        # ConvBN name -> (BatchNorm-folded filter, shift), see fold_batchnorm()
         # "f32" (parity path) or "bf16": bf16 MFMA operands with fp32 accumulation for the Linear / Winograd GEMMs
         self.gemm_dtype = getattr(cfg, "gemm_dtype", "f32")
+        if self.act_dtype == torch.bfloat16:
+            self.gemm_dtype = "f32"   # the fp32 islands of the bf16 mode (stems, VectorNet, head) are plain fp32
+            self._build_shadows()
         self.wino_layers = {}     # ConvBN name -> (filter storage, transformed-filter buffer): filled by the first training forward
         self.wino_table = None
         self.opt_group_of = None
@@ -949,6 +1031,62 @@ class Engine(object):
         self._hyper_pinned, self._hyper_slot = None, 0
         self.n_lanes = int(os.environ.get("MMFN_BRANCH_LANES", "3"))
         self.offload_wgrad = os.environ.get("MMFN_OFFLOAD_WGRAD", "1") == "1"
+
+    # ------------------------------------------------------------------ bf16 weight shadows
+    def _build_shadows(self):
+        """bf16 mode: every GEMM weight has a bf16 shadow at the same offset of layout.params16 (forward operand) and, where a
+        data gradient reads it, a transposed shadow ([in, out] / [Cin, taps, Cout]) in one extra flat buffer; both are
+        re-derived from the fp32 master weights once per step (refresh_shadows: two launches)."""
+        L = self.layout
+        L.make_shadows()
+        entries = []
+
+        def want(src, shape_t):
+            n = src.numel()
+            entries.append((src, n, shape_t))
+
+        trunks = [self.img, self.lid, self.map]
+        convs = [cb for t in trunks for cb in t.convbns() if cb.w.shape[3] % 64 == 0]   # all but the 7x7 stems
+        for cb in convs:
+            cb.w16 = L.w16(cb.conv_name + ".weight")
+            Co, KH, KW, Ci = cb.w.shape
+            want(cb.w.view(Co, KH * KW, Ci), (Ci, KH, KW, Co))
+        lins = []
+        for gpt in self.gpts:
+            for blk in gpt.blocks:
+                C = gpt.C
+                blk["wqkv16"] = L.packed16(blk["wqkv_name"], 3 * C, C)
+                want(blk["wqkv"], (C, 3 * C))
+                for k in ("proj", "fc1", "fc2"):
+                    lin = blk[k]
+                    lin.w16 = L.w16(lin.name)
+                    want(lin.w, (lin.w.shape[1], lin.w.shape[0]))
+                    lins.append(lin)
+        total = sum((n + 7) // 8 * 8 for _, n, _ in entries)
+        self.shadow_t = torch.zeros(total, dtype=torch.bfloat16, device=self.device)
+        off, pairs, views = 0, [], []
+        for src, n, shape_t in entries:
+            dst = self.shadow_t[off:off + n]
+            pairs.append((src, dst))
+            views.append(dst.view(shape_t))
+            off += (n + 7) // 8 * 8
+        it = iter(views)
+        for cb in convs:
+            cb.w16t = next(it)
+        for gpt in self.gpts:
+            for blk in gpt.blocks:
+                blk["wqkv16t"] = next(it)
+                for k in ("proj", "fc1", "fc2"):
+                    blk[k].w16t = next(it)
+        self.shadow_table = ops.make_shadow_table(pairs, self.device)
+        self.refresh_shadows()
+
+    def refresh_shadows(self):
+        """fp32 master weights -> bf16 operands (same offsets) + transposed copies.  Part of every bf16-mode forward: the weights
+        change at every optimizer step, and a captured step must not depend on host-side bookkeeping."""
+        L = self.layout
+        ops.cast_to_bf16(L.params, L.params16)
+        ops.shadow_transpose(*self.shadow_table)
 
     # ------------------------------------------------------------------ inputs
     def _bufs_for(self, B):
@@ -1049,6 +1187,10 @@ class Engine(object):
                 raise ValueError("folded=True is an eval-mode option and needs Engine.fold_batchnorm() first")
             ctx.folded = True
         self._last = (ctx, B)
+        if ctx.bf16:
+            if folded:
+                raise ValueError("BatchNorm folding is an fp32-mode option")
+            self.refresh_shadows()
         img, lid, mp = self._ingest(ctx, inp)
         vel = inp["velocity"]
         trunks = [self.img, self.lid, self.map]
@@ -1092,7 +1234,7 @@ class Engine(object):
                 prev, ptok = feats, tok
 
                 def stage(m, prev=prev, ptok=ptok, s=s):
-                    f = ops.upsample_add_fwd(prev[m], ptok, ctx.bufs.get("fuse%d.%d" % (s - 1, m), prev[m].shape), m)
+                    f = ops.upsample_add_fwd(prev[m], ptok, ctx.bufs.get("fuse%d.%d" % (s - 1, m), prev[m].shape, prev[m].dtype), m)
                     return trunks[m].layer_fwd(ctx, s + 1, f)
 
                 feats = self._branches([lambda m=m: stage(m) for m in range(3)])
@@ -1101,7 +1243,7 @@ class Engine(object):
             tok = self.gpts[s].fwd(ctx, feats, vel)
             self.taps["gpt%d" % (s + 1)] = tok
             self.pre_add.append(feats)
-        feats = [ops.upsample_add_fwd(f, tok, ctx.bufs.get("fuse3.%d" % m, f.shape), m) for m, f in enumerate(feats)]
+        feats = [ops.upsample_add_fwd(f, tok, ctx.bufs.get("fuse3.%d" % m, f.shape, f.dtype), m) for m, f in enumerate(feats)]
         fused = ops.gap_sum_fwd(feats, ctx.bufs.get("fused", (B, 512)))
         self.taps["fused"] = fused
         pred, loss = self.head.fwd(ctx, fused, inp["target_point"], gt)
@@ -1134,7 +1276,7 @@ class Engine(object):
         if self.rad is None:   # (rad: the "head" group also holds the radar encoder, complete after the deepest transformer)
             self._ready(on_ready, 0, "head")
         shapes = [f.shape for f in self.pre_add[3]]
-        self._G = [bufs.get("G3.%d" % m, shp) for m, shp in enumerate(shapes)]
+        self._G = [bufs.get("G3.%d" % m, shp, ctx.adt) for m, shp in enumerate(shapes)]
         ops.gap_sum_bwd(g_fused, self._G)
 
     @_in_precision
@@ -1148,7 +1290,7 @@ class Engine(object):
         trunks = [self.img, self.lid, self.map]
         G = self._G
         gpt = self.gpts[s]
-        gtok = bufs.get("gtok%d" % s, (B, gpt.T, gpt.C))
+        gtok = bufs.get("gtok%d" % s, (B, gpt.T, gpt.C), ctx.adt)
         for m, g in enumerate(G):
             if not (self._adj_done and m < 3):   # the three branch lanes of the previous scale already spread their gradient
                 ops.upsample_adj(g, gtok, m)
@@ -1162,10 +1304,10 @@ class Engine(object):
         in_lane_ok = not (self._recorder is not None and self._recorder.split_lanes)
         if s > 0:
             nxt = self.gpts[s - 1]
-            gtok_next = bufs.get("gtok%d" % (s - 1), (B, nxt.T, nxt.C))
+            gtok_next = bufs.get("gtok%d" % (s - 1), (B, nxt.T, nxt.C), ctx.adt)
 
             def stage(m):
-                d = ops.pool_bcast_add(G[m], gin, bufs.get("dF%d.%d" % (s, m), G[m].shape), m)
+                d = ops.pool_bcast_add(G[m], gin, bufs.get("dF%d.%d" % (s, m), G[m].shape, G[m].dtype), m)
                 g = trunks[m].layer_bwd(ctx, s + 1, d)
                 if in_lane_ok:
                     self._ready(on_ready, st, names[m])
@@ -1183,19 +1325,19 @@ class Engine(object):
             return
 
         def img_tail():
-            d = ops.pool_bcast_add(G[0], gin, bufs.get("dF0.0", G[0].shape), 0)
+            d = ops.pool_bcast_add(G[0], gin, bufs.get("dF0.0", G[0].shape, G[0].dtype), 0)
             self.img.stem_bwd(ctx, self.img.layer_bwd(ctx, 1, d))
             if in_lane_ok:
                 self._ready(on_ready, st, "img")
 
         def lid_tail():
-            d = ops.pool_bcast_add(G[1], gin, bufs.get("dF0.1", G[1].shape), 1)
+            d = ops.pool_bcast_add(G[1], gin, bufs.get("dF0.1", G[1].shape, G[1].dtype), 1)
             self.lid.stem_bwd(ctx, self.lid.layer_bwd(ctx, 1, d))
             if in_lane_ok:
                 self._ready(on_ready, st, "lid")
 
         def map_tail():
-            d = ops.pool_bcast_add(G[2], gin, bufs.get("dF0.2", G[2].shape), 2)
+            d = ops.pool_bcast_add(G[2], gin, bufs.get("dF0.2", G[2].shape, G[2].dtype), 2)
             if self.variant == "img":
                 self.map.stem_bwd(ctx, self.map.layer_bwd(ctx, 1, d))
             else:

@@ -44,7 +44,7 @@ class DrivingSession(object):
         self._n_points = 0
         self._n_dev = 0
         self.graph = None
-        self.fold = fold_batchnorm
+        self.fold = fold_batchnorm and self.eng.act_dtype == torch.float32   # (folding is an fp32-mode option)
         with torch.no_grad():
             if self.fold:
                 # eval-mode BatchNorm folded into the filters: convolution + shift + skip + ReLU is one launch instead of

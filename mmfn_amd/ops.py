@@ -15,6 +15,7 @@ from ._lib import (A_COLMAJOR, A_DGRAD, A_IM2COL, A_ROWMAJOR, B_DGRADW, B_IM2COL
                    EPI_ACCUM, EPI_BF16_OPERANDS, EPI_BF16X3, EPI_BIAS, EPI_DROPOUT, EPI_GELU, EPI_MASK_AUX, EPI_RELU, EPI_RELU_LAST, EPI_RESIDUAL,
                    GemmDesc, check, lib, ptr, stream)
 
+BF16 = torch.bfloat16   # activations of the bf16 training mode: the wrappers below dispatch on the tensors' dtype
 _workspace = {}
 _retired = []  # scratch buffers that were outgrown: never freed, captured hipGraphs may still point into them
 _lane = 0  # logical execution lane (0 = main stream, 1.. = engine side streams); scratch buffers are per lane
@@ -350,13 +351,19 @@ def linear_fwd(x, w, bias=None, out=None, **epi):
     """out[M,N] = x[M,K] @ w[N,K]^T (+bias, epilogue)."""
     M, K = x.shape
     N = w.shape[0]
+    if x.dtype == BF16:   # bf16 mode: w is the bf16 shadow of the weight
+        from . import ops16
+        return ops16.linear_fwd(x, w, bias, out=out, **epi)
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=x.device)
     return gemm(x, w, out, M, N, K, x.stride(0), w.stride(0), out.stride(0), A_ROWMAJOR, B_NK, bias=bias, **epi)
 
 
 def linear_dx(dy, w, out=None, **epi):
-    """dx[M,K] = dy[M,N] @ w[N,K]."""
+    """dx[M,K] = dy[M,N] @ w[N,K].  bf16 mode: w is the TRANSPOSED bf16 shadow [K,N]."""
+    if dy.dtype == BF16:
+        from . import ops16
+        return ops16.linear_dx(dy, w, out=out, **epi)
     M, N = dy.shape
     K = w.shape[1]
     if out is None:
@@ -366,6 +373,9 @@ def linear_dx(dy, w, out=None, **epi):
 
 def linear_dw(dy, x, out=None, **epi):
     """dw[N,K] = dy[M,N]^T @ x[M,K]."""
+    if dy.dtype == BF16:
+        from . import ops16
+        return ops16.linear_dw(dy, x, out, **epi)
     M, N = dy.shape
     K = x.shape[1]
     if out is None:
@@ -678,8 +688,15 @@ def axpby(y, x, a=1.0, b=1.0):
 # ---------------------------------------------------------------- BatchNorm / LayerNorm
 def bn_train_stats(x2d, mean, rstd, running_mean, running_var, nbt, eps=1e-5, momentum=0.1):
     M, C = x2d.shape
-    _call("mmfn_bn_train_stats_f32", ptr(x2d), M, C, eps, momentum, ptr(mean), ptr(rstd), ptr(running_mean),
-          ptr(running_var), ptr(nbt), ptr(norm_workspace(x2d.device)), stream())
+    _call("mmfn_bn_train_stats_bf16" if x2d.dtype == BF16 else "mmfn_bn_train_stats_f32", ptr(x2d), M, C, eps, momentum, ptr(mean),
+          ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt), ptr(norm_workspace(x2d.device)), stream())
+
+
+def bn_finalize_stats(partials, nblk, M, C, mean, rstd, running_mean, running_var, nbt, eps=1e-5, momentum=0.1):
+    """Second half of bn_train_stats for producers that emit the per-block (sum, sum of squares) rows themselves (the bf16
+    convolution's epilogue, ops16.conv2d_fwd(stats=...)): partials [nblk, 2, C] fp64."""
+    _call("mmfn_bn_finalize_stats_f32", ptr(partials), nblk, M, C, eps, momentum, ptr(mean), ptr(rstd), ptr(running_mean),
+          ptr(running_var), ptr(nbt), stream())
 
 
 def bn_fold(w, gamma, beta, running_mean, running_var, eps, w_out, b_out):
@@ -695,6 +712,10 @@ def bn_eval_prepare(running_mean, running_var, mean, rstd, eps=1e-5):
 
 def bn_apply(x2d, y2d, mean, rstd, weight, bias, relu, res=None):
     M, C = x2d.shape
+    if y2d.dtype == BF16:   # x: the convolution output, bf16 or (stems) fp32
+        _call("mmfn_bn_apply_bf16", ptr(x2d), 0 if x2d.dtype == BF16 else 1, ptr(res), ptr(y2d), M, C, ptr(mean), ptr(rstd),
+              ptr(weight), ptr(bias), 1 if relu else 0, stream())
+        return y2d
     _call("mmfn_bn_apply_f32", ptr(x2d), ptr(res), ptr(y2d), M, C, ptr(mean), ptr(rstd), ptr(weight), ptr(bias),
           1 if relu else 0, stream())
     return y2d
@@ -702,6 +723,11 @@ def bn_apply(x2d, y2d, mean, rstd, weight, bias, relu, res=None):
 
 def bn_bwd(g2d, y2d, x2d, mean, rstd, weight, dx, dweight, dbias, ge_out=None):
     M, C = x2d.shape
+    if g2d.dtype == BF16:   # x / dx: bf16, or both fp32 (stems)
+        assert dx.dtype == x2d.dtype
+        _call("mmfn_bn_bwd_bf16", ptr(g2d), ptr(y2d), ptr(x2d), 0 if x2d.dtype == BF16 else 1, M, C, ptr(mean), ptr(rstd), ptr(weight),
+              ptr(dx), ptr(ge_out), ptr(dweight), ptr(dbias), ptr(norm_workspace(x2d.device)), stream())
+        return dx
     _call("mmfn_bn_bwd_f32", ptr(g2d), ptr(y2d), ptr(x2d), M, C, ptr(mean), ptr(rstd), ptr(weight), ptr(dx), ptr(ge_out),
           ptr(dweight), ptr(dbias), ptr(norm_workspace(x2d.device)), stream())
     return dx
@@ -721,7 +747,8 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
 def layernorm_fwd(x, w, b, y, mean, rstd, act=ACT_NONE, eps=1e-5):
     M, C = x.shape
-    _call("mmfn_layernorm_fwd_f32", ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), M, C, eps, act, stream())
+    _call("mmfn_layernorm_fwd_bf16" if x.dtype == BF16 else "mmfn_layernorm_fwd_f32", ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean),
+          ptr(rstd), M, C, eps, act, stream())
     return y
 
 
@@ -730,6 +757,13 @@ def layernorm_bwd(g, x, w, b, mean, rstd, dx, dw, db, act=ACT_NONE, dres=None, d
     """dx_dropped: optional second output dx * dropout keep-scale (the mask of the residual branch that consumes dx).
     dx_colsum: optional [C] output, column sums of dx_dropped (of dx without a dropped copy): the next bias gradient."""
     M, C = x.shape
+    if x.dtype == BF16:   # the two halves separately (same kernels as the fused entry)
+        rows = layernorm_bwd_rows(M)
+        part = norm_workspace(x.device).view(torch.float32)[:rows * 3 * C].view(rows, 3, C)
+        layernorm_bwd_partial(g, x, w, b, mean, rstd, dx, part, act, dres=dres, dx_dropped=dx_dropped, drop_p=drop_p,
+                              rng_state=rng_state, rng_stream=rng_stream, want_colsum=dx_colsum is not None)
+        layernorm_bwd_finalize(part, rows, C, dw, db, dx_colsum)
+        return dx
     _call("mmfn_layernorm_bwd_drop_f32", ptr(g), ptr(x), ptr(w), ptr(b), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dw),
           ptr(db), M, C, act, ptr(dx_dropped), float(drop_p), ptr(rng_state), rng_stream, ptr(dx_colsum),
           ptr(norm_workspace(x.device)), stream())
@@ -745,7 +779,8 @@ def layernorm_bwd_partial(g, x, w, b, mean, rstd, dx, partials, act=ACT_NONE, dr
     """First half of layernorm_bwd: dx (and dx_dropped) now, the row reductions as partial rows in `partials`
     ([layernorm_bwd_rows(M), 3 or 2, C] floats) for layernorm_bwd_finalize - which may run later, on another stream."""
     M, C = x.shape
-    _call("mmfn_layernorm_bwd_partial_f32", ptr(g), ptr(x), ptr(w), ptr(b), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), M, C, act,
+    _call("mmfn_layernorm_bwd_partial_bf16" if x.dtype == BF16 else "mmfn_layernorm_bwd_partial_f32", ptr(g), ptr(x), ptr(w), ptr(b),
+          ptr(mean), ptr(rstd), ptr(dres), ptr(dx), M, C, act,
           ptr(dx_dropped), float(drop_p), ptr(rng_state), rng_stream, 1 if want_colsum else 0, ptr(partials), stream())
     return dx
 
@@ -759,7 +794,8 @@ def colsum(x2d, out, M=None, C=None, ld=None):
     C = x2d.shape[1] if C is None else C
     ld = x2d.stride(0) if ld is None else ld
     need = lib().mmfn_colsum_workspace_bytes(M, C)
-    _call("mmfn_colsum_f32", ptr(x2d), M, C, ld, ptr(out), ptr(norm_workspace(x2d.device, need)), stream())
+    _call("mmfn_colsum_bf16" if x2d.dtype == BF16 else "mmfn_colsum_f32", ptr(x2d), M, C, ld, ptr(out),
+          ptr(norm_workspace(x2d.device, need)), stream())
     return out
 
 
@@ -784,20 +820,20 @@ def linear_dw_batched(dy3d, x3d, out0, stride_out, **epi):
 # ---------------------------------------------------------------- pooling / tokens / upsample
 def maxpool_fwd(x, y, idx):
     B, H, W, C = x.shape
-    _call("mmfn_maxpool3x3s2_fwd_f32", ptr(x), ptr(y), ptr(idx), B, H, W, C, stream())
+    _call("mmfn_maxpool3x3s2_fwd_bf16" if x.dtype == BF16 else "mmfn_maxpool3x3s2_fwd_f32", ptr(x), ptr(y), ptr(idx), B, H, W, C, stream())
     return y
 
 
 def maxpool_bwd(gy, idx, gx):
     B, H, W, C = gx.shape
-    _call("mmfn_maxpool3x3s2_bwd_f32", ptr(gy), ptr(idx), ptr(gx), B, H, W, C, stream())
+    _call("mmfn_maxpool3x3s2_bwd_bf16" if gy.dtype == BF16 else "mmfn_maxpool3x3s2_bwd_f32", ptr(gy), ptr(idx), ptr(gx), B, H, W, C, stream())
     return gx
 
 
 def tokens_fwd(feats, pos, vel_w, vel_b, velocity, tok, drop_p=0.0, rng_state=None, rng_stream=0):
     B, S, _, C = feats[0].shape
     arr = _ptr_array(feats)
-    _call("mmfn_tokens_fwd_f32", arr, len(feats), B, S, C, ptr(pos), ptr(vel_w), ptr(vel_b), ptr(velocity), ptr(tok),
+    _call("mmfn_tokens_fwd_bf16" if tok.dtype == BF16 else "mmfn_tokens_fwd_f32", arr, len(feats), B, S, C, ptr(pos), ptr(vel_w), ptr(vel_b), ptr(velocity), ptr(tok),
           float(drop_p), ptr(rng_state), rng_stream, stream())
     return tok
 
@@ -805,56 +841,58 @@ def tokens_fwd(feats, pos, vel_w, vel_b, velocity, tok, drop_p=0.0, rng_state=No
 def tokens_bwd(gtok, velocity, dpos, dvel_w, dvel_b, drop_p=0.0, rng_state=None, rng_stream=0):
     B, T, C = gtok.shape
     need = lib().mmfn_tokens_bwd_workspace_bytes(T, C)
-    _call("mmfn_tokens_bwd_f32", ptr(gtok), B, T, C, ptr(velocity), ptr(dpos), ptr(dvel_w), ptr(dvel_b), float(drop_p),
+    _call("mmfn_tokens_bwd_bf16" if gtok.dtype == BF16 else "mmfn_tokens_bwd_f32", ptr(gtok), B, T, C, ptr(velocity), ptr(dpos), ptr(dvel_w), ptr(dvel_b), float(drop_p),
           ptr(rng_state), rng_stream, ptr(norm_workspace(gtok.device, need)), stream())
 
 
 def upsample_add_fwd(feat, tok, out, m):
     B, S, _, C = feat.shape
     T = tok.shape[1]
-    _call("mmfn_upsample_add_fwd_f32", ptr(feat), ptr(tok), ptr(out), B, S, C, T, m, stream())
+    _call("mmfn_upsample_add_fwd_bf16" if feat.dtype == BF16 else "mmfn_upsample_add_fwd_f32", ptr(feat), ptr(tok), ptr(out), B, S, C, T, m, stream())
     return out
 
 
 def upsample_adj(G, gtok, m):
     B, S, _, C = G.shape
     T = gtok.shape[1]
-    _call("mmfn_upsample_adj_f32", ptr(G), ptr(gtok), B, S, C, T, m, stream())
+    _call("mmfn_upsample_adj_bf16" if G.dtype == BF16 else "mmfn_upsample_adj_f32", ptr(G), ptr(gtok), B, S, C, T, m, stream())
 
 
 def pool_bcast_add(G, gtok, dF, m):
     B, S, _, C = G.shape
     T = gtok.shape[1]
-    _call("mmfn_pool_bcast_add_f32", ptr(G), ptr(gtok), ptr(dF), B, S, C, T, m, stream())
+    _call("mmfn_pool_bcast_add_bf16" if G.dtype == BF16 else "mmfn_pool_bcast_add_f32", ptr(G), ptr(gtok), ptr(dF), B, S, C, T, m, stream())
     return dF
 
 
 def gap_sum_fwd(feats, out):
     B, H, W, C = feats[0].shape
-    _call("mmfn_gap_sum_fwd_f32", _ptr_array(feats), len(feats), B, H * W, C, ptr(out), stream())
+    _call("mmfn_gap_sum_fwd_bf16" if feats[0].dtype == BF16 else "mmfn_gap_sum_fwd_f32", _ptr_array(feats), len(feats), B, H * W, C, ptr(out), stream())
     return out
 
 
 def gap_sum_bwd(g, outs):
     B, H, W, C = outs[0].shape
-    _call("mmfn_gap_sum_bwd_f32", ptr(g), _ptr_array(outs), len(outs), B, H * W, C, stream())
+    _call("mmfn_gap_sum_bwd_bf16" if outs[0].dtype == BF16 else "mmfn_gap_sum_bwd_f32", ptr(g), _ptr_array(outs), len(outs), B, H * W, C, stream())
 
 
 def transpose(inp, out, B, R, Cc):
-    _call("mmfn_transpose_f32", ptr(inp), ptr(out), B, R, Cc, stream())
+    name = {(torch.float32, torch.float32): "mmfn_transpose_f32", (torch.float32, BF16): "mmfn_transpose_f32_to_bf16",
+            (BF16, torch.float32): "mmfn_transpose_bf16_to_f32"}[(inp.dtype, out.dtype)]
+    _call(name, ptr(inp), ptr(out), B, R, Cc, stream())
     return out
 
 
 # ---------------------------------------------------------------- attention
 def attention_fwd(q, k, v, ld, o, ldo, lse, B, T, NH, HS, scale, kv_len=None, drop_p=0.0, rng_state=None, rng_stream=0):
-    _call("mmfn_attention_fwd_f32", ptr(q), ptr(k), ptr(v), ld, ptr(o), ldo, ptr(lse), B, T, NH, HS, float(scale),
+    _call("mmfn_attention_fwd_bf16" if q.dtype == BF16 else "mmfn_attention_fwd_f32", ptr(q), ptr(k), ptr(v), ld, ptr(o), ldo, ptr(lse), B, T, NH, HS, float(scale),
           ptr(kv_len), float(drop_p), ptr(rng_state), rng_stream, stream())
     return o
 
 
 def attention_bwd(q, k, v, ld, o, dO, ldo, lse, delta, dq, dk, dv, ldg, B, T, NH, HS, scale, kv_len=None, drop_p=0.0,
                   rng_state=None, rng_stream=0):
-    _call("mmfn_attention_bwd_f32", ptr(q), ptr(k), ptr(v), ld, ptr(o), ptr(dO), ldo, ptr(lse), ptr(delta), ptr(dq),
+    _call("mmfn_attention_bwd_bf16" if q.dtype == BF16 else "mmfn_attention_bwd_f32", ptr(q), ptr(k), ptr(v), ld, ptr(o), ptr(dO), ldo, ptr(lse), ptr(delta), ptr(dq),
           ptr(dk), ptr(dv), ldg, B, T, NH, HS, float(scale), ptr(kv_len), float(drop_p), ptr(rng_state), rng_stream, stream())
 
 
@@ -981,3 +1019,30 @@ def log_softmax_fwd(x, y, R, C, swap):
 def log_softmax_bwd(g, y, dx, R, C, swap):
     _call("mmfn_log_softmax_bwd_f32", ptr(g), ptr(y), ptr(dx), R, C, 1 if swap else 0, stream())
     return dx
+
+
+# ---------------------------------------------------------------- bf16 weight shadows
+def cast_to_bf16(src, dst):
+    _call("mmfn_cast_f32_to_bf16", ptr(src), ptr(dst), src.numel(), stream())
+    return dst
+
+
+def make_shadow_table(entries, device):
+    """entries: [(src fp32 storage tensor [R, T, C] or [R, C], dst bf16 flat tensor)] -> (device table, n, total tiles) for
+    shadow_transpose (dst[c][t][r] = src[r][t][c])."""
+    import struct
+    blob, tile0 = b"", 0
+    for src, dst in entries:
+        if src.dim() == 2:
+            R, T, C = src.shape[0], 1, src.shape[1]
+        else:
+            R, T, C = src.shape[0], src.numel() // (src.shape[0] * src.shape[-1]), src.shape[-1]
+        tiles_c = (C + 31) // 32
+        blob += struct.pack("<QQiiiiq", src.data_ptr(), dst.data_ptr(), R, T, C, tiles_c, tile0)
+        tile0 += T * ((R + 31) // 32) * tiles_c
+    t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    return t, len(entries), tile0
+
+
+def shadow_transpose(table, n, total):
+    _call("mmfn_shadow_transpose_bf16", ptr(table), n, total, stream())

@@ -318,6 +318,22 @@ class FlatLayout(object):
         self.device = device
         return self
 
+    # ------------------------------------------------------------------ bf16 weight shadows (bf16 training mode)
+    def make_shadows(self):
+        """params16: the flat parameter buffer rounded to bf16 at the same offsets (every kernel-side weight view has a bf16 twin,
+        w16()).  Refreshed once per step by the engine (ops.cast_to_bf16): the master weights stay fp32."""
+        if getattr(self, "params16", None) is None or self.params16.device != self.params.device:
+            self.params16 = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
+        return self.params16
+
+    def w16(self, name):
+        off, n = self.offsets[name]
+        return self.params16[off:off + n].view(self.storage_views[name].shape)
+
+    def packed16(self, first_name, count_rows, cols):
+        off, _ = self.offsets[first_name]
+        return self.params16[off:off + count_rows * cols].view(count_rows, cols)
+
     # kernel-side accessors
     def w(self, name):
         return self.storage_views[name]

@@ -1,85 +1,71 @@
-"""Dev tool: gradient quality of the bf16-operand mode against the fp32 HIP path at the bench size (B=32), per backward stage,
-under a REALISTIC initialisation (the reference's own: torchvision kaiming-normal ResNets, N(0, 0.02) GPT linears, PyTorch
-defaults elsewhere; seed 42 as run_steps/utils.py:77-84) and, for contrast, under the closed-form test fill.
-Prints per stage: cosine(g_bf16, g_fp32), relative error, and the loss difference."""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""bf16 training mode (GlobalConfig(act_dtype="bf16")) against the fp32 HIP path on the same weights and batch: loss, eval
+waypoints, per-backward-stage gradient cosine / relative error, and a few optimizer steps of both.
+  python tools/bf16_quality.py [--batch 8] [--oracle-init]"""
+import argparse
+import os
+import sys
+
 import torch
-import bench
-from mmfn_amd.config import GlobalConfig
-from mmfn_amd.model import MMFN
 
-dev = torch.device("cuda:0")
-B = int(os.environ.get("B", "32"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
-def grads(net, inp, gt):
-    eng = net._engine_for()
-    net.train()
-    _, loss = eng.forward(inp, True, gt)
-    eng.backward()
+def stage_stats(La, Lb):
+    out = []
+    for st, (b, e) in enumerate(La.stage_ranges):
+        a, c = La.grads[b:min(e, La.tail)].double(), Lb.grads[b:min(e, Lb.tail)].double()
+        cos = float((a * c).sum() / (a.norm() * c.norm() + 1e-300))
+        rel = float((a - c).norm() / (a.norm() + 1e-300))
+        out.append((st, cos, rel))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--variant", default="vec")
+    ap.add_argument("--seed", type=int, default=42)
+    args = ap.parse_args()
+    import bench
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd.model import MMFN, MMFNImg
+    dev = torch.device("cuda", 0)
+    cls = {"vec": MMFN, "img": MMFNImg}[args.variant]
+    torch.manual_seed(args.seed)
+    a = cls(GlobalConfig(embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0), dev)
+    b = cls(GlobalConfig(embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0, act_dtype="bf16"), dev)
+    b.load_state_dict(a.state_dict())
+    a.train(), b.train()
+    inp, gt = bench.synth_inputs(args.batch, dev, seed=args.seed, variant=args.variant)
+    ea, eb = a._engine_for(), b._engine_for()
+    _, la = ea.forward(inp, True, gt)
+    ea.backward()
+    _, lb = eb.forward(inp, True, gt)
+    eb.backward()
     torch.cuda.synchronize()
-    L = net._layout
-    return float(loss.item()), L.grads[:L.tail].clone()
+    print("loss f32 %.6f  bf16 %.6f  rel %.2e" % (la.item(), lb.item(), abs(la.item() - lb.item()) / abs(la.item())))
+    for st, cos, rel in stage_stats(a._layout, b._layout):
+        print("backward stage %d: gradient cosine %.4f  relative error %.3f" % (st, cos, rel))
+    for k in ("stage1", "gpt1", "gpt2", "gpt3", "gpt4"):
+        ta, tb = ea.taps[k], eb.taps[k]
+        if isinstance(ta, tuple):
+            for m, (x, y) in enumerate(zip(ta, tb)):
+                print("tap %s.%d rel err %.2e" % (k, m, float((x.float() - y.float()).norm() / x.float().norm())))
+        else:
+            print("tap %s rel err %.2e" % (k, float((ta.float() - tb.float()).norm() / ta.float().norm())))
+    a.eval(), b.eval()
+    with torch.no_grad():
+        pa, _ = ea.forward(inp, False, None)
+        pb, _ = eb.forward(inp, False, None)
+    print("eval waypoints max |diff| %.3e (scale %.3f)" % (float((pa - pb).abs().max()), float(pa.abs().max())))
+    a.train(), b.train()
+    for i in range(5):
+        la = a.train_step(inp, gt)
+        lb = b.train_step(inp, gt)
+    torch.cuda.synchronize()
+    print("after 5 AdamW steps on the same batch: loss f32 %.5f bf16 %.5f" % (la.item(), lb.item()))
 
 
-def report(tag, sd):
-    inp, gt = bench.synth_inputs(B, dev, seed=42)
-    out = {}
-    for dtype in ("f32", "bf16"):
-        torch.manual_seed(42)
-        net = MMFN(GlobalConfig(embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0, gemm_dtype=dtype), dev)
-        if sd is not None:
-            net.load_state_dict(sd, strict=True)
-        out[dtype] = grads(net, inp, gt) + (net._layout,)
-    (l32, g32, L), (l16, g16, _) = out["f32"], out["bf16"]
-    print("[%s] loss fp32 %.6f bf16 %.6f  rel diff %.2e" % (tag, l32, l16, abs(l32 - l16) / abs(l32)))
-    for st, (b, e) in enumerate(L.stage_ranges):
-        e = min(e, L.tail)
-        a, c = g32[b:e].double(), g16[b:e].double()
-        cos = float(torch.dot(a, c) / (a.norm() * c.norm()))
-        print("   stage %d (%s): cosine %.5f  rel err %.3e  |g| %.3e" % (st, ["scale 4 + head", "scale 3", "scale 2", "scale 1 + stems + VectorNet"][st], cos,
-                                                                          float((a - c).norm() / a.norm()), float(a.norm())))
-    a, c = g32.double(), g16.double()
-    print("   all: cosine %.5f rel err %.3e" % (float(torch.dot(a, c) / (a.norm() * c.norm())), float((a - c).norm() / a.norm())))
-
-
-report("reference init (seed 42)", None)
-from oracle import harness
-report("closed-form test fill", harness.build_oracle("vec", dropout=0.0).state_dict())
-
-
-def oracle_yardstick(Bo=8):
-    """What torch's OWN mixed precision does to this network's gradients: the CPU oracle under torch.autocast(bfloat16)
-    against itself in fp32, same reference-style init, per backward stage.  The yardstick for the HIP bf16 mode."""
-    from oracle import fixtures, harness
-    from mmfn_amd.params import FlatLayout
-    torch.manual_seed(42)
-    torch.set_num_threads(bench.usable_cores())
-    net = MMFN(GlobalConfig(embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0), "cpu")   # reference-style init (parameter skeleton)
-    oracle = harness.build_oracle("vec", dropout=0.0)
-    oracle.load_state_dict(net.state_dict(), strict=True)
-    inp, gt = bench.synth_inputs(Bo, torch.device("cpu"), seed=42)
-    args = harness.forward_args(bench.oracle_batch_from_inputs(inp, "vec"), "vec")
-
-    def run(autocast):
-        oracle.train()
-        for p in oracle.parameters():
-            p.grad = None
-        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
-            pred = oracle(*args)
-        loss = harness.l1_waypoint_loss(pred.float(), gt)
-        loss.backward()
-        return float(loss), {k: p.grad.detach().clone() for k, p in oracle.named_parameters() if p.grad is not None}
-
-    l32, g32 = run(False)
-    l16, g16 = run(True)
-    print("[CPU oracle, torch.autocast(bfloat16) vs fp32, batch %d] loss %.6f vs %.6f" % (Bo, l16, l32))
-    for st in range(4):
-        names = [k for k in g32 if FlatLayout.stage_of(k) == st]
-        a = torch.cat([g32[k].flatten().double() for k in names]); c = torch.cat([g16[k].flatten().double() for k in names])
-        print("   stage %d: cosine %.5f  rel err %.3e" % (st, float(torch.dot(a, c) / (a.norm() * c.norm())), float((a - c).norm() / a.norm())))
-
-
-if os.environ.get("ORACLE_YARDSTICK", "1") == "1":
-    oracle_yardstick()
+if __name__ == "__main__":
+    main()
