@@ -321,9 +321,11 @@ def main():
     ap.add_argument("--lane-format", default="10x5", choices=["10x5", "19x8"],
                     help="10x5 = the reference's lane nodes (parity format, default); 19x8 = north_star's perf-only pre-vectorised "
                          "polylines [B,64,19,8] (VectorNet with lane_channels=8; no reference checkpoint has this shape)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="f32 = the parity path (headline); bf16 = bf16 MFMA operands for the Linear / Winograd GEMMs with fp32 "
-                         "accumulation, activations and master weights (BASELINE configs[2]; reported as dtype bf16)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16-operands"],
+                    help="f32 = the parity path (headline).  bf16 = the bf16 training mode (BASELINE configs[2]): bf16 activations, "
+                         "saved tensors and weight shadows in HBM, bf16 MFMA with fp32 accumulation, fp32 statistics / master weights "
+                         "/ gradients / optimizer.  bf16-operands = round 2's mode: fp32 tensors in HBM, GEMM operands rounded to "
+                         "bf16 on their way into LDS")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-oracle-check", action="store_true", help="skip the loss_vs_oracle block (one CPU oracle forward)")
@@ -368,7 +370,8 @@ def main():
     from mmfn_amd.parallel import DataParallel
 
     torch.manual_seed(42)  # init_torch(): run_steps/utils.py:77-84
-    net = {"vec": MMFN, "img": MMFNImg, "rad": MMFNRad}[args.variant](GlobalConfig(gemm_dtype=args.dtype, lane_channels=8 if args.lane_format == "19x8" else 7), dev)
+    net = {"vec": MMFN, "img": MMFNImg, "rad": MMFNRad}[args.variant](GlobalConfig(gemm_dtype="bf16" if args.dtype == "bf16-operands" else "f32", act_dtype="bf16" if args.dtype == "bf16" else "f32",
+                                                                       lane_channels=8 if args.lane_format == "19x8" else 7), dev)
     net.train()
     B = args.batch
     inp, gt = synth_inputs(B, dev, seed=42 + rank, n_lidar=args.n_lidar, variant=args.variant, lane_format=args.lane_format)
@@ -540,7 +543,7 @@ def main():
     result = {
         "metric": "image-branch fwd+bwd samples/sec" if image_only else "train samples/sec (RGB+LiDAR+vec-map fusion)", "value": round(value, 2), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype != "f32" else "f32", "data": "synthetic",
         "config": {"workload": workload,
                    "global_batch": B * world, "parallelism": "dp%d" % world, "hipgraph": graph is not None,
                    "branch_streams": 1 if args.single_stream else eng.n_lanes},
@@ -602,12 +605,19 @@ def main():
                                                    "launches_per_step": r["launches_per_step"], "kernel_ms_per_step": r["kernel_ms_per_step"]}
             ach = fb / (msb * 1e-3) / 1e12 if msb > 0 else 0.0
             r.update({"achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
-                      "kernel": "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16; fp32 operands in HBM rounded to bf16 on the way into LDS, "
-                                "fp32 accumulate): Linear GEMMs and direct 3x3 convolutions fwd / data gradient",
+                      "kernel": ("gemm16_nt / gemm16_tn kernels (v_mfma_f32_32x32x16_bf16, bf16 operands in HBM staged by global_load_lds, fp32 "
+                                 "accumulate): Linear fwd / dX / dW and every trunk convolution fwd / data gradient / weight gradient"
+                                 if args.dtype == "bf16" else
+                                 "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16; fp32 operands in HBM rounded to bf16 on the way into LDS, "
+                                 "fp32 accumulate): Linear GEMMs and direct 3x3 convolutions fwd / data gradient"),
                       "launches_per_step": nb // steps_p, "kernel_ms_per_step": round(msb / steps_p, 3),
                       "algorithmic_gflop_per_step": round(fb / steps_p / 1e9, 1), "traffic": None, "traffic_source": None,
-                      "note": "operands are read as fp32 from HBM (4 B/element), so these GEMMs are HBM/LDS-bound long before the "
-                              "2.5 PFLOP/s bf16 MFMA peak; see DESIGN.md section 7"})
+                      "note": ("the step is HBM / launch-latency bound in this mode (SURVEY 8d): see hbm_roofline" if args.dtype == "bf16" else
+                               "operands are read as fp32 from HBM (4 B/element), so these GEMMs are HBM/LDS-bound long before the "
+                               "2.5 PFLOP/s bf16 MFMA peak; see DESIGN.md section 7")})
+            if args.dtype == "bf16":
+                r["mode"] = dict(dtype_detail="bf16 activations / saved tensors / weight shadows in HBM; fp32 accumulation, BatchNorm and "
+                                              "LayerNorm statistics, master weights, gradients, AdamW, loss head, VectorNet and the two 7x7 stems")
             for k in ("executed_gflop_per_step", "executed_tflops", "algorithmic_bytes_per_launch"):
                 r.pop(k, None)
         if not image_only and args.dtype == "f32" and not args.no_oracle_check:
