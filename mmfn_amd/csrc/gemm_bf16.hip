@@ -74,14 +74,29 @@ __device__ __forceinline__ void store8_bf16(void* p, const float* v) {
 // one logical chunk, i.e. 16 different slot positions of the 256-byte bank row.
 __device__ __forceinline__ int nt_swz(int r) { return (r >> 1) & 7; }
 
+// vmcnt(n) only (expcnt / lgkmcnt untouched): gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
+#define MMFN_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x70 | 0xF00)
+
+// NS LDS stages, tiles kt+1 .. kt+NS-2 in flight while tile kt is multiplied: the step's GEMMs are a few hundred tiles each
+// (1-2 blocks per CU), so it is the depth of the per-block operand stream, not occupancy, that hides the L2 / HBM latency.
+// One raw s_barrier per k-tile; the global_load_lds pieces are retired with COUNTED vmcnt waits (a __syncthreads() would drain
+// them all); the stage overwritten in iteration kt was last read in iteration kt-2, two barriers back.
+template <int FORM, int BM, int BN>
+struct NtCfg {
+  static constexpr int STAGE = (BM + BN) * 128;
+  static constexpr int NS = 4;
+  static constexpr int EPI = 4 * (BM / 64) * 32 * (BN / 64) * 32 * 4;
+  static constexpr int SMEM = NS * STAGE > EPI ? NS * STAGE : EPI;
+};
+
 template <int FORM, int BM, int BN>
 __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d, const int tiles_n, const int tap_shift) {
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 accumulator tiles per wave (2 x 2 waves)
   constexpr int PA = BM / 32, PB = BN / 32;      // 1 KB pieces (8 rows) per wave per stage
-  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int STAGE = NtCfg<FORM, BM, BN>::STAGE;
+  constexpr int NS = NtCfg<FORM, BM, BN>::NS, D = NS - 2;
   constexpr int EPI_LD = TN * 32;                // fp32 staging row of one wave tile; 16-byte chunks XOR-swizzled by (row >> 1) & 1
-  constexpr int SMEM = (2 * STAGE > 4 * TM * 32 * EPI_LD * 4) ? 2 * STAGE : 4 * TM * 32 * EPI_LD * 4;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -130,6 +145,7 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
   auto stage = [&](int kt, int buf) {
     unsigned char* As = smem + buf * STAGE;
     unsigned char* Bs = As + BM * 128;
+    const bool live = kt < nkt;   // past the end: the same number of (dummy) loads, so the counted waits stay constant
     int kh = 0, kw = 0, c0 = 0;
     if (FORM != 0) {   // wave-uniform tap of this k-tile (channels % 64 == 0: a k-tile never straddles a tap)
       const int tap = kt >> tap_shift;
@@ -141,14 +157,14 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
     for (int i = 0; i < PA; ++i) {
       const bf16_t* src;
       if (FORM == 0) {
-        src = pa[i] + (size_t)kt * BK;
+        src = live ? pa[i] + (size_t)kt * BK : zero;
       } else if (FORM == 1) {
         const int ih = ay[i] + kh, iw = ax[i] + kw;
-        const bool ok = (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+        const bool ok = live && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
         src = ok ? pa[i] + ((size_t)ih * d.W + iw) * d.Cin + c0 : zero;
       } else {
         const int th = ay[i] - kh, tw = ax[i] - kw;
-        bool ok = th >= 0 && tw >= 0;
+        bool ok = live && th >= 0 && tw >= 0;
         int oh = th, ow = tw;
         if (d.stride == 2) {
           ok = ok && !((th | tw) & 1);
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
       glds16(src, As + (wave + 4 * i) * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < PB; ++i) glds16(pb[i] + (size_t)kt * BK, Bs + (wave + 4 * i) * 1024);
+    for (int i = 0; i < PB; ++i) glds16(live ? pb[i] + (size_t)kt * BK : zero, Bs + (wave + 4 * i) * 1024);
   };
 
   f32x16 acc[TM][TN];
@@ -174,35 +190,42 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (nkt > 0) stage(0, 0);
-  __syncthreads();
-  int cur = 0;
+#pragma unroll
+  for (int s = 0; s < D; ++s) stage(s, s);
+  int cur = 0, nxt = D;
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+    stage(kt + D, nxt);
+    MMFN_WAIT_VMCNT((PA + PB) * D);     // this wave's pieces of tile kt have landed ...
+    __builtin_amdgcn_s_barrier();       // ... and everybody else's
     const unsigned char* As = smem + cur * STAGE;
     const unsigned char* Bs = As + BM * 128;
+    cur = cur + 1 == NS ? 0 : cur + 1;
+    nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    // all fragment reads of the k-tile first (the compiler then retires them with counted lgkmcnt waits under the MFMAs)
+    bf16x8 a[BK / 16][TM], b[BK / 16][TN];
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      bf16x8 a[TM], b[TN];
       const int c = ks * 2 + h;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int r = wm * TM * 32 + i * 32 + l31;
-        a[i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + ((c ^ nt_swz(r)) << 4));
+        a[ks][i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + ((c ^ nt_swz(r)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int r = wn * TN * 32 + j * 32 + l31;
-        b[j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + ((c ^ nt_swz(r)) << 4));
+        b[ks][j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + ((c ^ nt_swz(r)) << 4));
       }
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-    cur ^= 1;
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
   }
+  MMFN_WAIT_VMCNT(0);   // the trailing dummy pieces
+  __syncthreads();      // nobody still reads operands: the stages become the epilogue's staging area
 
   // ---- epilogue: accumulators -> LDS (fp32, one region per wave) -> 8 consecutive columns per lane
   float* ep = reinterpret_cast<float*>(smem) + wave * (TM * 32 * EPI_LD);
@@ -354,7 +377,8 @@ __global__ __launch_bounds__(NT) void gemm16_tn_kernel(const mmfn_gemm16_desc d,
   constexpr int RA = 1024 / (BM * 2), RB = 1024 / (BN * 2);   // contraction rows per 1 KB piece
   constexpr int PA = 64 / RA / 4, PB = 64 / RB / 4;           // pieces per wave per stage
   constexpr int STAGE = 64 * (BM + BN) * 2;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+  constexpr int NS = 4, D = NS - 2;   // stages / tiles in flight, as in the NT kernel
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -386,7 +410,7 @@ __global__ __launch_bounds__(NT) void gemm16_tn_kernel(const mmfn_gemm16_desc d,
       const int k = kt * 64 + kl;
       const int c = as ^ tn_swz<BM>(kl);            // logical column chunk this physical slot holds
       const int mcol = min(m0 + c * 8, d.M - 8);    // M % 8 == 0; columns beyond M are clamped (never stored)
-      const bf16_t* src = k < d.K ? A + (size_t)k * d.lda + mcol : zero;
+      const bf16_t* src = (k < d.K && kt < kt_end) ? A + (size_t)k * d.lda + mcol : zero;
       glds16(src, As + piece * 1024);
     }
 #pragma unroll
@@ -398,12 +422,12 @@ __global__ __launch_bounds__(NT) void gemm16_tn_kernel(const mmfn_gemm16_desc d,
       const bf16_t* src;
       if (FORM == 0) {
         const int ncol = min(n0 + c * 8, d.N - 8);
-        src = k < d.K ? Bp + (size_t)k * d.ldb + ncol : zero;
+        src = (k < d.K && kt < kt_end) ? Bp + (size_t)k * d.ldb + ncol : zero;
       } else {   // k = output pixel (b, oh, ow); the row is x[b, oh*s - p + kh, ow*s - p + kw, bci + c*8 ...]
         const int b = k >> log2_ohw, rem = k & ((1 << log2_ohw) - 1);
         const int oh = rem >> log2_ow, ow = rem & ((1 << log2_ow) - 1);
         const int ih = oh * d.stride - d.pad + bkh, iw = ow * d.stride - d.pad + bkw;
-        const bool ok = k < d.K && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
+        const bool ok = k < d.K && kt < kt_end && (unsigned)ih < (unsigned)d.H && (unsigned)iw < (unsigned)d.W;
         src = ok ? Bp + ((size_t)(b * d.H + ih) * d.W + iw) * d.Cin + bci + c * 8 : zero;
       }
       glds16(src, Bs + piece * 1024);
@@ -418,28 +442,33 @@ __global__ __launch_bounds__(NT) void gemm16_tn_kernel(const mmfn_gemm16_desc d,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (kt_begin < kt_end) stage(kt_begin, 0);
-  __syncthreads();
-  int cur = 0;
+#pragma unroll
+  for (int s = 0; s < D; ++s) stage(kt_begin + s, s);
+  int cur = 0, nxt = D;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    if (kt + 1 < kt_end) stage(kt + 1, cur ^ 1);
+    stage(kt + D, nxt);
+    MMFN_WAIT_VMCNT((PA + PB) * D);
+    __builtin_amdgcn_s_barrier();
     const unsigned char* As = smem + cur * STAGE;
     const unsigned char* Bs = As + 64 * BM * 2;
+    cur = cur + 1 == NS ? 0 : cur + 1;
+    nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    bf16x8 a[4][TM], b[4][TN];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = tn_fragment<BM>(As, wm * TM * 32 + i * 32, ks * 16, lane);
+      for (int i = 0; i < TM; ++i) a[ks][i] = tn_fragment<BM>(As, wm * TM * 32 + i * 32, ks * 16, lane);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = tn_fragment<BN>(Bs, wn * TN * 32 + j * 32, ks * 16, lane);
+      for (int j = 0; j < TN; ++j) b[ks][j] = tn_fragment<BN>(Bs, wn * TN * 32 + j * 32, ks * 16, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-    cur ^= 1;
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
   }
+  MMFN_WAIT_VMCNT(0);
   // fp32 output (a gradient) or a split slab; 32 consecutive columns per store instruction
   const bool to_slab = gridDim.y > 1;
   float* out = to_slab ? d.workspace + (size_t)blockIdx.y * d.M * d.N : reinterpret_cast<float*>(d.C);
@@ -534,12 +563,36 @@ extern "C" int mmfn_gemm_bf16_stats_rows(const mmfn_gemm16_desc* d) {
   return 2 * ceil_div(d->M, bm);
 }
 
-#define LAUNCH_NT(F, BM_, BN_)                                                                                       \
-  hipLaunchKernelGGL((gemm16_nt_kernel<F, BM_, BN_>), dim3(ceil_div(d.M, BM_) * ceil_div(d.N, BN_)), dim3(NT), 0, s, d, \
-                     ceil_div(d.N, BN_), tap_shift)
-#define LAUNCH_TN(F, BM_, BN_)                                                                                          \
-  hipLaunchKernelGGL((gemm16_tn_kernel<F, BM_, BN_>), dim3(ceil_div(d.M, BM_) * ceil_div(d.N, BN_), sk), dim3(NT), 0, s, d, \
-                     ceil_div(d.N, BN_), per, l2ow, l2ohw)
+template <int F, int BM_, int BN_>
+int launch_nt(const mmfn_gemm16_desc& d, int tap_shift, hipStream_t s) {
+  constexpr int smem = NtCfg<F, BM_, BN_>::SMEM;
+  static bool ready = false;   // more than 64 KB of dynamic LDS needs the attribute, once per kernel
+  if (!ready) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_nt_kernel<F, BM_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            smem) != hipSuccess)
+      return MMFN_EINVAL;
+    ready = true;
+  }
+  hipLaunchKernelGGL((gemm16_nt_kernel<F, BM_, BN_>), dim3(ceil_div(d.M, BM_) * ceil_div(d.N, BN_)), dim3(NT), smem, s, d,
+                     ceil_div(d.N, BN_), tap_shift);
+  return 0;
+}
+#define LAUNCH_NT(F, BM_, BN_) rc_nt = launch_nt<F, BM_, BN_>(d, tap_shift, s)
+template <int F, int BM_, int BN_>
+int launch_tn(const mmfn_gemm16_desc& d, int sk, int per, int l2ow, int l2ohw, hipStream_t s) {
+  constexpr int smem = 4 * 64 * (BM_ + BN_) * 2;
+  static bool ready = false;
+  if (!ready) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_tn_kernel<F, BM_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            smem) != hipSuccess)
+      return MMFN_EINVAL;
+    ready = true;
+  }
+  hipLaunchKernelGGL((gemm16_tn_kernel<F, BM_, BN_>), dim3(ceil_div(d.M, BM_) * ceil_div(d.N, BN_), sk), dim3(NT), smem, s, d,
+                     ceil_div(d.N, BN_), per, l2ow, l2ohw);
+  return 0;
+}
+#define LAUNCH_TN(F, BM_, BN_) rc_tn = launch_tn<F, BM_, BN_>(d, sk, per, l2ow, l2ohw, s)
 
 extern "C" int mmfn_gemm_bf16(const mmfn_gemm16_desc* dp, void* stream) {
   if (!dp) return MMFN_EINVAL;
@@ -561,6 +614,7 @@ extern "C" int mmfn_gemm_bf16(const mmfn_gemm16_desc* dp, void* stream) {
     }
     if ((d.flags & MMFN_EPI_RESIDUAL) && (!d.res || d.ldr % 8)) return MMFN_EINVAL;
     if ((d.flags & MMFN_EPI_MASK_AUX) && (!d.aux || d.ldaux % 8)) return MMFN_EINVAL;
+    int rc_nt = 0;
 #define NT_FORMS(BM_, BN_)                          \
   if (d.form == 0) LAUNCH_NT(0, BM_, BN_);          \
   else if (d.form == 1) LAUNCH_NT(1, BM_, BN_);     \
@@ -569,6 +623,7 @@ extern "C" int mmfn_gemm_bf16(const mmfn_gemm16_desc* dp, void* stream) {
     else if (bm == 128) { NT_FORMS(128, 64); }
     else if (bn == 128) { NT_FORMS(64, 128); }
     else { NT_FORMS(64, 64); }
+    if (rc_nt) return rc_nt;
     MMFN_LAUNCH_CHECK();
     return 0;
   }
@@ -586,6 +641,7 @@ extern "C" int mmfn_gemm_bf16(const mmfn_gemm16_desc* dp, void* stream) {
   int sk, per;
   tn_config(d, bm, bn, &sk, &per);
   if (sk > 1 && !d.workspace) return MMFN_EINVAL;
+  int rc_tn = 0;
 #define TN_FORMS(BM_, BN_)                      \
   if (d.form == 3) LAUNCH_TN(0, BM_, BN_);      \
   else LAUNCH_TN(1, BM_, BN_)
@@ -593,6 +649,7 @@ extern "C" int mmfn_gemm_bf16(const mmfn_gemm16_desc* dp, void* stream) {
   else if (bm == 128) { TN_FORMS(128, 64); }
   else if (bn == 128) { TN_FORMS(64, 128); }
   else { TN_FORMS(64, 64); }
+  if (rc_tn) return rc_tn;
   MMFN_LAUNCH_CHECK();
   if (sk > 1) {
     if ((size_t)d.M * d.N % 4 || d.ldc % 4) return MMFN_EINVAL;
