@@ -167,7 +167,7 @@ typedef struct mmfn_gemm16_desc {
   int32_t tile;        /* 0 auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128 */
   uint32_t rng_stream;
   float drop_p;
-  int32_t reserved;
+  int32_t stages;      /* LDS stages of the operand pipeline: 0 auto, 2 = double buffer, 3 / 4 = 1 / 2 k-tiles in flight beyond it */
 } mmfn_gemm16_desc;
 
 int mmfn_sizeof_gemm16_desc(void);

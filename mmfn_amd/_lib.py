@@ -48,7 +48,7 @@ class Gemm16Desc(ctypes.Structure):
         ("H", _i32), ("W", _i32), ("Cin", _i32), ("OH", _i32), ("OW", _i32), ("Cout", _i32),
         ("KH", _i32), ("KW", _i32), ("stride", _i32), ("pad", _i32),
         ("flags", _i32), ("splitk", _i32), ("tile", _i32),
-        ("rng_stream", ctypes.c_uint32), ("drop_p", _f32), ("reserved", _i32),
+        ("rng_stream", ctypes.c_uint32), ("drop_p", _f32), ("stages", _i32),
     ]
 
 

@@ -81,20 +81,21 @@ __device__ __forceinline__ int nt_swz(int r) { return (r >> 1) & 7; }
 // (1-2 blocks per CU), so it is the depth of the per-block operand stream, not occupancy, that hides the L2 / HBM latency.
 // One raw s_barrier per k-tile; the global_load_lds pieces are retired with COUNTED vmcnt waits (a __syncthreads() would drain
 // them all); the stage overwritten in iteration kt was last read in iteration kt-2, two barriers back.
-template <int FORM, int BM, int BN>
+// NS = 2 is the plain double buffer (tile kt+1 in flight, drained before the barrier that ends iteration kt): half the LDS, so
+// twice the resident blocks - the better trade when the grid is many blocks per CU.  The host picks (desc.stages, tuning table).
+template <int BM, int BN, int NS>
 struct NtCfg {
   static constexpr int STAGE = (BM + BN) * 128;
-  static constexpr int NS = 4;
   static constexpr int EPI = 4 * (BM / 64) * 32 * (BN / 64) * 32 * 4;
   static constexpr int SMEM = NS * STAGE > EPI ? NS * STAGE : EPI;
 };
 
-template <int FORM, int BM, int BN>
+template <int FORM, int BM, int BN, int NS>
 __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d, const int tiles_n, const int tap_shift) {
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 accumulator tiles per wave (2 x 2 waves)
   constexpr int PA = BM / 32, PB = BN / 32;      // 1 KB pieces (8 rows) per wave per stage
-  constexpr int STAGE = NtCfg<FORM, BM, BN>::STAGE;
-  constexpr int NS = NtCfg<FORM, BM, BN>::NS, D = NS - 2;
+  constexpr int STAGE = NtCfg<BM, BN, NS>::STAGE;
+  constexpr int D = NS == 2 ? 1 : NS - 2;
   constexpr int EPI_LD = TN * 32;                // fp32 staging row of one wave tile; 16-byte chunks XOR-swizzled by (row >> 1) & 1
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
@@ -193,10 +194,16 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
 #pragma unroll
   for (int s = 0; s < D; ++s) stage(s, s);
   int cur = 0, nxt = D;
+  if (NS == 2) {
+    MMFN_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+  }
   for (int kt = 0; kt < nkt; ++kt) {
     stage(kt + D, nxt);
-    MMFN_WAIT_VMCNT((PA + PB) * D);     // this wave's pieces of tile kt have landed ...
-    __builtin_amdgcn_s_barrier();       // ... and everybody else's
+    if (NS > 2) {
+      MMFN_WAIT_VMCNT((PA + PB) * D);     // this wave's pieces of tile kt have landed ...
+      __builtin_amdgcn_s_barrier();       // ... and everybody else's
+    }
     const unsigned char* As = smem + cur * STAGE;
     const unsigned char* Bs = As + BM * 128;
     cur = cur + 1 == NS ? 0 : cur + 1;
@@ -223,6 +230,10 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+    if (NS == 2) {   // tile kt+1 landed, and nobody still reads the stage the next iteration overwrites
+      MMFN_WAIT_VMCNT(0);
+      __builtin_amdgcn_s_barrier();
+    }
   }
   MMFN_WAIT_VMCNT(0);   // the trailing dummy pieces
   __syncthreads();      // nobody still reads operands: the stages become the epilogue's staging area
@@ -370,14 +381,14 @@ __device__ __forceinline__ bf16x8 tn_fragment(const unsigned char* tile, int col
   return out;
 }
 
-template <int FORM, int BM, int BN>
+template <int FORM, int BM, int BN, int NS>
 __global__ __launch_bounds__(NT) void gemm16_tn_kernel(const mmfn_gemm16_desc d, const int tiles_n, const int kt_per_split,
                                                        const int log2_ow, const int log2_ohw) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int RA = 1024 / (BM * 2), RB = 1024 / (BN * 2);   // contraction rows per 1 KB piece
   constexpr int PA = 64 / RA / 4, PB = 64 / RB / 4;           // pieces per wave per stage
   constexpr int STAGE = 64 * (BM + BN) * 2;
-  constexpr int NS = 4, D = NS - 2;   // stages / tiles in flight, as in the NT kernel
+  constexpr int D = NS == 2 ? 1 : NS - 2;   // stages / tiles in flight, as in the NT kernel
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
@@ -445,10 +456,16 @@ __global__ __launch_bounds__(NT) void gemm16_tn_kernel(const mmfn_gemm16_desc d,
 #pragma unroll
   for (int s = 0; s < D; ++s) stage(kt_begin + s, s);
   int cur = 0, nxt = D;
+  if (NS == 2) {
+    MMFN_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+  }
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     stage(kt + D, nxt);
-    MMFN_WAIT_VMCNT((PA + PB) * D);
-    __builtin_amdgcn_s_barrier();
+    if (NS > 2) {
+      MMFN_WAIT_VMCNT((PA + PB) * D);
+      __builtin_amdgcn_s_barrier();
+    }
     const unsigned char* As = smem + cur * STAGE;
     const unsigned char* Bs = As + 64 * BM * 2;
     cur = cur + 1 == NS ? 0 : cur + 1;
@@ -467,6 +484,10 @@ __global__ __launch_bounds__(NT) void gemm16_tn_kernel(const mmfn_gemm16_desc d,
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+    if (NS == 2) {
+      MMFN_WAIT_VMCNT(0);
+      __builtin_amdgcn_s_barrier();
+    }
   }
   MMFN_WAIT_VMCNT(0);
   // fp32 output (a gradient) or a split slab; 32 consecutive columns per store instruction
@@ -563,36 +584,48 @@ extern "C" int mmfn_gemm_bf16_stats_rows(const mmfn_gemm16_desc* d) {
   return 2 * ceil_div(d->M, bm);
 }
 
-template <int F, int BM_, int BN_>
-int launch_nt(const mmfn_gemm16_desc& d, int tap_shift, hipStream_t s) {
-  constexpr int smem = NtCfg<F, BM_, BN_>::SMEM;
+template <int F, int BM_, int BN_, int NS_>
+int launch_nt_ns(const mmfn_gemm16_desc& d, int tap_shift, hipStream_t s) {
+  constexpr int smem = NtCfg<BM_, BN_, NS_>::SMEM;
   static bool ready = false;   // more than 64 KB of dynamic LDS needs the attribute, once per kernel
   if (!ready) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_nt_kernel<F, BM_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_nt_kernel<F, BM_, BN_, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             smem) != hipSuccess)
       return MMFN_EINVAL;
     ready = true;
   }
-  hipLaunchKernelGGL((gemm16_nt_kernel<F, BM_, BN_>), dim3(ceil_div(d.M, BM_) * ceil_div(d.N, BN_)), dim3(NT), smem, s, d,
+  hipLaunchKernelGGL((gemm16_nt_kernel<F, BM_, BN_, NS_>), dim3(ceil_div(d.M, BM_) * ceil_div(d.N, BN_)), dim3(NT), smem, s, d,
                      ceil_div(d.N, BN_), tap_shift);
   return 0;
 }
-#define LAUNCH_NT(F, BM_, BN_) rc_nt = launch_nt<F, BM_, BN_>(d, tap_shift, s)
 template <int F, int BM_, int BN_>
-int launch_tn(const mmfn_gemm16_desc& d, int sk, int per, int l2ow, int l2ohw, hipStream_t s) {
-  constexpr int smem = 4 * 64 * (BM_ + BN_) * 2;
+int launch_nt(const mmfn_gemm16_desc& d, int tap_shift, int stages, hipStream_t s) {
+  if (stages == 2) return launch_nt_ns<F, BM_, BN_, 2>(d, tap_shift, s);
+  if (stages == 3) return launch_nt_ns<F, BM_, BN_, 3>(d, tap_shift, s);
+  return launch_nt_ns<F, BM_, BN_, 4>(d, tap_shift, s);
+}
+#define LAUNCH_NT(F, BM_, BN_) rc_nt = launch_nt<F, BM_, BN_>(d, tap_shift, stages, s)
+template <int F, int BM_, int BN_, int NS_>
+int launch_tn_ns(const mmfn_gemm16_desc& d, int sk, int per, int l2ow, int l2ohw, hipStream_t s) {
+  constexpr int smem = NS_ * 64 * (BM_ + BN_) * 2;
   static bool ready = false;
   if (!ready) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_tn_kernel<F, BM_, BN_>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm16_tn_kernel<F, BM_, BN_, NS_>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             smem) != hipSuccess)
       return MMFN_EINVAL;
     ready = true;
   }
-  hipLaunchKernelGGL((gemm16_tn_kernel<F, BM_, BN_>), dim3(ceil_div(d.M, BM_) * ceil_div(d.N, BN_), sk), dim3(NT), smem, s, d,
+  hipLaunchKernelGGL((gemm16_tn_kernel<F, BM_, BN_, NS_>), dim3(ceil_div(d.M, BM_) * ceil_div(d.N, BN_), sk), dim3(NT), smem, s, d,
                      ceil_div(d.N, BN_), per, l2ow, l2ohw);
   return 0;
 }
-#define LAUNCH_TN(F, BM_, BN_) rc_tn = launch_tn<F, BM_, BN_>(d, sk, per, l2ow, l2ohw, s)
+template <int F, int BM_, int BN_>
+int launch_tn(const mmfn_gemm16_desc& d, int sk, int per, int l2ow, int l2ohw, int stages, hipStream_t s) {
+  if (stages == 2) return launch_tn_ns<F, BM_, BN_, 2>(d, sk, per, l2ow, l2ohw, s);
+  if (stages == 3) return launch_tn_ns<F, BM_, BN_, 3>(d, sk, per, l2ow, l2ohw, s);
+  return launch_tn_ns<F, BM_, BN_, 4>(d, sk, per, l2ow, l2ohw, s);
+}
+#define LAUNCH_TN(F, BM_, BN_) rc_tn = launch_tn<F, BM_, BN_>(d, sk, per, l2ow, l2ohw, stages, s)
 
 extern "C" int mmfn_gemm_bf16(const mmfn_gemm16_desc* dp, void* stream) {
   if (!dp) return MMFN_EINVAL;
@@ -601,6 +634,13 @@ extern "C" int mmfn_gemm_bf16(const mmfn_gemm16_desc* dp, void* stream) {
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || !d.A || !d.B || !d.C) return MMFN_EINVAL;
   int bm, bn;
   pick_tile(d, &bm, &bn);
+  // LDS stages (desc.stages: 0 = auto): deep operand streams for grids of a few blocks per CU, the double buffer (half the
+  // LDS, twice the resident blocks) for grids of many; the weight-gradient forms split the contraction into many blocks anyway
+  int stages = d.stages;
+  if (stages < 2 || stages > 4) {
+    const int blocks = ceil_div(d.M, bm) * ceil_div(d.N, bn);
+    stages = d.form <= 2 ? (blocks >= 1536 ? 2 : 4) : 2;
+  }
   if (d.form <= 2) {
     if (d.K % BK || d.N % 8 || d.ldb % 8 || d.ldc % 8) return MMFN_EINVAL;
     int tap_shift = 0;

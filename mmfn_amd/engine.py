@@ -165,10 +165,9 @@ class ConvBN(object):
             else:
                 ops.conv2d_fwd(x, self.w, self.stride, self.pad, out=co)
         elif ctx.training:
-            K = self.w.shape[1] * self.w.shape[2] * self.w.shape[3]
-            rows = ops16.stats_rows(M, self.cout, K)
-            ws = ops.norm_workspace(x.device, rows * 2 * self.cout * 8)
+            ws = ops.norm_workspace(x.device, 2 * ((M + 63) // 64) * 2 * self.cout * 8)   # sized for the smallest tile
             ops16.conv2d_fwd(x, self.w16, self.stride, self.pad, co, stats=ws)
+            rows = ops16.conv_stats_rows(x.shape, self.w.shape, self.stride, self.pad)   # AFTER the launch: autotune may add the entry
             ops.bn_finalize_stats(ws, rows, M, self.cout, mean, rstd, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                                   bn.eps, bn.momentum)
         else:
