@@ -408,6 +408,12 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+#ifndef MMFN_F32_STAGES
+#define MMFN_F32_STAGES 3
+#endif
+// vmcnt(n) only (expcnt / lgkmcnt untouched): gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
+#define MMFN_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x70 | 0xF00)
+
 template <int AM, int BMODE, int BM, int BN>
 __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, const int tiles_n,
                                                            const int log2_ow, const int log2_ohw) {
@@ -433,7 +439,14 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
   constexpr int LDK = BK;
   constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;
   constexpr int UA = BM * BK / 4 / NT, UB = BN * BK / 4 / NT;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (A_ELEMS + B_ELEMS)];
+  // LDS stages of the operand pipeline (global_load_lds path).  NS >= 3: tiles kt+1 .. kt+NS-2 are in flight while tile kt is
+  // multiplied, retired with COUNTED vmcnt waits, one raw s_barrier per k-tile - the step's GEMMs are a few hundred 64x64
+  // tiles each (1-3 blocks per CU) with 36-288 k-tiles, so it is the depth of each block's operand stream, not occupancy,
+  // that hides the L2 / HBM latency (wait_inst 0.6 of the wave cycles on the double-buffered form, profiles/r02d_pmc.txt).
+  // The stage overwritten in iteration kt was last read in iteration kt-2, two barriers back.  NS = 2: the double buffer.
+  constexpr int NS = USE_GLDS ? MMFN_F32_STAGES : 2;
+  constexpr int D = NS == 2 ? 1 : NS - 2;
+  __shared__ __attribute__((aligned(16))) float smem[NS * (A_ELEMS + B_ELEMS)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -590,10 +603,11 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
   // is applied to the SOURCE address); otherwise through registers (issue now, ds_write after the MFMAs).
   auto stage_issue = [&](int kt, float* dst) {
     if (USE_GLDS) {
+      const bool live = kt < kt_end;   // past the end: the same number of (dummy) pieces, so the counted waits stay constant
 #pragma unroll
-      for (int i = 0; i < UA; ++i) glds16(src_a(i, kt), dst + (i * NT + wave * 64) * 4);
+      for (int i = 0; i < UA; ++i) glds16(live ? src_a(i, kt) : zero, dst + (i * NT + wave * 64) * 4);
 #pragma unroll
-      for (int i = 0; i < UB; ++i) glds16(src_b(i, kt), dst + A_ELEMS + (i * NT + wave * 64) * 4);
+      for (int i = 0; i < UB; ++i) glds16(live ? src_b(i, kt) : zero, dst + A_ELEMS + (i * NT + wave * 64) * 4);
     } else {
 #pragma unroll
       for (int i = 0; i < UA; ++i) ra[i] = ld4(src_a(i, kt));
@@ -610,17 +624,29 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
       for (int i = 0; i < UB; ++i) store_b(dst + A_ELEMS, i, rb[i]);
     }
   };
-  if (kt_begin < kt_end) {
-    stage_issue(kt_begin, smem);
-    stage_commit(smem);
+  constexpr int STG = A_ELEMS + B_ELEMS;
+  if (NS > 2) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) stage_issue(kt_begin + s, smem + s * STG);
+  } else {
+    if (kt_begin < kt_end) {
+      stage_issue(kt_begin, smem);
+      stage_commit(smem);
+    }
+    __syncthreads();
   }
-  __syncthreads();
 
-  int cur = 0;
+  int cur = 0, nxt = D;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const bool more = (kt + 1 < kt_end);
-    if (more) stage_issue(kt + 1, smem + (cur ^ 1) * (A_ELEMS + B_ELEMS));
-    const float* As = smem + cur * (A_ELEMS + B_ELEMS);
+    if (NS > 2) {
+      stage_issue(kt + D, smem + nxt * STG);
+      MMFN_WAIT_VMCNT((UA + UB) * D);   // this wave's pieces of tile kt have landed ...
+      __builtin_amdgcn_s_barrier();     // ... and everybody else's
+    } else if (more) {
+      stage_issue(kt + 1, smem + (cur ^ 1) * STG);
+    }
+    const float* As = smem + cur * STG;
     const float* Bs = As + A_ELEMS;
 #pragma unroll
     for (int c = 0; c < BK / 8; ++c) {
@@ -655,10 +681,16 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
           for (int q = 0; q < TN; ++q)
             acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[q][j], acc[i][q], 0, 0, 0);
     }
-    if (more) stage_commit(smem + (cur ^ 1) * (A_ELEMS + B_ELEMS));
-    __syncthreads();
-    cur ^= 1;
+    if (NS > 2) {
+      cur = cur + 1 == NS ? 0 : cur + 1;
+      nxt = nxt + 1 == NS ? 0 : nxt + 1;
+    } else {
+      if (more) stage_commit(smem + (cur ^ 1) * STG);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
+  if (NS > 2) MMFN_WAIT_VMCNT(0);   // the trailing dummy pieces must not land in LDS after the block has gone
 
   uint64_t key = 0;
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);

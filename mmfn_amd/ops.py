@@ -63,6 +63,10 @@ class lane(object):
         _lane = self.prev
 
 
+def current_lane():
+    return _lane
+
+
 class GemmProfiler(object):
     """Brackets every GEMM / convolution of the step with HIP events on the launch stream and tallies
       * its ALGORITHMIC FLOPs: what the operation is (2*M*N*K of the matmul; output pixels x taps x Cin x Cout of the
