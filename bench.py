@@ -91,7 +91,6 @@ class ImageBranchOnly(object):
         for li in range(4, 0, -1):
             g = eng.img.layer_bwd(ctx, li, g)
         eng.img.stem_bwd(ctx, g)
-        ctx.wgrad_join()   # (bf16 mode: the weight gradients run on a side stream)
         return pooled
 
 

@@ -114,35 +114,6 @@ class Ctx(object):
         with torch.cuda.stream(self.side), ops.lane(1):
             fn()
 
-    # ---- bf16 mode: convolution weight gradients beside the data-gradient chain
-    def wgrad_fork(self, fn):
-        """Run fn (a convolution's weight gradient + split combine: it only feeds the optimizer) on the weight-gradient stream
-        of the CURRENT branch lane, ordered after everything enqueued so far; wgrad_join() makes the lane wait for it.  The bf16
-        kernels are small (a few hundred 64x64 tiles, 1-2 blocks per CU), so the data gradient of the same layer - the only
-        thing the dependent chain needs - runs beside it instead of behind it."""
-        eng = self.engine
-        if eng is None or not eng.multi_stream or not WGRAD_STREAMS or self.recorder() is not None:
-            return fn()
-        li = ops.current_lane()
-        st = eng.wgrad_streams[li]
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        st.wait_event(ev)
-        with torch.cuda.stream(st), ops.lane(4 + li):
-            fn()
-        eng.wgrad_pending[li] = True
-
-    def wgrad_join(self):
-        eng = self.engine
-        if eng is None:
-            return
-        li = ops.current_lane()
-        if eng.wgrad_pending.get(li):
-            ev = torch.cuda.Event()
-            ev.record(eng.wgrad_streams[li])
-            torch.cuda.current_stream().wait_event(ev)
-            eng.wgrad_pending[li] = False
-
     def rejoin(self):
         """Current stream waits for all offloaded work (before its input buffers are reused)."""
         if self.side is None:
@@ -157,7 +128,6 @@ class Ctx(object):
 
 # ----------------------------------------------------------------------------- conv + BN
 FUSE_BN_BWD_APPLY = os.environ.get("MMFN_FUSE_BN_BWD", "1") == "1"   # A/B switch, see ConvBN.bwd
-WGRAD_STREAMS = os.environ.get("MMFN_WGRAD_STREAMS", "1") == "1"      # A/B switch, see Ctx.wgrad_fork (bf16 mode)
 
 
 class ConvBN(object):
@@ -221,7 +191,7 @@ class ConvBN(object):
         if x.dtype == torch.float32:   # stem: fp32 weight gradient, no data gradient
             ops.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, out=self.gw)
             return None
-        ctx.wgrad_fork(lambda: ops16.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, self.gw))
+        ops16.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, self.gw)
         if not need_dx:
             return None
         dx = ctx.bufs.get(self.name + ".dx", x.shape, ctx.adt)
@@ -1044,8 +1014,6 @@ class Engine(object):
         # kernels of the deep stages (M = 2048..8192 rows at B = 32) overlap each other's tails and launch
         # gaps; captured into the hipGraph this becomes a fork/join DAG.
         self.side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-        self.wgrad_streams = [torch.cuda.Stream(device=dev) for _ in range(3)]   # per branch lane (Ctx.wgrad_fork, bf16 mode)
-        self.wgrad_pending = {}
         self.multi_stream = True
         self._recorder = None   # mmfn_amd.graphs.Recorder while a lane-graph capture is running
         self.folded = {}        # ConvBN name -> (BatchNorm-folded filter, shift), see fold_batchnorm()
@@ -1340,8 +1308,7 @@ class Engine(object):
             def stage(m):
                 d = ops.pool_bcast_add(G[m], gin, bufs.get("dF%d.%d" % (s, m), G[m].shape, G[m].dtype), m)
                 g = trunks[m].layer_bwd(ctx, s + 1, d)
-                ctx.wgrad_join()
-                if in_lane_ok:
+                    if in_lane_ok:
                     self._ready(on_ready, st, names[m])
                 if LANE_TAIL_ADJOINT:
                     # the adjoint of the next scale's upsample-add for this branch (its own 64 token rows of gtok) at the tail of
@@ -1359,14 +1326,12 @@ class Engine(object):
         def img_tail():
             d = ops.pool_bcast_add(G[0], gin, bufs.get("dF0.0", G[0].shape, G[0].dtype), 0)
             self.img.stem_bwd(ctx, self.img.layer_bwd(ctx, 1, d))
-            ctx.wgrad_join()
             if in_lane_ok:
                 self._ready(on_ready, st, "img")
 
         def lid_tail():
             d = ops.pool_bcast_add(G[1], gin, bufs.get("dF0.1", G[1].shape, G[1].dtype), 1)
             self.lid.stem_bwd(ctx, self.lid.layer_bwd(ctx, 1, d))
-            ctx.wgrad_join()
             if in_lane_ok:
                 self._ready(on_ready, st, "lid")
 
@@ -1376,7 +1341,6 @@ class Engine(object):
                 self.map.stem_bwd(ctx, self.map.layer_bwd(ctx, 1, d))
             else:
                 self.vec.bwd(ctx, d)
-            ctx.wgrad_join()
             if in_lane_ok:
                 self._ready(on_ready, st, "map" if self.variant == "img" else "vec")
 

@@ -89,8 +89,7 @@ class Recorder(object):
             # joined yet when the exception struck: join them first - ending a capture with unjoined forks fails and leaves
             # those streams in capture mode
             cur = torch.cuda.current_stream()
-            for st in list(getattr(self.engine, "side", [])) + list(getattr(self.engine, "wgrad_streams", [])) + \
-                    [s for s in self.extra_streams if s is not None]:
+            for st in list(getattr(self.engine, "side", [])) + [s for s in self.extra_streams if s is not None]:
                 try:
                     with torch.cuda.stream(st):
                         forked = torch.cuda.is_current_stream_capturing()
