@@ -1308,7 +1308,7 @@ class Engine(object):
             def stage(m):
                 d = ops.pool_bcast_add(G[m], gin, bufs.get("dF%d.%d" % (s, m), G[m].shape, G[m].dtype), m)
                 g = trunks[m].layer_bwd(ctx, s + 1, d)
-                    if in_lane_ok:
+                if in_lane_ok:
                     self._ready(on_ready, st, names[m])
                 if LANE_TAIL_ADJOINT:
                     # the adjoint of the next scale's upsample-add for this branch (its own 64 token rows of gtok) at the tail of
