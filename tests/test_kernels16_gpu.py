@@ -1,0 +1,193 @@
+"""The *_bf16 entry points (bf16 activations in HBM) against their fp32 twins: the arithmetic is the same fp32 code (the kernels
+are templates on the element type), so on bf16-exact inputs a bf16 output must be EXACTLY the round-to-nearest-even bf16 of the
+fp32 kernel's output, and every fp32 output (statistics, gradients of parameters, lse) must be bit-identical."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BF = torch.bfloat16
+
+
+def _r(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV).to(BF)
+
+
+def _same(a16, a32):
+    assert a16.dtype == BF
+    assert torch.equal(a16, a32.to(BF)), float((a16.float() - a32).abs().max())
+
+
+def test_batchnorm_forward_backward():
+    from mmfn_amd import ops
+    M, C = 4096, 128
+    x, res, g = _r(M, C, seed=1, scale=2.0), _r(M, C, seed=2), _r(M, C, seed=3)
+    w, b = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    outs = []
+    for dt in (torch.float32, BF):
+        xx, rr, gg = x.to(dt), res.to(dt), g.to(dt)
+        mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        rm, rv, nbt = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        ops.bn_train_stats(xx, mean, rstd, rm, rv, nbt)
+        y = torch.empty(M, C, dtype=dt, device=DEV)
+        ops.bn_apply(xx, y, mean, rstd, w, b, True, res=rr)
+        dx, ge = torch.empty(M, C, dtype=dt, device=DEV), torch.empty(M, C, dtype=dt, device=DEV)
+        dw, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        ops.bn_bwd(gg, y, xx, mean, rstd, w, dx, dw, db, ge_out=ge)
+        outs.append((mean, rstd, rm, rv, y, dx, ge, dw, db))
+    f, h = outs
+    for i in (0, 1, 2, 3):
+        assert torch.equal(f[i], h[i])
+    _same(h[4], f[4])
+    # the backward's mask uses the STORED y: identical here because relu output rounds to zero only where it is zero
+    _same(h[6], f[6])
+    _same(h[5], f[5])
+    assert torch.equal(f[7], h[7]) and torch.equal(f[8], h[8])
+    # stem form: fp32 convolution output, bf16 activations
+    xx = x.float() * 1.0001   # not bf16-exact
+    mean, rstd = f[0], f[1]
+    y32, y16 = torch.empty(M, C, device=DEV), torch.empty(M, C, dtype=BF, device=DEV)
+    ops.bn_apply(xx, y32, mean, rstd, w, b, True)
+    ops.bn_apply(xx, y16, mean, rstd, w, b, True)
+    _same(y16, y32)
+    dx32, dx_mixed = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
+    dw, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    ops.bn_bwd(g.float(), y16.float(), xx, mean, rstd, w, dx32, dw, db)
+    ops.bn_bwd(g, y16, xx, mean, rstd, w, dx_mixed, dw, db)
+    assert torch.equal(dx32, dx_mixed)
+
+
+@pytest.mark.parametrize("C", [64, 128, 256, 512])
+def test_layernorm_forward_backward(C):
+    from mmfn_amd import ops
+    M = 1536
+    x, g, dres = _r(M, C, seed=1), _r(M, C, seed=2), _r(M, C, seed=3)
+    w, b = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    rng = torch.tensor([77, 3], dtype=torch.int64, device=DEV)
+    res = []
+    for dt in (torch.float32, BF):
+        xx = x.to(dt)
+        y, mean, rstd = torch.empty(M, C, dtype=dt, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        ops.layernorm_fwd(xx, w, b, y, mean, rstd, ops.ACT_RELU)
+        dx, dxd = torch.empty(M, C, dtype=dt, device=DEV), torch.empty(M, C, dtype=dt, device=DEV)
+        dw, db, cs = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        ops.layernorm_bwd(g.to(dt), xx, w, b, mean, rstd, dx, dw, db, ops.ACT_RELU, dres=dres.to(dt), dx_dropped=dxd, drop_p=0.1,
+                          rng_state=rng, rng_stream=5, dx_colsum=cs)
+        res.append((mean, rstd, y, dx, dxd, dw, db, cs))
+    f, h = res
+    assert torch.equal(f[0], h[0]) and torch.equal(f[1], h[1])
+    _same(h[2], f[2])
+    _same(h[3], f[3])
+    assert torch.equal(f[5], h[5]) and torch.equal(f[6], h[6])
+    # the dropped copy is the dropout of the fp32 dx rounded once (not of the rounded dx): compare against that
+    keep = (f[4] != 0) | (f[3] == 0)
+    _same(h[4], f[4])
+    assert keep.float().mean() > 0.85
+
+
+def test_pooling_tokens_upsample_gap_transposes():
+    from mmfn_amd import ops
+    B, S, C, T = 2, 32, 64, 192
+    feats = [_r(B, S, S, C, seed=i) for i in range(3)]
+    pos, vw, vb, vel = torch.randn(T, C, device=DEV), torch.randn(C, device=DEV), torch.randn(C, device=DEV), torch.rand(B, device=DEV)
+    rng = torch.tensor([5, 1], dtype=torch.int64, device=DEV)
+    t32 = ops.tokens_fwd([f.float() for f in feats], pos, vw, vb, vel, torch.empty(B, T, C, device=DEV), 0.1, rng, 3)
+    t16 = ops.tokens_fwd(feats, pos, vw, vb, vel, torch.empty(B, T, C, dtype=BF, device=DEV), 0.1, rng, 3)
+    _same(t16, t32)
+    tok = _r(B, T, C, seed=9)
+    for m in range(3):
+        u32 = ops.upsample_add_fwd(feats[m].float(), tok.float(), torch.empty(B, S, S, C, device=DEV), m)
+        u16 = ops.upsample_add_fwd(feats[m], tok, torch.empty(B, S, S, C, dtype=BF, device=DEV), m)
+        _same(u16, u32)
+        g32, g16 = torch.zeros(B, T, C, device=DEV), torch.zeros(B, T, C, dtype=BF, device=DEV)
+        ops.upsample_adj(feats[m].float(), g32, m)
+        ops.upsample_adj(feats[m], g16, m)
+        _same(g16[:, m * 64:(m + 1) * 64], g32[:, m * 64:(m + 1) * 64])
+        d32 = ops.pool_bcast_add(feats[m].float(), tok.float(), torch.empty(B, S, S, C, device=DEV), m)
+        d16 = ops.pool_bcast_add(feats[m], tok, torch.empty(B, S, S, C, dtype=BF, device=DEV), m)
+        _same(d16, d32)
+    # token backward: in-place dropout mask + fp32 parameter gradients
+    gt32 = tok.float().clone()
+    gt16 = tok.clone()
+    outs = []
+    for gt in (gt32, gt16):
+        dpos, dvw, dvb = torch.empty(T, C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        ops.tokens_bwd(gt, vel, dpos, dvw, dvb, 0.1, rng, 3)
+        outs.append((dpos, dvw, dvb))
+    _same(gt16, gt32)
+    # (parameter gradients are sums of the masked values: fp32 of fp32 values vs fp32 of bf16-rounded ones)
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, rtol=2e-2, atol=2e-2 * float(a.abs().max()))
+    # global average pool + branch sum, and its adjoint
+    small = [_r(B, 8, 8, 512, seed=20 + i) for i in range(3)]
+    p32 = ops.gap_sum_fwd([f.float() for f in small], torch.empty(B, 512, device=DEV))
+    p16 = ops.gap_sum_fwd(small, torch.empty(B, 512, device=DEV))
+    assert torch.equal(p32, p16)
+    gq = torch.randn(B, 512, device=DEV)
+    o32 = [torch.empty(B, 8, 8, 512, device=DEV) for _ in range(3)]
+    o16 = [torch.empty(B, 8, 8, 512, dtype=BF, device=DEV) for _ in range(3)]
+    ops.gap_sum_bwd(gq, o32)
+    ops.gap_sum_bwd(gq, o16)
+    _same(o16[1], o32[1])
+    # max pool with saved argmax
+    x = _r(B, 64, 64, 64, seed=31)
+    y32, i32 = torch.empty(B, 32, 32, 64, device=DEV), torch.empty(B, 32, 32, 64, dtype=torch.uint8, device=DEV)
+    y16, i16 = torch.empty(B, 32, 32, 64, dtype=BF, device=DEV), torch.empty(B, 32, 32, 64, dtype=torch.uint8, device=DEV)
+    ops.maxpool_fwd(x.float(), y32, i32)
+    ops.maxpool_fwd(x, y16, i16)
+    _same(y16, y32)
+    assert torch.equal(i16, i32)
+    gy = _r(B, 32, 32, 64, seed=32)
+    _same(ops.maxpool_bwd(gy, i16, torch.empty(B, 64, 64, 64, dtype=BF, device=DEV)),
+          ops.maxpool_bwd(gy.float(), i32, torch.empty(B, 64, 64, 64, device=DEV)))
+    # transposes across the precision boundary
+    a = torch.randn(B, 64, 4096, device=DEV)
+    t = ops.transpose(a, torch.empty(B, 4096, 64, dtype=BF, device=DEV), B, 64, 4096)
+    _same(t, a.transpose(1, 2).contiguous())
+    back = ops.transpose(t, torch.empty(B, 64, 4096, device=DEV), B, 4096, 64)
+    assert torch.equal(back, t.float().transpose(1, 2).contiguous())
+    cs32, cs16 = torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    ops.colsum(t.view(-1, 64).float(), cs32)
+    ops.colsum(t.view(-1, 64), cs16)
+    assert torch.equal(cs32, cs16)
+
+
+@pytest.mark.parametrize("hs", [16, 32, 64, 128])
+def test_attention_bf16_io(hs):
+    from mmfn_amd import ops
+    B, T, NH = 4, 192, 4
+    C = NH * hs
+    qkv = _r(B * T, 3 * C, seed=1, scale=0.5)
+    dO = _r(B * T, C, seed=2)
+    rng = torch.tensor([9, 2], dtype=torch.int64, device=DEV)
+    res = []
+    for dt in (torch.float32, BF):
+        x, g = qkv.to(dt), dO.to(dt)
+        o, lse = torch.empty(B * T, C, dtype=dt, device=DEV), torch.empty(B, NH, T, device=DEV)
+        ops.attention_fwd(x[:, C:], x, x[:, 2 * C:], 3 * C, o, C, lse, B, T, NH, hs, hs ** -0.5, drop_p=0.1, rng_state=rng, rng_stream=4)
+        dq = torch.zeros(B * T, 3 * C, dtype=dt, device=DEV)
+        delta = torch.empty(B, NH, T, device=DEV)
+        ops.attention_bwd(x[:, C:], x, x[:, 2 * C:], 3 * C, o, g, C, lse, delta, dq[:, C:], dq, dq[:, 2 * C:], 3 * C, B, T, NH, hs,
+                          hs ** -0.5, drop_p=0.1, rng_state=rng, rng_stream=4)
+        res.append((o, lse, dq, delta))
+    f, h = res
+    _same(h[0], f[0])
+    assert torch.equal(f[1], h[1])
+    # the backward reads the STORED (bf16) o: delta and the gradients differ from the fp32 run by that rounding only
+    assert torch.allclose(h[3], f[3], rtol=0, atol=2e-2 * float(f[3].abs().max()))
+    err = float((h[2].float() - f[2]).abs().max())
+    assert err <= 2e-2 * float(f[2].abs().max()), err
+
+
+def test_weight_shadows():
+    from mmfn_amd import ops
+    w = torch.randn(96, 9, 160, device=DEV)
+    lin = torch.randn(200, 72, device=DEV)
+    d1, d2 = torch.zeros(w.numel(), dtype=BF, device=DEV), torch.zeros(lin.numel(), dtype=BF, device=DEV)
+    table = ops.make_shadow_table([(w, d1), (lin, d2)], torch.device(DEV))
+    ops.shadow_transpose(*table)
+    assert torch.equal(d1.view(160, 9, 96), w.permute(2, 1, 0).contiguous().to(BF))
+    assert torch.equal(d2.view(72, 200), lin.t().contiguous().to(BF))
+    flat = torch.randn(1 << 16, device=DEV)
+    assert torch.equal(ops.cast_to_bf16(flat, torch.empty(1 << 16, dtype=BF, device=DEV)), flat.to(BF))

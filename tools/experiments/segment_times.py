@@ -14,9 +14,9 @@ from mmfn_amd.parallel import GraphedStep  # noqa: E402
 
 dev = torch.device("cuda:0")
 B = int(os.environ.get("BATCH", "32"))
-net = MMFN(GlobalConfig(gemm_dtype=os.environ.get("GEMM_DTYPE", "f32")), dev)
+net = MMFN(GlobalConfig(gemm_dtype=os.environ.get("GEMM_DTYPE", "f32"), act_dtype=os.environ.get("ACT_DTYPE", "f32")), dev)
 inp, gt = bench.synth_inputs(B, dev, seed=0)
-step = GraphedStep(net._engine_for(), None, inp, gt, warm=2)
+step = GraphedStep(net._engine_for(), None, inp, gt, warm=2, lane_graphs=True)
 rec = step.recorder
 
 
