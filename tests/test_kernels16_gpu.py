@@ -1,6 +1,8 @@
 """The *_bf16 entry points (bf16 activations in HBM) against their fp32 twins: the arithmetic is the same fp32 code (the kernels
-are templates on the element type), so on bf16-exact inputs a bf16 output must be EXACTLY the round-to-nearest-even bf16 of the
-fp32 kernel's output, and every fp32 output (statistics, gradients of parameters, lse) must be bit-identical."""
+are templates on the element type), so on bf16-exact inputs a bf16 output must be the round-to-nearest-even bf16 of the fp32
+kernel's output - exactly, except where the two instantiations contract a multiply-add differently (an fp32 ulp that moves a
+value across a bf16 rounding boundary: at most one bf16 ulp, on a vanishing fraction of the elements) - and every fp32 output
+whose inputs are the same numbers (statistics, parameter gradients, lse) must be bit-identical."""
 import pytest
 import torch
 
@@ -16,7 +18,13 @@ def _r(*shape, seed=0, scale=1.0):
 
 def _same(a16, a32):
     assert a16.dtype == BF
-    assert torch.equal(a16, a32.to(BF)), float((a16.float() - a32).abs().max())
+    want = a32.to(BF)
+    if torch.equal(a16, want):
+        return
+    diff = (a16.float() - want.float()).abs()
+    ulp = want.float().abs().clamp_min(1e-30) * 2.0 ** -7          # one bf16 ulp is at most 2^-7 of the value
+    assert bool((diff <= ulp).all()), float((diff / ulp).max())
+    assert float((diff > 0).float().mean()) <= 1e-3, float((diff > 0).float().mean())
 
 
 def test_batchnorm_forward_backward():
