@@ -32,6 +32,15 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak (AMD's 5 PF h
 ALGO_GFLOP_PER_SAMPLE = {"vec": 106.6, "img": 112.4, "rad": 117.7, "image-only": 28.4}
 
 
+# BASELINE.json configs -> flags (`--config NAME`); vec32 is what `python bench.py` runs without flags
+PRESETS = {
+    "vec32": ("configs[1]: full MMFN vec, fp32, batch 32, 1 GPU", dict()),
+    "bf16": ("configs[2] per-GPU arithmetic: bf16 training mode, batch 32/GPU (add --gpus 8 for the 8 x 32 = 256 run)", dict(dtype="bf16")),
+    "img128": ("configs[3]: ResNet-34 camera branch alone, batch 128", dict(workload="image-only", batch=128)),
+    "rad16": ("configs[4]: rad variant (4 modalities), 65536-point LiDAR, batch 16", dict(variant="rad", batch=16, n_lidar=65536)),
+}
+
+
 def synth_inputs(B, device, seed, lanes=64, n_lidar=16384, variant="vec", lane_format="10x5"):
     g = torch.Generator().manual_seed(seed)
     rgb = torch.randint(0, 256, (B, 300, 400, 3), generator=g, dtype=torch.uint8)
@@ -331,7 +340,13 @@ def main():
     ap.add_argument("--no-oracle-check", action="store_true", help="skip the loss_vs_oracle block (one CPU oracle forward)")
     ap.add_argument("--single-stream", action="store_true", help="disable encoder-branch concurrency (profiling runs)")
     ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps for the roofline block")
+    ap.add_argument("--config", default=None, choices=sorted(PRESETS),
+                    help="BASELINE.json configuration presets (one flag per config): " + "; ".join("%s = %s" % (k, v[0]) for k, v in sorted(PRESETS.items())))
     args = ap.parse_args()
+    if args.config:   # a preset only fills in the flags the command line left at their defaults
+        for k, v in PRESETS[args.config][1].items():
+            if getattr(args, k) == ap.get_default(k):
+                setattr(args, k, v)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no outer launcher: start the ranks ourselves (the same command line works under torch.distributed.run too)

@@ -156,8 +156,18 @@ typedef struct mmfn_gemm16_desc {
   const void* aux; /* bf16 [M, ldaux] (MMFN_EPI_MASK_AUX) */
   const uint64_t* rng_state;
   float* workspace; /* TN forms: split slabs, mmfn_gemm_bf16_workspace_bytes() */
-  double* stats;    /* NT forms, optional: BatchNorm batch-statistics partial rows of the raw output, [2 * ceil(M / tile rows)][2][N]
-                       doubles (sum, sum of squares), to be finished by mmfn_bn_finalize_stats_f32 */
+  double* stats;    /* NT forms, optional: per-column partial sums of the output tile, [2 * ceil(M / tile rows)][2][N] doubles, by
+                       stats_mode: 0 = (sum, sum of squares) of the RAW accumulators - BatchNorm batch statistics of a convolution
+                       output, finished by mmfn_bn_finalize_stats_f32;  1 = (sum, sum of squares) of the FINAL value after the whole
+                       epilogue - column sums = the bias gradient when the output is a Linear's input gradient, finished by
+                       mmfn_colsum_partials_f64;  2 = (sum ge, sum ge * xhat) with ge = final value masked by bn_y > 0 (bn_y may be
+                       NULL) and xhat = (bn_x - bn_mean) * bn_rstd: the two reductions of the BatchNorm backward whose output
+                       gradient this launch produces (a data gradient feeding the BatchNorm of the layer below), finished by
+                       mmfn_bn_bwd_bf16(..., partials) */
+  const void* bn_y;       /* stats_mode 2: bf16 [M, N] (ldc), the BatchNorm output whose sign gates the ReLU, or NULL */
+  const void* bn_x;       /* stats_mode 2: bf16 [M, N] (ldc), the BatchNorm input (the convolution output) */
+  const float* bn_mean;   /* stats_mode 2: [N] */
+  const float* bn_rstd;   /* stats_mode 2: [N] */
   int32_t M, N, K;
   int32_t lda, ldb, ldc, ldr, ldaux; /* in elements */
   int32_t form;
@@ -168,6 +178,8 @@ typedef struct mmfn_gemm16_desc {
   uint32_t rng_stream;
   float drop_p;
   int32_t stages;      /* LDS stages of the operand pipeline: 0 auto, 2 = double buffer, 3 / 4 = 1 / 2 k-tiles in flight beyond it */
+  int32_t stats_mode;  /* see `stats` */
+  int32_t reserved;
 } mmfn_gemm16_desc;
 
 int mmfn_sizeof_gemm16_desc(void);
@@ -379,6 +391,13 @@ int mmfn_layernorm_bwd_partial_bf16(const void* g, const void* x, const float* w
                                     float drop_p, const uint64_t* rng_state, uint32_t rng_stream, int want_colsum,
                                     float* partials, void* stream);
 int mmfn_colsum_bf16(const void* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream);
+/* out[c] = sum over rows of partials[row][0][c] (mmfn_gemm_bf16 stats_mode 1: the bias gradient from the producing GEMM's epilogue) */
+int mmfn_colsum_partials_f64(const double* partials, int rows, int C, float* out, void* stream);
+/* BatchNorm backward whose two reductions were emitted as partial rows by the GEMM that produced g (mmfn_gemm_bf16 stats_mode 2):
+ * finalize (dweight, dbias, means) + the elementwise pass; arguments as mmfn_bn_bwd_bf16 (x / dx bf16) */
+int mmfn_bn_bwd_partials_bf16(const double* partials, int rows, const void* g, const void* y, const void* x, int64_t M, int C,
+                              const float* mean, const float* rstd, const float* weight, void* dx, void* ge_out, float* dweight,
+                              float* dbias, void* workspace, void* stream);
 int mmfn_maxpool3x3s2_fwd_bf16(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
 int mmfn_maxpool3x3s2_bwd_bf16(const void* gy, const uint8_t* idx, void* gx, int B, int H, int W, int C, void* stream);
 int mmfn_tokens_fwd_bf16(const void* const* feats, int n_modal, int B, int S, int C, const float* pos, const float* vel_w,

@@ -41,14 +41,14 @@ class Gemm16Desc(ctypes.Structure):
     """mmfn_gemm16_desc (include/mmfn_hip.h): the bf16-operand GEMM / convolution of the bf16 training mode."""
     _fields_ = [
         ("A", _vp), ("B", _vp), ("C", _vp), ("bias", _vp), ("res", _vp), ("aux", _vp), ("rng_state", _vp), ("workspace", _vp),
-        ("stats", _vp),
+        ("stats", _vp), ("bn_y", _vp), ("bn_x", _vp), ("bn_mean", _vp), ("bn_rstd", _vp),
         ("M", _i32), ("N", _i32), ("K", _i32),
         ("lda", _i32), ("ldb", _i32), ("ldc", _i32), ("ldr", _i32), ("ldaux", _i32),
         ("form", _i32),
         ("H", _i32), ("W", _i32), ("Cin", _i32), ("OH", _i32), ("OW", _i32), ("Cout", _i32),
         ("KH", _i32), ("KW", _i32), ("stride", _i32), ("pad", _i32),
         ("flags", _i32), ("splitk", _i32), ("tile", _i32),
-        ("rng_stream", ctypes.c_uint32), ("drop_p", _f32), ("stages", _i32),
+        ("rng_stream", ctypes.c_uint32), ("drop_p", _f32), ("stages", _i32), ("stats_mode", _i32), ("reserved", _i32),
     ]
 
 

@@ -266,6 +266,11 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
     for (int e = 0; e < 4; ++e) { bias[e] = b0[e]; bias[4 + e] = b1[e]; }
   }
   float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float bnm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bnr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (d.stats && d.stats_mode == 2 && col_ok) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bnm[e] = d.bn_mean[col + e]; bnr[e] = d.bn_rstd[col + e]; }
+  }
 #pragma unroll
   for (int p = 0; p < TM * 32 / RPP; ++p) {
     const int rl = p * RPP + lane / LPR;
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = t0[e]; v[4 + e] = t1[e]; }
     }
-    if (d.stats) {   // BatchNorm batch statistics of the raw convolution output
+    if (d.stats && d.stats_mode == 0) {   // BatchNorm batch statistics of the raw convolution output
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
     }
@@ -308,6 +313,29 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
       const Row8 a = load8_bf16(reinterpret_cast<const bf16_t*>(d.res) + (size_t)row * d.ldr + col);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += a.v[e];
+    }
+    if (d.stats && d.stats_mode != 0 && !(f & (MMFN_EPI_ACCUM | MMFN_EPI_RELU_LAST))) {
+      if (d.stats_mode == 1) {          // column sums of the final value: the bias gradient of the Linear whose dX this is
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
+      } else {                          // the reductions of the BatchNorm backward this gradient enters (bn_bwd's col_partial pass)
+        const Row8 xq = load8_bf16(reinterpret_cast<const bf16_t*>(d.bn_x) + (size_t)row * d.ldc + col);
+        float ge[8];
+        if (d.bn_y) {
+          const Row8 yq = load8_bf16(reinterpret_cast<const bf16_t*>(d.bn_y) + (size_t)row * d.ldc + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ge[e] = yq.v[e] > 0.f ? bf2f(f2bf(v[e])) : 0.f;   // the STORED (bf16) gradient, as bn_bwd reads it
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ge[e] = bf2f(f2bf(v[e]));
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xq.v[e] - bnm[e]) * bnr[e];
+          s1[e] += ge[e];
+          s2[e] += ge[e] * xh;
+        }
+      }
     }
     if (f & MMFN_EPI16_OUT_F32) {
       float* c = reinterpret_cast<float*>(d.C) + (size_t)row * d.ldc + col;
@@ -654,6 +682,9 @@ extern "C" int mmfn_gemm_bf16(const mmfn_gemm16_desc* dp, void* stream) {
     }
     if ((d.flags & MMFN_EPI_RESIDUAL) && (!d.res || d.ldr % 8)) return MMFN_EINVAL;
     if ((d.flags & MMFN_EPI_MASK_AUX) && (!d.aux || d.ldaux % 8)) return MMFN_EINVAL;
+    if (d.stats && d.stats_mode == 2 && (!d.bn_x || !d.bn_mean || !d.bn_rstd || (d.flags & MMFN_EPI16_OUT_F32))) return MMFN_EINVAL;
+    if (d.stats && (d.stats_mode < 0 || d.stats_mode > 2)) return MMFN_EINVAL;
+    if (d.stats && d.stats_mode != 0 && (d.flags & (MMFN_EPI_ACCUM | MMFN_EPI_RELU_LAST))) return MMFN_EINVAL;
     int rc_nt = 0;
 #define NT_FORMS(BM_, BN_)                          \
   if (d.form == 0) LAUNCH_NT(0, BM_, BN_);          \

@@ -704,6 +704,43 @@ int colsum_batched_launch(const TA* in, int batch, int64_t stride_in, int64_t M,
 }
 }  // namespace
 
+namespace {
+__global__ void colsum_partials_kernel(const double* __restrict__ partials, int nblk, int C, float* __restrict__ out) {
+  __shared__ double sh[1][FIN_LANES][FIN_COLS];
+  const int c = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
+  const bool valid = c < C;
+  double r[1];
+  reduce_partials<1>(partials, nblk, (size_t)2 * C, C, c, valid, sh, r);
+  if (!valid || threadIdx.x >= FIN_COLS) return;
+  out[c] = (float)r[0];
+}
+}  // namespace
+
+extern "C" int mmfn_colsum_partials_f64(const double* partials, int rows, int C, float* out, void* stream) {
+  if (!partials || rows <= 0 || C <= 0 || !out) return MMFN_EINVAL;
+  hipLaunchKernelGGL(colsum_partials_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, (hipStream_t)stream, partials, rows,
+                     C, out);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_bn_bwd_partials_bf16(const double* partials, int rows, const void* g, const void* y, const void* x, int64_t M, int C,
+                                         const float* mean, const float* rstd, const float* weight, void* dx, void* ge_out,
+                                         float* dweight, float* dbias, void* workspace, void* stream) {
+  if (!partials || rows <= 0 || C % 4 || M <= 0 || !workspace) return MMFN_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  float* means = (float*)workspace;   // [2][C]
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, partials, rows, M, C, dweight, dbias,
+                     means);
+  MMFN_LAUNCH_CHECK();
+  const int64_t total4 = M * (C / 4);
+  const int blocks = (int)std::min<int64_t>(ceil_div64(total4, NT), 8192);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(NT), 0, s, (const bf16_t*)g, (const bf16_t*)y, (const bf16_t*)x,
+                     (bf16_t*)dx, (bf16_t*)ge_out, total4, C, mean, rstd, weight, means);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmfn_colsum_batched_f32(const float* in, int batch, int64_t stride_in, int64_t M, int C, int ld, float* out,
                                        int64_t stride_out, void* workspace, void* stream) {
   return colsum_batched_launch(in, batch, stride_in, M, C, ld, out, stride_out, workspace, stream);

@@ -128,6 +128,7 @@ class Ctx(object):
 
 # ----------------------------------------------------------------------------- conv + BN
 FUSE_BN_BWD_APPLY = os.environ.get("MMFN_FUSE_BN_BWD", "1") == "1"   # A/B switch, see ConvBN.bwd
+FUSE_BN_BWD_REDUCE = os.environ.get("MMFN_FUSE_BN_REDUCE", "1") == "1"   # A/B switch, see ConvBN.bwd16 (bf16 mode)
 
 
 class ConvBN(object):
@@ -180,14 +181,23 @@ class ConvBN(object):
         self.saved = (x, co, y, mean, rstd, relu)
         return y
 
-    def bwd16(self, ctx, g, need_dx=True, ge_out=None, dx_res=None, mask_y=None):
+    def bwd16(self, ctx, g, need_dx=True, ge_out=None, dx_res=None, mask_y=None, emit=None):
+        """emit: the ConvBN whose BatchNorm receives THIS call's data gradient as its output gradient (the layer below on the
+        dependent chain): the data-gradient GEMM's epilogue then also forms the two reductions of that BatchNorm's backward
+        (sum ge, sum ge * xhat) from the tile it is storing, so the consumer skips its reduction pass over g, y and x."""
         from . import ops16
         x, co, y, mean, rstd, relu = self.saved
         M = co.numel() // self.cout
         dco = ctx.bufs.get(self.name + ".dconv", co.shape, co.dtype)
         ymask = (y if mask_y is None else mask_y).view(M, self.cout) if relu else None
-        ops.bn_bwd(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.bn_w, dco.view(M, self.cout),
-                   self.g_bn_w, self.g_bn_b, ge_out=None if ge_out is None else ge_out.view(M, self.cout))
+        pre, self._pre = getattr(self, "_pre", None), None
+        if pre is not None and mask_y is None and co.dtype == torch.bfloat16:
+            ops16.bn_bwd_partials(pre[0], pre[1], g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.bn_w,
+                                  dco.view(M, self.cout), self.g_bn_w, self.g_bn_b,
+                                  ge_out=None if ge_out is None else ge_out.view(M, self.cout))
+        else:
+            ops.bn_bwd(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.bn_w, dco.view(M, self.cout),
+                       self.g_bn_w, self.g_bn_b, ge_out=None if ge_out is None else ge_out.view(M, self.cout))
         if x.dtype == torch.float32:   # stem: fp32 weight gradient, no data gradient
             ops.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, out=self.gw)
             return None
@@ -196,11 +206,18 @@ class ConvBN(object):
             return None
         dx = ctx.bufs.get(self.name + ".dx", x.shape, ctx.adt)
         cin = x.shape[-1]
-        if dx_res is None:
-            ops16.conv2d_dgrad(dco, self.w16t, tuple(x.shape), tuple(self.w.shape), self.stride, self.pad, dx)
-        else:
-            ops16.conv2d_dgrad(dco, self.w16t, tuple(x.shape), tuple(self.w.shape), self.stride, self.pad, dx,
-                               res=dx_res.view(-1, cin), ldr=cin)
+        extra = {}
+        if emit is not None and FUSE_BN_BWD_REDUCE and emit.saved[1].dtype == torch.bfloat16:
+            ex, eco, ey, emean, erstd, erelu = emit.saved
+            Mx = x.shape[0] * x.shape[1] * x.shape[2]
+            part = ctx.bufs.get(emit.name + ".bnpart", (ops16.max_stats_rows(Mx), 2, cin), torch.float64)
+            extra = dict(stats=part, stats_mode=2, bn=(ey if erelu else None, eco, emean, erstd))
+        if dx_res is not None:
+            extra.update(res=dx_res.view(-1, cin), ldr=cin)
+        ops16.conv2d_dgrad(dco, self.w16t, tuple(x.shape), tuple(self.w.shape), self.stride, self.pad, dx, **extra)
+        if "stats" in extra:   # (after the launch: the autotuner may just have added the shape's table entry)
+            g_, _ = ops.conv_geom(tuple(x.shape), tuple(self.w.shape), self.stride, self.pad)
+            emit._pre = (extra["stats"], ops16.gemm_stats_rows(ops16.G16_CONV_DGRAD, Mx, cin, g_[6] * g_[7] * g_[5], g_))
         return dx
 
     def fwd(self, ctx, x, relu=True, res=None):
@@ -248,12 +265,13 @@ class ConvBN(object):
         self.saved_u = keep_u
         return y
 
-    def bwd(self, ctx, g, need_dx=True, ge_out=None, dx_res=None, mask_y=None):
+    def bwd(self, ctx, g, need_dx=True, ge_out=None, dx_res=None, mask_y=None, emit=None):
         """g: dL/dy.  ge_out receives the ReLU-masked g (the residual branch's gradient).
         dx_res is added to dx (gradient arriving at x from another branch).
-        mask_y overrides the tensor whose sign gates the ReLU (when y was further modified)."""
+        mask_y overrides the tensor whose sign gates the ReLU (when y was further modified).
+        emit (bf16 mode): see bwd16."""
         if ctx.bf16:
-            return self.bwd16(ctx, g, need_dx, ge_out, dx_res, mask_y)
+            return self.bwd16(ctx, g, need_dx, ge_out, dx_res, mask_y, emit)
         x, co, y, mean, rstd, relu = self.saved
         M = co.numel() // self.cout
         dco = ctx.bufs.get(self.name + ".dconv", co.shape)
@@ -304,13 +322,14 @@ class BasicBlock(object):
         skip = x if self.down is None else self.down.fwd(ctx, x, relu=False)
         return self.c2.fwd(ctx, y1, relu=True, res=skip)
 
-    def bwd(self, ctx, g, mask_y=None):
+    def bwd(self, ctx, g, mask_y=None, emit=None):
+        """emit: the ConvBN (the previous block's second convolution) whose BatchNorm this block's input gradient enters."""
         ge = ctx.bufs.get(self.name + ".ge", g.shape, g.dtype)
-        g_y1 = self.c2.bwd(ctx, g, ge_out=ge, mask_y=mask_y)
+        g_y1 = self.c2.bwd(ctx, g, ge_out=ge, mask_y=mask_y, emit=self.c1)
         if self.down is None:
-            return self.c1.bwd(ctx, g_y1, dx_res=ge)
+            return self.c1.bwd(ctx, g_y1, dx_res=ge, emit=emit)
         dx_skip = self.down.bwd(ctx, ge)
-        return self.c1.bwd(ctx, g_y1, dx_res=dx_skip)
+        return self.c1.bwd(ctx, g_y1, dx_res=dx_skip, emit=emit)
 
 
 class ResNetTrunk(object):
@@ -356,7 +375,7 @@ class ResNetTrunk(object):
     def layer_bwd(self, ctx, li, g, mask_y=None):
         blocks = self.layers[li]
         for i in range(len(blocks) - 1, -1, -1):
-            g = blocks[i].bwd(ctx, g, mask_y=mask_y if i == len(blocks) - 1 else None)
+            g = blocks[i].bwd(ctx, g, mask_y=mask_y if i == len(blocks) - 1 else None, emit=blocks[i - 1].c2 if i > 0 else None)
         return g
 
 
@@ -577,11 +596,22 @@ class GPT(object):
             if not grouped:
                 side.append(lambda gp=gp, blk=blk, h=h: ops.linear_dw(gp, h, out=blk["fc2"].gw))   # fc2.gb: from the LayerNorm backward
             gh = GH[i]
-            ops.linear_dx(gp, Wb(blk["fc2"]), out=gh, aux=h, ldaux=4 * C)
+            ghpart = None
+            if ctx.bf16 and not grouped:
+                # the column sums of gh (= mlp.0's bias gradient) come out of this GEMM's epilogue as partial rows
+                from . import ops16
+                ghpart = bufs.get("%s.b%d.ghpart" % (nm, i), (ops16.max_stats_rows(M), 2, 4 * C), torch.float64)
+                ops.linear_dx(gp, Wb(blk["fc2"]), out=gh, aux=h, ldaux=4 * C, stats=ghpart, stats_mode=1)
+                ghrows = ops16.gemm_stats_rows(ops16.G16_NT, M, 4 * C, C)
+            else:
+                ops.linear_dx(gp, Wb(blk["fc2"]), out=gh, aux=h, ldaux=4 * C)
             if pending is not None:
                 ctx.offload_at(pending[0], lambda work=pending[1]: [f() for f in work])
                 pending = None
-            if not grouped:
+            if not grouped and ghpart is not None:
+                side.append(lambda gh=gh, blk=blk, a2=a2, p=ghpart, r=ghrows: (ops16.colsum_partials(p, r, 4 * C, blk["fc1"].gb),
+                                                                               ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
+            elif not grouped:
                 side.append(lambda gh=gh, blk=blk, a2=a2: (ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
             ga2 = bufs.get(nm + ".ga", (M, C), adt)
             ops.linear_dx(gh, Wb(blk["fc1"]), out=ga2)

@@ -116,3 +116,48 @@ def test_convolution_forward_dgrad_wgrad(B, H, W, Ci, Co, k, s, p):
     dw = torch.empty(Co, k, k, Ci, dtype=torch.float32, device=DEV)
     ops16.conv2d_wgrad(dy, x, tuple(w.shape), s, p, dw)
     _close(dw, wt.grad.permute(0, 2, 3, 1), tol=3e-3)
+
+
+def test_epilogue_partial_sums_bias_gradient_and_batchnorm_backward_reductions():
+    """stats_mode 1: column sums of the FINAL epilogue value (the bias gradient of the Linear whose dX the launch computes);
+    stats_mode 2: the two reductions of the BatchNorm backward that the launch's output gradient enters, with the consumer's
+    ReLU mask - against mmfn_bn_bwd_bf16's own reduction pass on the stored tensors."""
+    from mmfn_amd import ops, ops16
+    M, N, K = 6144, 512, 128
+    dy, wt, aux = _rnd(M, K, seed=1), _rnd(N, K, scale=0.1, seed=2), _rnd(M, N, seed=3)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    part = torch.zeros(ops16.max_stats_rows(M), 2, N, dtype=torch.float64, device=DEV)
+    ops16.linear_dx(dy, wt, out=out, aux=aux, ldaux=N, stats=part, stats_mode=1)
+    rows = ops16.gemm_stats_rows(ops16.G16_NT, M, N, K)
+    got = ops16.colsum_partials(part, rows, N, torch.empty(N, device=DEV))
+    ref = ((dy.float() @ wt.float().t()) * (aux.float() > 0)).sum(0)
+    assert torch.allclose(got, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    # BatchNorm-backward reductions from a data-gradient epilogue
+    B, H, W, Ci, Co = 2, 16, 16, 128, 128
+    dyc = _rnd(B, H, W, Co, seed=4)
+    w_t = _rnd(Ci, 3, 3, Co, scale=0.05, seed=5)
+    res = _rnd(B, H, W, Ci, seed=6)
+    y_c, x_c = _rnd(B, H, W, Ci, seed=7), _rnd(B, H, W, Ci, seed=8, scale=2.0)
+    mean, rstd = torch.randn(Ci, device=DEV) * 0.1, torch.rand(Ci, device=DEV) + 0.5
+    Mx = B * H * W
+    part = torch.zeros(ops16.max_stats_rows(Mx), 2, Ci, dtype=torch.float64, device=DEV)
+    dx = torch.empty(B, H, W, Ci, dtype=torch.bfloat16, device=DEV)
+    ops16.conv2d_dgrad(dyc, w_t, (B, H, W, Ci), (Co, 3, 3, Ci), 1, 1, dx, res=res.view(-1, Ci), ldr=Ci, stats=part, stats_mode=2,
+                       bn=(y_c, x_c, mean, rstd))
+    g_, _ = ops.conv_geom((B, H, W, Ci), (Co, 3, 3, Ci), 1, 1)
+    rows = ops16.gemm_stats_rows(ops16.G16_CONV_DGRAD, Mx, Ci, 9 * Co, g_)
+    wgt = torch.rand(Ci, device=DEV) + 0.5
+    outs = []
+    for fused in (False, True):
+        dco, ge = torch.empty(Mx, Ci, dtype=torch.bfloat16, device=DEV), torch.empty(Mx, Ci, dtype=torch.bfloat16, device=DEV)
+        dwt, dbs = torch.empty(Ci, device=DEV), torch.empty(Ci, device=DEV)
+        if fused:
+            ops16.bn_bwd_partials(part, rows, dx.view(Mx, Ci), y_c.view(Mx, Ci), x_c.view(Mx, Ci), mean, rstd, wgt, dco, dwt, dbs, ge_out=ge)
+        else:
+            ops.bn_bwd(dx.view(Mx, Ci), y_c.view(Mx, Ci), x_c.view(Mx, Ci), mean, rstd, wgt, dco, dwt, dbs, ge_out=ge)
+        outs.append((dco, ge, dwt, dbs))
+    a, b = outs
+    assert torch.allclose(a[2], b[2], rtol=1e-4, atol=1e-4 * float(a[2].abs().max()))
+    assert torch.allclose(a[3], b[3], rtol=1e-4, atol=1e-4 * float(a[3].abs().max()))
+    assert torch.equal(a[1], b[1])
+    assert float((a[0].float() - b[0].float()).abs().max()) <= 2e-2 * float(a[0].float().abs().max())

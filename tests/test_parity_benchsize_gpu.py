@@ -80,6 +80,34 @@ def _grad_report(hip_grads, g32, g64):
     return rows
 
 
+def _stage_cosines(hip_grads, g32, g64):
+    """Per BACKWARD STAGE (params.FlatLayout.stage_of: fusion scale 4 first), over all tensors of the stage together: cosine of
+    the HIP gradient and of the fp32 oracle's gradient to the fp64 gradient.  A systematic (non-noise) kernel error - a wrong
+    scale, a dropped term, a transposed filter - moves the direction of a whole stage; rounding noise that the per-tensor
+    error-ratio test has to tolerate does not (round-2 review, item 8)."""
+    from mmfn_amd.params import FlatLayout
+    acc = {}
+    for name, t in g64.items():
+        if t is None:
+            continue
+        st = FlatLayout.stage_of(name)
+        a, b, c = hip_grads[name].detach().cpu().double().flatten(), t.flatten(), g32[name].double().flatten()
+        d = acc.setdefault(st, [0.0] * 5)
+        d[0] += float(torch.dot(a, b)); d[1] += float(torch.dot(a, a)); d[2] += float(torch.dot(b, b))
+        d[3] += float(torch.dot(c, b)); d[4] += float(torch.dot(c, c))
+    return {st: (d[0] / (d[1] * d[2]) ** 0.5, d[3] / (d[4] * d[2]) ** 0.5) for st, d in sorted(acc.items())}
+
+
+def _judge_stage_cosines(cos, tag):
+    print("[%s] per-stage gradient cosine to fp64 (HIP, CPU fp32 oracle): %s"
+          % (tag, "  ".join("stage %d: %.6f, %.6f" % (st, h, c) for st, (h, c) in cos.items())))
+    for st, (h, c) in cos.items():
+        # 0.9999 wherever the fp32 oracle itself gets there; otherwise the HIP gradient may be at most 3x further (in angle^2)
+        # from the fp64 direction than the fp32 oracle is
+        bar = min(0.9999, 1.0 - 3.0 * (1.0 - c) - 1e-6)
+        assert h >= bar, "stage %d: cosine(HIP, fp64) %.6f below %.6f (fp32 oracle %.6f)" % (st, h, bar, c)
+
+
 def _judge_gradients(rows, tag):
     """Both the HIP path and the CPU oracle are fp32 evaluations of a graph whose backward amplifies rounding (85 train-mode
     BatchNorms): the yardstick for the HIP error is the fp32 oracle's OWN error against fp64 on the same tensor."""
@@ -126,6 +154,7 @@ def _check_train_step(variant, B, n_lidar):
     assert wp_err <= 1e-4 * max(1.0, pred_ref.abs().max().item()), wp_err
     hip_grads = {n: p.grad for n, p in net.named_parameters()}
     _judge_gradients(_grad_report(hip_grads, grads_ref, g64), "%s B=%d" % (variant, B))
+    _judge_stage_cosines(_stage_cosines(hip_grads, grads_ref, g64), "%s B=%d" % (variant, B))
     # one fused AdamW step from these gradients == torch.optim.AdamW on the oracle, on the elements whose gradient sign both
     # fp32 evaluations determine
     init = {k: v.detach().clone() for k, v in net.named_parameters()}
