@@ -80,7 +80,7 @@ def _grad_report(hip_grads, g32, g64):
     return rows
 
 
-def _stage_cosines(hip_grads, g32, g64):
+def _stage_cosines_vs_fp64(hip_grads, g32, g64):
     """Per BACKWARD STAGE (params.FlatLayout.stage_of: fusion scale 4 first), over all tensors of the stage together: cosine of
     the HIP gradient and of the fp32 oracle's gradient to the fp64 gradient.  A systematic (non-noise) kernel error - a wrong
     scale, a dropped term, a transposed filter - moves the direction of a whole stage; rounding noise that the per-tensor
@@ -154,7 +154,7 @@ def _check_train_step(variant, B, n_lidar):
     assert wp_err <= 1e-4 * max(1.0, pred_ref.abs().max().item()), wp_err
     hip_grads = {n: p.grad for n, p in net.named_parameters()}
     _judge_gradients(_grad_report(hip_grads, grads_ref, g64), "%s B=%d" % (variant, B))
-    _judge_stage_cosines(_stage_cosines(hip_grads, grads_ref, g64), "%s B=%d" % (variant, B))
+    _judge_stage_cosines(_stage_cosines_vs_fp64(hip_grads, grads_ref, g64), "%s B=%d" % (variant, B))
     # one fused AdamW step from these gradients == torch.optim.AdamW on the oracle, on the elements whose gradient sign both
     # fp32 evaluations determine
     init = {k: v.detach().clone() for k, v in net.named_parameters()}
