@@ -66,6 +66,14 @@ int mmfn_wino_outgrad_bn_f32(const float* g, const float* y, const float* x, con
  * (+ res).  H, W multiples of 4; replaces cuDNN's backward-data for the BasicBlock 3x3 convolutions (model_vec.py:539-593). */
 int mmfn_wino_input_adjoint_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, void* stream);
 int mmfn_wino_wgrad_out_f32(const float* dU, float* dw, int Co, int Ci, void* stream);
+/* The 7x7 stride-2 stems (torchvision conv1, model_vec.py:509,515: 3 camera / 2 BEV channels) as explicit im2col + plain GEMM:
+ * col[B*OH*OW][KP] (fp32, or bf16 with out_bf16) = the zero-padded patch matrix of x [B,H,W,Cin] (fp32, Cin <= 4), k = (kh, kw, ci),
+ * columns K = KH*KW*Cin .. KP zero.  Forward = col . w_padded^T, weight gradient = dY^T . col (the same matrix, kept). */
+int mmfn_im2col_small(const float* x, void* col, int out_bf16, int B, int H, int W, int Cin, int KH, int KW, int stride, int pad,
+                      int KP, void* stream);
+/* rows of K fp32 values from pitch ps to pitch pd >= K (columns K..pd zero-filled; dst fp32, or bf16 with dst_bf16): the stem
+ * filter [Cout][K] -> [Cout][KP] for the GEMM above, and its padded gradient back to [Cout][K] */
+int mmfn_repitch_rows(const float* src, void* dst, int dst_bf16, int R, int K, int ps, int pd, void* stream);
 /* y = a*x + b*y (b == 0 ignores the old y) */
 int mmfn_axpby_f32(float* y, const float* x, float a, float b, int64_t n, void* stream);
 /* out = y > 0 ? g : 0  (ReLU backward) */

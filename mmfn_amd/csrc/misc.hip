@@ -176,3 +176,75 @@ extern "C" int mmfn_shadow_transpose_bf16(const void* table, int n_entries, int6
   MMFN_LAUNCH_CHECK();
   return 0;
 }
+
+// ---------------------------------------------------------------- the 7x7 stems as explicit im2col + plain GEMM
+// conv1 of the torchvision ResNets (model_vec.py:509,515: 7x7, stride 2, 3 camera / 2 BEV channels).  With K = 49 * Cin =
+// 147 / 98 the implicit-GEMM gather spends its time on per-element tap arithmetic (40 TF/s on the generic kernel); because Cin
+// is tiny the im2col matrix itself is cheap - [B*OH*OW][KP] is 2.5x the convolution's OUTPUT - and turns both the forward and
+// the weight gradient (which re-reads the same matrix) into plain tuned GEMMs.  KP = K rounded up to the GEMM's k-tile,
+// zero-filled, as are the taps that fall into the padding.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_small_kernel(const float* __restrict__ x, T* __restrict__ col, int B, int H, int W, int Cin,
+                                                           int OH, int OW, int KH, int KW, int stride, int pad, int K, int KP) {
+  const int kq = KP >> 2;
+  const int64_t total = (int64_t)B * OH * OW * kq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k4 = (int)(i % kq) * 4;
+    int64_t m = i / kq;
+    const int ow = (int)(m % OW); m /= OW;
+    const int oh = (int)(m % OH);
+    const int b = (int)(m / OH);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k4 + e;
+      if (k < K) {
+        const int tap = k / Cin, ci = k - tap * Cin;
+        const int kh = tap / KW, kw = tap - kh * KW;
+        const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v[e] = x[((size_t)(b * H + ih) * W + iw) * Cin + ci];
+      }
+    }
+    stx4(col + i * 4, v);
+  }
+}
+
+// dst[r][0..KP) = src[r][0..K) zero-padded (T out), or - unpad - dst[r][0..K) = src[r][0..K) out of rows of KP
+template <typename TI, typename TO>
+__global__ void repitch_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int R, int K, int ps, int pd) {
+  const int64_t total = (int64_t)R * pd;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / pd), k = (int)(i - (int64_t)r * pd);
+    if (k < K) stx1(dst + (size_t)r * pd + k, ldx1(src + (size_t)r * ps + k));
+    else if (k < pd) stx1(dst + (size_t)r * pd + k, 0.f);
+  }
+}
+}  // namespace
+
+extern "C" int mmfn_im2col_small(const float* x, void* col, int out_bf16, int B, int H, int W, int Cin, int KH, int KW, int stride,
+                                 int pad, int KP, void* stream) {
+  const int K = KH * KW * Cin;
+  if (!x || !col || KP < K || KP % 4 || Cin <= 0 || Cin > 4) return MMFN_EINVAL;
+  const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  const int64_t total = (int64_t)B * OH * OW * (KP / 4);
+  const int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
+  if (out_bf16)
+    hipLaunchKernelGGL(im2col_small_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)col, B, H, W, Cin, OH, OW,
+                       KH, KW, stride, pad, K, KP);
+  else
+    hipLaunchKernelGGL(im2col_small_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (float*)col, B, H, W, Cin, OH, OW, KH,
+                       KW, stride, pad, K, KP);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+/* rows of K fp32 values: pitch ps -> pitch pd (pd >= K; columns K..pd zero-filled); dst fp32 or bf16 */
+extern "C" int mmfn_repitch_rows(const float* src, void* dst, int dst_bf16, int R, int K, int ps, int pd, void* stream) {
+  if (!src || !dst || R <= 0 || K <= 0 || ps < K || pd < K) return MMFN_EINVAL;
+  const int blocks = (int)std::min<int64_t>(((int64_t)R * pd + 255) / 256, 4096);
+  if (dst_bf16) hipLaunchKernelGGL((repitch_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, R, K, ps, pd);
+  else hipLaunchKernelGGL((repitch_kernel<float, float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, R, K, ps, pd);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}

@@ -146,6 +146,37 @@ class ConvBN(object):
         self.conv_name = conv_name
         self.w16 = self.w16t = None   # bf16 shadows [Cout,KH,KW,Cin] / [Cin,KH,KW,Cout] (Engine._build_shadows, bf16 mode)
 
+    # ---- the 7x7 stems (3 / 2 input channels) as explicit im2col + plain GEMM (csrc/misc.hip: mmfn_im2col_small)
+    def is_stem(self):
+        return self.w.shape[3] <= 4 and ops.STEM_IM2COL
+
+    def stem_conv(self, ctx, x, co, stats=None):
+        """co [B,OH,OW,Cout] = conv(x) through the patch matrix, which is kept for the weight gradient (stem_wgrad)."""
+        Co, KH, KW, Ci = self.w.shape
+        K = KH * KW * Ci
+        M = co.numel() // Co
+        tile = 64 if co.dtype == torch.bfloat16 else 16
+        KP = (K + tile - 1) // tile * tile
+        col = ctx.bufs.get(self.name + ".col", (M, KP), co.dtype)
+        wp = ctx.bufs.get(self.name + ".wpad", (Co, KP), co.dtype)
+        ops.im2col_small(x, col, KH, KW, self.stride, self.pad)
+        ops.repitch_rows(self.w, wp, Co, K, K, KP)
+        if stats is not None:
+            ops.linear_fwd(col, wp, None, out=co.view(M, Co), stats=stats)
+        else:
+            ops.linear_fwd(col, wp, None, out=co.view(M, Co))
+        self.saved_col = col
+        return co
+
+    def stem_wgrad(self, ctx, dco):
+        Co, KH, KW, Ci = self.w.shape
+        K = KH * KW * Ci
+        col = self.saved_col
+        KP = col.shape[1]
+        dwp = ctx.bufs.get(self.name + ".dwpad", (Co, KP))
+        ops.linear_dw(dco.view(-1, Co), col, out=dwp)
+        ops.repitch_rows(dwp, self.gw, Co, K, KP, K)
+
     def fwd16(self, ctx, x, relu=True, res=None):
         """bf16 mode.  A trunk convolution (bf16 input): direct implicit GEMM on the bf16 MFMA pipe whose epilogue also emits
         the BatchNorm batch-statistics partial sums of its fp32 accumulators (no statistics pass over the output); a stem (fp32
@@ -155,11 +186,21 @@ class ConvBN(object):
         _, oshape = ops.conv_geom(x.shape, self.w.shape, self.stride, self.pad)
         M = oshape[0] * oshape[1] * oshape[2]
         stem = x.dtype == torch.float32
-        co = ctx.bufs.get(self.name + ".conv", oshape, torch.float32 if stem else ctx.adt)
+        col_stem = stem and self.is_stem()   # patch-matrix form: the stem joins the bf16 pipeline (bf16 conv output, statistics from the epilogue)
+        co = ctx.bufs.get(self.name + ".conv", oshape, torch.float32 if (stem and not col_stem) else ctx.adt)
         mean = ctx.bufs.get(self.name + ".mean", (self.cout,))
         rstd = ctx.bufs.get(self.name + ".rstd", (self.cout,))
         bn = self.bn
-        if stem:
+        if col_stem:
+            if ctx.training:
+                ws = ops.norm_workspace(x.device, 2 * ((M + 63) // 64) * 2 * self.cout * 8)
+                self.stem_conv(ctx, x, co, stats=ws)
+                rows = ops16.gemm_stats_rows(ops16.G16_NT, M, self.cout, self.saved_col.shape[1])
+                ops.bn_finalize_stats(ws, rows, M, self.cout, mean, rstd, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                      bn.eps, bn.momentum)
+            else:
+                self.stem_conv(ctx, x, co)
+        elif stem:
             if ctx.training:
                 ops.conv2d_fwd_bn_stats(x, self.w, self.stride, self.pad, co, mean, rstd, bn.running_mean, bn.running_var,
                                         bn.num_batches_tracked, bn.eps, bn.momentum)
@@ -198,8 +239,11 @@ class ConvBN(object):
         else:
             ops.bn_bwd(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.bn_w, dco.view(M, self.cout),
                        self.g_bn_w, self.g_bn_b, ge_out=None if ge_out is None else ge_out.view(M, self.cout))
-        if x.dtype == torch.float32:   # stem: fp32 weight gradient, no data gradient
-            ops.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, out=self.gw)
+        if x.dtype == torch.float32:   # stem: no data gradient
+            if self.is_stem():
+                self.stem_wgrad(ctx, dco)
+            else:
+                ops.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, out=self.gw)
             return None
         ops16.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, self.gw)
         if not need_dx:
@@ -250,7 +294,14 @@ class ConvBN(object):
         co2 = co.view(M, self.cout)
         mean = ctx.bufs.get(self.name + ".mean", (self.cout,))
         rstd = ctx.bufs.get(self.name + ".rstd", (self.cout,))
-        if ctx.training:
+        if self.is_stem():
+            self.stem_conv(ctx, x, co)
+            if ctx.training:
+                ops.bn_train_stats(co2, mean, rstd, self.bn.running_mean, self.bn.running_var, self.bn.num_batches_tracked, self.bn.eps,
+                                   self.bn.momentum)
+            else:
+                ops.bn_eval_prepare(self.bn.running_mean, self.bn.running_var, mean, rstd, self.bn.eps)
+        elif ctx.training:
             ops.conv2d_fwd_bn_stats(x, self.w, self.stride, self.pad, co, mean, rstd, self.bn.running_mean, self.bn.running_var,
                                     self.bn.num_batches_tracked, self.bn.eps, self.bn.momentum, keep_v=keep_v, keep_u=keep_u,
                                     u_ready=keep_u is not None and ctx.wino_in_table(self.name))
@@ -294,6 +345,9 @@ class ConvBN(object):
             dx = ctx.bufs.get(self.name + ".dx", x.shape)
             ops.conv2d_bwd_winograd(dco, x, u, self.gw, dx, v=getattr(self, "saved_v", None), res=dx_res)
             return dx
+        if self.is_stem() and not need_dx:
+            self.stem_wgrad(ctx, dco)
+            return None
         ops.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, out=self.gw, v=getattr(self, "saved_v", None))
         if not need_dx:
             return None

@@ -1050,3 +1050,18 @@ def make_shadow_table(entries, device):
 
 def shadow_transpose(table, n, total):
     _call("mmfn_shadow_transpose_bf16", ptr(table), n, total, stream())
+
+
+# ---------------------------------------------------------------- 7x7 stems: explicit im2col + plain GEMM
+STEM_IM2COL = os.environ.get("MMFN_STEM_IM2COL", "1") == "1"   # A/B switch (engine.ConvBN stems)
+
+
+def im2col_small(x, col, kh, kw, stride, pad):
+    B, H, W, Cin = x.shape
+    _call("mmfn_im2col_small", ptr(x), ptr(col), 1 if col.dtype == BF16 else 0, B, H, W, Cin, kh, kw, stride, pad, col.shape[1], stream())
+    return col
+
+
+def repitch_rows(src, dst, R, K, ps, pd):
+    _call("mmfn_repitch_rows", ptr(src), ptr(dst), 1 if dst.dtype == BF16 else 0, R, K, ps, pd, stream())
+    return dst
