@@ -502,9 +502,19 @@ bool tile_kernels_only() {
   return v;
 }
 
+// MMFN_ATTN16=0: bf16 tensors through the fp32-arithmetic workgroup kernels instead (A/B runs, tests)
+bool bf16_mfma_off() {
+  static const bool v = [] { const char* e = getenv("MMFN_ATTN16"); return e && e[0] == '0'; }();
+  return v;
+}
+
 int dispatch(int which, int hs, const AttnArgs& a, hipStream_t s) {
   if (a.B <= 0 || a.T <= 0 || a.T > 256 || a.NH <= 0) return MMFN_EINVAL;
   if ((a.ld & 3) || (a.ldo & 3) || ((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.v & 15)) return MMFN_EINVAL;
+  if (a.io_bf16 && !bf16_mfma_off()) {   // bf16 mode: bf16 MFMA kernels (attention16.hip)
+    const int rc = mmfn_attn16_launch(which, hs, a, s);
+    if (rc >= 0) return rc;
+  }
   if ((!tile_kernels_only() || a.io_bf16) && !(a.ldg & 3)) {
     // T = 64 / 128 / 192 (the fusion transformers: 192 tokens): one workgroup per (sample, head, half), attention_wg.hip
     const int rc = mmfn_attn_wg_launch(which, hs, a, s);

@@ -22,3 +22,5 @@ struct AttnArgs {
 // attention_wg.hip.  which: 0 forward, 1 backward dQ (+delta), 2 backward dK/dV.  Returns -1 when the shape is not
 // covered by the workgroup-per-half kernels (the caller then uses the tile kernels of attention.hip).
 int mmfn_attn_wg_launch(int which, int hs, const AttnArgs& a, hipStream_t s);
+// attention16.hip: the bf16 mode's kernels (bf16 I/O AND bf16 MFMA, fp32 softmax / accumulation); T = 64 / 128 / 192.  -1 = not covered.
+int mmfn_attn16_launch(int which, int hs, const AttnArgs& a, hipStream_t s);
