@@ -16,7 +16,10 @@
 //     ds_read_b64_tr_b16, the gfx950 LDS transpose read: no cross-lane traffic, no second LDS image;
 //   * one slot swizzle serves both read kinds of a staged matrix (row fragments by ds_read_b128, transposed fragments by
 //     tr_b16): slot ^= ((row & 3) << 2) | ((row >> 2) & 3) at head size 128, its analogues below.
-// Dropout (attn_pdrop) uses the engine's counter RNG at index ((b * NH + h) * T + query) * T + key in all three kernels.
+// Dropout (attn_pdrop): the keep mask of element (b, h, query, key) is a 32-bit hash (lowbias32) of query * T + key, salted per
+// (rng state, stream, b, h) - the same function in all three kernels.  (The engine's 64-bit splitmix counter RNG costs ~25
+// integer instructions per element, a dozen of them quarter-rate multiplies: 96 elements per lane made it a third of the
+// backward's time at these shapes; two 32-bit multiplies are enough for a dropout mask.)
 #include <stdlib.h>
 
 #include "attention_args.h"
@@ -77,6 +80,30 @@ __device__ __forceinline__ bf16x8 trfrag(const unsigned char* m, int col0, int k
   }
   return out;
 }
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {   // lowbias32
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+struct Drop {
+  uint32_t salt, thresh;
+  float inv_keep;
+  bool on;
+  __device__ __forceinline__ void init(const AttnArgs& a, int b, int hd) {
+    on = a.drop_p > 0.f;
+    salt = 0; thresh = 0; inv_keep = 1.f;
+    if (on) {
+      const uint64_t k = mmfn_rng_key(a.rng_state, a.rng_stream) + (uint64_t)(b * a.NH + hd) * 0x9E3779B97F4A7C15ull;
+      salt = hash32((uint32_t)k ^ hash32((uint32_t)(k >> 32)));
+      thresh = (uint32_t)fminf(a.drop_p * 4294967296.0f, 4294967040.0f);
+      inv_keep = 1.0f / (1.0f - a.drop_p);
+    }
+  }
+  // keep-scale of element (query, key): 0 or 1 / (1 - p)
+  __device__ __forceinline__ float scale(int query, int key, int T) const {
+    return hash32((uint32_t)(query * T + key) ^ salt) >= thresh ? inv_keep : 0.f;
+  }
+};
 
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
   bf16x8 o;
@@ -172,14 +199,13 @@ __global__ __launch_bounds__(64 * NQT) void attn16_fwd_kernel(const AttnArgs a) 
     }
   sum = xhalf_sum(sum);
   if (a.lse && h == 0) a.lse[((size_t)id.b * a.NH + id.hd) * T + query] = mx + logf(sum);
-  if (a.drop_p > 0.f) {
-    const uint64_t key64 = mmfn_rng_key(a.rng_state, a.rng_stream);
-    const float inv_keep = 1.0f / (1.0f - a.drop_p);
-    const uint64_t base = (((uint64_t)id.b * a.NH + id.hd) * T + query) * T;
+  Drop dr;
+  dr.init(a, id.b, id.hd);
+  if (dr.on) {
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] *= mmfn_dropout_scale(key64, base + kt * 32 + accrow(r, h), a.drop_p, inv_keep);
+      for (int r = 0; r < 16; ++r) s[kt][r] *= dr.scale(query, kt * 32 + accrow(r, h), T);
   }
   f32x16 o[ND];
 #pragma unroll
@@ -232,11 +258,8 @@ __global__ __launch_bounds__(64 * NQT) void attn16_dq_kernel(const AttnArgs a) {
   __builtin_amdgcn_s_waitcnt(0x0070);
   __syncthreads();
   const int kvlen = a.kv_len ? min(T, a.kv_len[id.b]) : T;
-  const bool drop = a.drop_p > 0.f;
-  uint64_t key64 = 0;
-  float inv_keep = 1.f;
-  if (drop) { key64 = mmfn_rng_key(a.rng_state, a.rng_stream); inv_keep = 1.0f / (1.0f - a.drop_p); }
-  const uint64_t base = (((uint64_t)id.b * a.NH + id.hd) * T + query) * T;
+  Drop dr;
+  dr.init(a, id.b, id.hd);
   f32x16 dq[ND];
 #pragma unroll
   for (int dt = 0; dt < ND; ++dt)
@@ -257,7 +280,7 @@ __global__ __launch_bounds__(64 * NQT) void attn16_dq_kernel(const AttnArgs a) {
       const int key = kt * 32 + accrow(r, h);
       const float p = kvlen <= 0 ? 1.0f / (float)T : (key < kvlen ? mmfn_exp(s[r] * a.scale - lse) : 0.f);
       float g = dp[r];
-      if (drop) g *= mmfn_dropout_scale(key64, base + key, a.drop_p, inv_keep);
+      if (dr.on) g *= dr.scale(query, key, T);
       s[r] = (kvlen <= 0 ? 0.f : p * (g - delta)) * a.scale;   // (no valid key: the scores are constants, no gradient reaches q / k)
     }
 #pragma unroll
@@ -277,6 +300,7 @@ __global__ __launch_bounds__(64 * NQT) void attn16_dkv_kernel(const AttnArgs a) 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Qs = smem;
   unsigned char* Gs = smem + T * HS * 2;   // dO
+  float* stats = reinterpret_cast<float*>(smem + 2 * T * HS * 2);   // [2][T]: lse, delta of every query (read 16 + 16 times per tile per lane)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   const Ids id = block_ids(a.NH, NKT / NQT);
   const size_t rowbase = (size_t)id.b * T;
@@ -286,6 +310,11 @@ __global__ __launch_bounds__(64 * NQT) void attn16_dkv_kernel(const AttnArgs a) 
   const bf16_t* dO = reinterpret_cast<const bf16_t*>(a.dO) + rowbase * a.ldo + id.hd * HS;
   stage<HS, T, NQT>(q, a.ld, Qs, wave, lane);
   stage<HS, T, NQT>(dO, a.ldo, Gs, wave, lane);
+  const size_t stat0 = ((size_t)id.b * a.NH + id.hd) * T;
+  for (int t = threadIdx.x; t < T; t += 64 * NQT) {
+    stats[t] = a.lse[stat0 + t];
+    stats[T + t] = a.delta[stat0 + t];
+  }
   const int key = (id.part * NQT + wave) * 32 + l31;
   bf16x8 kf[NKS], vf[NKS];
 #pragma unroll
@@ -297,11 +326,8 @@ __global__ __launch_bounds__(64 * NQT) void attn16_dkv_kernel(const AttnArgs a) 
   __syncthreads();
   const int kvlen = a.kv_len ? min(T, a.kv_len[id.b]) : T;
   const bool valid = key < kvlen;
-  const bool drop = a.drop_p > 0.f;
-  uint64_t key64 = 0;
-  float inv_keep = 1.f;
-  if (drop) { key64 = mmfn_rng_key(a.rng_state, a.rng_stream); inv_keep = 1.0f / (1.0f - a.drop_p); }
-  const size_t stat0 = ((size_t)id.b * a.NH + id.hd) * T;
+  Drop dr;
+  dr.init(a, id.b, id.hd);
   f32x16 dk[ND], dv[ND];
 #pragma unroll
   for (int dt = 0; dt < ND; ++dt)
@@ -321,10 +347,10 @@ __global__ __launch_bounds__(64 * NQT) void attn16_dkv_kernel(const AttnArgs a) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int query = qt * 32 + accrow(r, h);
-      const float lse = a.lse[stat0 + query], delta = a.delta[stat0 + query];
+      const float lse = stats[query], delta = stats[T + query];
       const float p = kvlen <= 0 ? 1.0f / (float)T : (valid ? mmfn_exp(s[r] * a.scale - lse) : 0.f);
       float m = 1.f;
-      if (drop) m = mmfn_dropout_scale(key64, ((uint64_t)(stat0 + query)) * T + key, a.drop_p, inv_keep);
+      if (dr.on) m = dr.scale(query, key, T);
       pd[r] = p * m;
       s[r] = (kvlen <= 0 ? 0.f : p * (dp[r] * m - delta)) * a.scale;
     }
@@ -345,7 +371,7 @@ __global__ __launch_bounds__(64 * NQT) void attn16_dkv_kernel(const AttnArgs a) 
 template <int HS, int NKT>
 int launch16(int which, const AttnArgs& a, hipStream_t s) {
   constexpr int NQT = (NKT % 2 == 0) ? NKT / 2 : NKT;
-  constexpr int smem = 2 * 32 * NKT * HS * 2;
+  constexpr int smem = 2 * 32 * NKT * HS * 2 + 2 * 32 * NKT * 4;   // two staged matrices (+ lse / delta in the key-owned pass)
   const dim3 grid(a.B * a.NH * (NKT / NQT)), block(64 * NQT);
   static bool ready[3] = {false, false, false};
   const void* fn = which == 0 ? reinterpret_cast<const void*>(&attn16_fwd_kernel<HS, NKT, NQT>)
