@@ -71,17 +71,25 @@ import json
 fetch = glob.glob(os.path.join(out, "pmc_fetch*counter_collection.csv"))
 write = glob.glob(os.path.join(out, "pmc_write*counter_collection.csv"))
 if fetch and write:
-    def fam(fname, cname):
+    FAMILY = os.environ.get("PROFILE_FAMILY", "gemm_f32")   # "gemm16" for the bf16 mode
+
+    def fam(fname, cname, every=False):
         tot, ids = 0.0, set()
         for r in csv.DictReader(open(fname)):
-            if "gemm_f32" in r["Kernel_Name"] and r["Counter_Name"] == cname:
+            if (every or FAMILY in r["Kernel_Name"]) and r["Counter_Name"] == cname:
                 tot += float(r["Counter_Value"])
                 ids.add(r["Dispatch_Id"])
         return tot, len(ids)
     f, nf = fam(fetch[0], "FETCH_SIZE")
     w, nw = fam(write[0], "WRITE_SIZE")
+    fa, _ = fam(fetch[0], "FETCH_SIZE", True)
+    wa, _ = fam(write[0], "WRITE_SIZE", True)
+    STEPS = 4   # the SHORT command: 2 sizing steps + 1 timed + 1 instrumented
     rec = {
-        "kernel_family": "gemm_f32_kernel / gemm_f32_fast_kernel", "launches_profiled": nf,
+        "kernel_family": FAMILY + "*", "launches_profiled": nf,
+        # every kernel of the run (model construction included: a few hundred MB once), per train step
+        "whole_step_hbm_bytes": (2.0 * fa + wa) * 1024.0 / STEPS, "whole_step_fetch_bytes_corrected": 2.0 * fa * 1024.0 / STEPS,
+        "whole_step_write_bytes": wa * 1024.0 / STEPS, "steps_profiled": STEPS,
         "fetch_bytes_per_launch_raw": f * 1024.0 / max(nf, 1),
         "fetch_bytes_per_launch_corrected": 2.0 * f * 1024.0 / max(nf, 1),
         "write_bytes_per_launch": w * 1024.0 / max(nw, 1),
