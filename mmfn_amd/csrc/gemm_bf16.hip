@@ -192,17 +192,22 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #pragma unroll
-  for (int s = 0; s < D; ++s) stage(s, s);
+  for (int s = 0; s < D; ++s)
+    if (s < nkt) stage(s, s);
   int cur = 0, nxt = D;
   if (NS == 2) {
     MMFN_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
   }
   for (int kt = 0; kt < nkt; ++kt) {
-    stage(kt + D, nxt);
+    // tiles kt+1 .. kt+D stay in flight; near the end fewer exist and the (immediate) wait count shrinks with them
+    const int ahead = nkt - 1 - kt;
+    if (ahead >= D) stage(kt + D, nxt);
     if (NS > 2) {
-      MMFN_WAIT_VMCNT((PA + PB) * D);     // this wave's pieces of tile kt have landed ...
-      __builtin_amdgcn_s_barrier();       // ... and everybody else's
+      if (ahead >= D) MMFN_WAIT_VMCNT((PA + PB) * D);     // this wave's pieces of tile kt have landed ...
+      else if (D > 1 && ahead == 1) MMFN_WAIT_VMCNT(PA + PB);
+      else MMFN_WAIT_VMCNT(0);
+      __builtin_amdgcn_s_barrier();                       // ... and everybody else's
     }
     const unsigned char* As = smem + cur * STAGE;
     const unsigned char* Bs = As + BM * 128;
@@ -235,7 +240,6 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
       __builtin_amdgcn_s_barrier();
     }
   }
-  MMFN_WAIT_VMCNT(0);   // the trailing dummy pieces
   __syncthreads();      // nobody still reads operands: the stages become the epilogue's staging area
 
   // ---- epilogue: accumulators -> LDS (fp32, one region per wave) -> 8 consecutive columns per lane
@@ -482,16 +486,20 @@ __global__ __launch_bounds__(NT) void gemm16_tn_kernel(const mmfn_gemm16_desc d,
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #pragma unroll
-  for (int s = 0; s < D; ++s) stage(kt_begin + s, s);
+  for (int s = 0; s < D; ++s)
+    if (kt_begin + s < kt_end) stage(kt_begin + s, s);
   int cur = 0, nxt = D;
   if (NS == 2) {
     MMFN_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
   }
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    stage(kt + D, nxt);
+    const int ahead = kt_end - 1 - kt;
+    if (ahead >= D) stage(kt + D, nxt);
     if (NS > 2) {
-      MMFN_WAIT_VMCNT((PA + PB) * D);
+      if (ahead >= D) MMFN_WAIT_VMCNT((PA + PB) * D);
+      else if (D > 1 && ahead == 1) MMFN_WAIT_VMCNT(PA + PB);
+      else MMFN_WAIT_VMCNT(0);
       __builtin_amdgcn_s_barrier();
     }
     const unsigned char* As = smem + cur * STAGE;
@@ -517,7 +525,6 @@ __global__ __launch_bounds__(NT) void gemm16_tn_kernel(const mmfn_gemm16_desc d,
       __builtin_amdgcn_s_barrier();
     }
   }
-  MMFN_WAIT_VMCNT(0);
   // fp32 output (a gradient) or a split slab; 32 consecutive columns per store instruction
   const bool to_slab = gridDim.y > 1;
   float* out = to_slab ? d.workspace + (size_t)blockIdx.y * d.M * d.N : reinterpret_cast<float*>(d.C);

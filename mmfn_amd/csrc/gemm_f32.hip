@@ -603,11 +603,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
   // is applied to the SOURCE address); otherwise through registers (issue now, ds_write after the MFMAs).
   auto stage_issue = [&](int kt, float* dst) {
     if (USE_GLDS) {
-      const bool live = kt < kt_end;   // past the end: the same number of (dummy) pieces, so the counted waits stay constant
 #pragma unroll
-      for (int i = 0; i < UA; ++i) glds16(live ? src_a(i, kt) : zero, dst + (i * NT + wave * 64) * 4);
+      for (int i = 0; i < UA; ++i) glds16(src_a(i, kt), dst + (i * NT + wave * 64) * 4);
 #pragma unroll
-      for (int i = 0; i < UB; ++i) glds16(live ? src_b(i, kt) : zero, dst + A_ELEMS + (i * NT + wave * 64) * 4);
+      for (int i = 0; i < UB; ++i) glds16(src_b(i, kt), dst + A_ELEMS + (i * NT + wave * 64) * 4);
     } else {
 #pragma unroll
       for (int i = 0; i < UA; ++i) ra[i] = ld4(src_a(i, kt));
@@ -627,7 +626,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
   constexpr int STG = A_ELEMS + B_ELEMS;
   if (NS > 2) {
 #pragma unroll
-    for (int s = 0; s < D; ++s) stage_issue(kt_begin + s, smem + s * STG);
+    for (int s = 0; s < D; ++s)
+      if (kt_begin + s < kt_end) stage_issue(kt_begin + s, smem + s * STG);
   } else {
     if (kt_begin < kt_end) {
       stage_issue(kt_begin, smem);
@@ -640,9 +640,13 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const bool more = (kt + 1 < kt_end);
     if (NS > 2) {
-      stage_issue(kt + D, smem + nxt * STG);
-      MMFN_WAIT_VMCNT((UA + UB) * D);   // this wave's pieces of tile kt have landed ...
-      __builtin_amdgcn_s_barrier();     // ... and everybody else's
+      // tiles kt+1 .. kt+D stay in flight; near the end fewer exist, and the (immediate) wait count shrinks with them
+      const int ahead = kt_end - 1 - kt;            // tiles after kt
+      if (ahead >= D) stage_issue(kt + D, smem + nxt * STG);
+      if (ahead >= D) MMFN_WAIT_VMCNT((UA + UB) * D);   // this wave's pieces of tile kt have landed ...
+      else if (D > 1 && ahead == 1) MMFN_WAIT_VMCNT(UA + UB);
+      else MMFN_WAIT_VMCNT(0);
+      __builtin_amdgcn_s_barrier();                 // ... and everybody else's
     } else if (more) {
       stage_issue(kt + 1, smem + (cur ^ 1) * STG);
     }
@@ -690,7 +694,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
       cur ^= 1;
     }
   }
-  if (NS > 2) MMFN_WAIT_VMCNT(0);   // the trailing dummy pieces must not land in LDS after the block has gone
 
   uint64_t key = 0;
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
