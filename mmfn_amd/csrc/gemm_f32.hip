@@ -409,7 +409,10 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 }
 
 #ifndef MMFN_F32_STAGES
-#define MMFN_F32_STAGES 3
+#define MMFN_F32_STAGES 3         // 128-row / 128-column tiles
+#endif
+#ifndef MMFN_F32_STAGES_SMALL
+#define MMFN_F32_STAGES_SMALL 3   // 64x64 tiles (8 KB per stage)
 #endif
 // vmcnt(n) only (expcnt / lgkmcnt untouched): gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
 #define MMFN_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x70 | 0xF00)
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
   // tiles each (1-3 blocks per CU) with 36-288 k-tiles, so it is the depth of each block's operand stream, not occupancy,
   // that hides the L2 / HBM latency (wait_inst 0.6 of the wave cycles on the double-buffered form, profiles/r02d_pmc.txt).
   // The stage overwritten in iteration kt was last read in iteration kt-2, two barriers back.  NS = 2: the double buffer.
-  constexpr int NS = USE_GLDS ? MMFN_F32_STAGES : 2;
+  constexpr int NS = USE_GLDS ? ((BM == 64 && BN == 64) ? MMFN_F32_STAGES_SMALL : MMFN_F32_STAGES) : 2;
   constexpr int D = NS == 2 ? 1 : NS - 2;
   __shared__ __attribute__((aligned(16))) float smem[NS * (A_ELEMS + B_ELEMS)];
 
