@@ -26,9 +26,12 @@ PY
   rm -rf $OUT/tr_$name
   echo "$name: $(cut -c1-200 $OUT/${TAG}_$name.json)"
 }
-run rad_b16_65536 --variant rad --batch 16 --n-lidar 65536
+run rad_b16_65536 --config rad16
 run img_b32 --variant img
-run image_only_b128 --workload image-only --batch 128
-run bf16_b32 --dtype bf16
+run image_only_b128 --config img128
+run bf16_b32 --config bf16
+run bf16_img_b32 --dtype bf16 --variant img
+run bf16_image_only_b128 --dtype bf16 --config img128
+run bf16_operands_b32 --dtype bf16-operands
 run vec_19x8 --lane-format 19x8
 MMFN_F32X3=1 run vec_f32x3
