@@ -103,6 +103,11 @@ class ImageBranchOnly(object):
         return pooled
 
 
+def default_like_bf16(args, B):
+    """True when the run is the workload the committed bf16 traffic profile was taken on."""
+    return (args.workload == "train" and args.variant == "vec" and B == 32 and args.n_lidar == 16384 and args.lane_format == "10x5")
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box
     reports 256 logical CPUs but grants a 16-CPU quota; oversubscribing it stalls oneDNN for minutes)."""
@@ -631,6 +636,22 @@ def main():
                                "operands are read as fp32 from HBM (4 B/element), so these GEMMs are HBM/LDS-bound long before the "
                                "2.5 PFLOP/s bf16 MFMA peak; see DESIGN.md section 7")})
             if args.dtype == "bf16":
+                # this mode is HBM / launch bound, not MFMA bound - the second roofline.  Measured bytes: rocprofv3
+                # FETCH_SIZE (x2, the guide's gfx950 correction) + WRITE_SIZE over every kernel of a step (tools/profile_round.sh
+                # with EXTRA="--dtype bf16"); algorithmic bytes: SURVEY 8d's activation estimate (317 MB/sample saved in fp32
+                # -> write + read, halved for bf16) + parameter traffic (bf16 shadows read twice, their derivation, fp32
+                # gradients written, AdamW 28 B/param)
+                hb = sorted(glob.glob(os.path.join(ROOT, "profiles", "*bf16_traffic.json")))
+                measured = json.load(open(hb[-1])).get("whole_step_hbm_bytes") if hb and default_like_bf16(args, B) else None
+                algo = B * 317e6 * 2 / 2 + (2 * 210e6 + 419e6 + 382e6 + 419e6 + 2.93e9)
+                r["hbm_roofline"] = {
+                    "bound": "hbm", "peak": 8.0, "unit": "TB/s",
+                    "algorithmic_bytes_per_step": round(algo), "achieved_algorithmic": round(algo / (ms_per_step * 1e-3) / 1e12, 3),
+                    "frac_algorithmic": round(algo / (ms_per_step * 1e-3) / 8e12, 4),
+                    "measured_bytes_per_step": None if measured is None else round(measured),
+                    "achieved_measured": None if measured is None else round(measured / (ms_per_step * 1e-3) / 1e12, 3),
+                    "frac_measured": None if measured is None else round(measured / (ms_per_step * 1e-3) / 8e12, 4),
+                    "traffic_source": os.path.basename(hb[-1]) if (hb and measured is not None) else None}
                 r["mode"] = dict(dtype_detail="bf16 activations / saved tensors / weight shadows in HBM; fp32 accumulation, BatchNorm and "
                                               "LayerNorm statistics, master weights, gradients, AdamW, loss head, VectorNet and the two 7x7 stems")
             for k in ("executed_gflop_per_step", "executed_tflops", "algorithmic_bytes_per_launch"):
