@@ -95,7 +95,7 @@ class ImageBranchOnly(object):
         for li in range(1, 5):
             f = eng.img.layer_fwd(ctx, li, f)
         pooled = ops.gap_sum_fwd([f], bufs.get("fused", (B, 512)))
-        g = bufs.get("G3.0", f.shape)
+        g = bufs.get("G3.0", f.shape, f.dtype)   # (bf16 in the bf16 mode)
         ops.gap_sum_bwd(self.gseed, [g])
         for li in range(4, 0, -1):
             g = eng.img.layer_bwd(ctx, li, g)

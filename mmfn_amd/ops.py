@@ -727,6 +727,8 @@ def bn_apply(x2d, y2d, mean, rstd, weight, bias, relu, res=None):
 
 def bn_bwd(g2d, y2d, x2d, mean, rstd, weight, dx, dweight, dbias, ge_out=None):
     M, C = x2d.shape
+    if g2d.dtype != BF16 and (x2d.dtype == BF16 or (y2d is not None and y2d.dtype == BF16)):
+        raise TypeError("bn_bwd: fp32 output gradient with bf16 activations (every activation-side tensor of the bf16 mode is bf16)")
     if g2d.dtype == BF16:   # x / dx: bf16, or both fp32 (stems)
         assert dx.dtype == x2d.dtype
         _call("mmfn_bn_bwd_bf16", ptr(g2d), ptr(y2d), ptr(x2d), 0 if x2d.dtype == BF16 else 1, M, C, ptr(mean), ptr(rstd), ptr(weight),
