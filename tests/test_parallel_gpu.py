@@ -130,15 +130,17 @@ def test_single_graph_data_parallel_step_with_captured_collectives():
     assert torch.equal(outs[0][0], outs[1][0])
 
 
-def test_bench_launches_its_own_ranks():
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_bench_launches_its_own_ranks(dtype):
     """`python bench.py --gpus 2` with no outer launcher (how the driver starts the single-GPU bench): bench.py starts the two
     ranks itself and rank 0 prints the JSON line with the `comm` block.  One GPU here, so both ranks share cuda:0 over gloo
-    (MMFN_BENCH_SINGLE_DEVICE); on a multi-GPU node the same command runs one rank per GPU over RCCL."""
+    (MMFN_BENCH_SINGLE_DEVICE); on a multi-GPU node the same command runs one rank per GPU over RCCL.  dtype bf16 = BASELINE
+    configs[2]'s arithmetic (bf16 training mode, 32 samples per rank) on the data-parallel path."""
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(MMFN_BENCH_SINGLE_DEVICE="1", OMP_NUM_THREADS="4")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-           "--no-oracle-check", "--profile-steps", "1"]
+           "--no-oracle-check", "--profile-steps", "1", "--dtype", dtype]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
@@ -146,6 +148,7 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, tail
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 64 and rec["value"] > 0 and rec["scaling"] == "weak"
+    assert rec["dtype"] == dtype
     c = rec["comm"]
     assert c["ranks"] == 2 and c["buckets"] >= 10 and c["ranks_in_lock_step"] is True and c["exposed_ms_per_step"] >= 0.0
     assert c["allreduce_bytes_per_step"] > 400e6 and rec["config"]["hipgraph"] is True
