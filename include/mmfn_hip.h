@@ -279,31 +279,38 @@ int mmfn_colsum_batched_f32(const float* in, int batch, int64_t stride_in, int64
 /* MaxPool2d(3,2,1) with first-max argmax (uint8 tap index) — torchvision stem (model_vec.py:512,518) */
 int mmfn_maxpool3x3s2_fwd_f32(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
 int mmfn_maxpool3x3s2_bwd_f32(const float* gy, const uint8_t* idx, float* gx, int B, int H, int W, int C, void* stream);
-/* tok[b, m*64+a, :] = dropout(pos_emb + AdaptiveAvgPool2d(8,8)(F_m)[b,a,:] + vel_emb(velocity[b]))
- * for n_modal feature maps F_m[B,S,S,C]: model_vec.py:527-529 + GPT.forward :223-235 in one pass. */
-int mmfn_tokens_fwd_f32(const float* const* feats, int n_modal, int B, int S, int C, const float* pos, const float* vel_w,
+/* tok[b, g*64+a, :] = dropout(pos_emb + AdaptiveAvgPool2d(8,8)(frame g of sample b)[a,:] + vel_emb(velocity[b]))
+ * for n_modal feature maps F_m[B*frames[m],S,S,C]: model_vec.py:527-529 + GPT.forward :223-235 in one pass.  A token
+ * group g is one frame: the frames[0] frames of modality 0 (n_views*seq_len camera frames per sample), then the
+ * frames[1] of modality 1 (seq_len LiDAR frames), ... in the order GPT.forward concatenates them (:226-231).
+ * frames == NULL: one frame per modality (seq_len = n_views = 1), group of modality m = m. */
+int mmfn_tokens_fwd_f32(const float* const* feats, int n_modal, const int32_t* frames, int B, int S, int C, const float* pos, const float* vel_w,
                         const float* vel_b, const float* velocity, float* tok, float drop_p, const uint64_t* rng_state,
                         uint32_t rng_stream, void* stream);
 int64_t mmfn_tokens_bwd_workspace_bytes(int T, int C);
 /* in place: gtok *= dropout mask; dpos[T,C], dvel_w[C], dvel_b[C] */
 int mmfn_tokens_bwd_f32(float* gtok, int B, int T, int C, const float* velocity, float* dpos, float* dvel_w, float* dvel_b,
                         float drop_p, const uint64_t* rng_state, uint32_t rng_stream, void* workspace, void* stream);
-/* out = feat + bilinear_upsample(align_corners=True)(tok[:, m*64:(m+1)*64, :] as 8x8xC)   (model_vec.py:531-536) */
-int mmfn_upsample_add_fwd_f32(const float* feat, const float* tok, float* out, int B, int S, int C, int T, int m,
+/* The next three work on one modality: B = its frames over the whole batch (samples * frames), frame i belongs to sample
+ * i / frames and owns token group m + i % frames (m = the modality's first group, `frames` = its frames per sample;
+ * seq_len = n_views = 1: frames = 1 and m = the modality index).
+ * out = feat + bilinear_upsample(align_corners=True)(the frame's 64 tokens as 8x8xC)   (model_vec.py:531-536) */
+int mmfn_upsample_add_fwd_f32(const float* feat, const float* tok, float* out, int B, int S, int C, int T, int m, int frames,
                               void* stream);
-/* adjoint of the upsample: gtok[:, m*64+a, :] = sum_pixels w(a,pixel) G[b,pixel,:] */
-int mmfn_upsample_adj_f32(const float* G, float* gtok, int B, int S, int C, int T, int m, void* stream);
-/* dF = G + avgpool-adjoint(gtok[:, m*64.., :]) */
-int mmfn_pool_bcast_add_f32(const float* G, const float* gtok, float* dF, int B, int S, int C, int T, int m, void* stream);
-/* out[b,c] = sum_m mean_p feats[m][b,p,c]   (model_vec.py:585-596) and its backward */
-int mmfn_gap_sum_fwd_f32(const float* const* feats, int n, int B, int P, int C, float* out, void* stream);
-int mmfn_gap_sum_bwd_f32(const float* g, float* const* outs, int n, int B, int P, int C, void* stream);
+/* adjoint of the upsample: gtok[sample, group*64+a, :] = sum_pixels w(a,pixel) G[i,pixel,:] */
+int mmfn_upsample_adj_f32(const float* G, float* gtok, int B, int S, int C, int T, int m, int frames, void* stream);
+/* dF = G + avgpool-adjoint(the frame's 64 token gradients) */
+int mmfn_pool_bcast_add_f32(const float* G, const float* gtok, float* dF, int B, int S, int C, int T, int m, int frames, void* stream);
+/* out[b,c] = sum_m sum_frames mean_p feats[m][b*frames[m]+j,p,c]   (model_vec.py:585-596) and its backward; B = samples,
+ * frames as in mmfn_tokens_fwd_f32 */
+int mmfn_gap_sum_fwd_f32(const float* const* feats, int n, const int32_t* frames, int B, int P, int C, float* out, void* stream);
+int mmfn_gap_sum_bwd_f32(const float* g, float* const* outs, int n, const int32_t* frames, int B, int P, int C, void* stream);
 /* in[B,R,Cc] -> out[B,Cc,R] */
 int mmfn_transpose_f32(const float* in, float* out, int B, int R, int Cc, void* stream);
 
 /* ---- fused attention --------------------------------------------------------------------- */
 /* o = softmax(q k^T * scale [keys >= kv_len[b] masked]) (dropout) v per (batch, head); q/k/v rows
- * have stride ld, head h at columns [h*HS, (h+1)*HS); T <= 256, HS in {16,32,64,128}.
+ * have stride ld, head h at columns [h*HS, (h+1)*HS); T <= 384, HS in {16,32,64,128}.
  * Replaces the bmm/softmax/dropout/bmm + transposes of SelfAttention.forward (model_vec.py:96-105)
  * and MaskSelfAttention.forward (model_vec.py:308-322).  lse[B,NH,T] is saved for the backward. */
 int mmfn_attention_fwd_f32(const float* q, const float* k, const float* v, int ld, float* o, int ldo, float* lse, int B,
@@ -408,16 +415,16 @@ int mmfn_bn_bwd_partials_bf16(const double* partials, int rows, const void* g, c
                               float* dbias, void* workspace, void* stream);
 int mmfn_maxpool3x3s2_fwd_bf16(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
 int mmfn_maxpool3x3s2_bwd_bf16(const void* gy, const uint8_t* idx, void* gx, int B, int H, int W, int C, void* stream);
-int mmfn_tokens_fwd_bf16(const void* const* feats, int n_modal, int B, int S, int C, const float* pos, const float* vel_w,
+int mmfn_tokens_fwd_bf16(const void* const* feats, int n_modal, const int32_t* frames, int B, int S, int C, const float* pos, const float* vel_w,
                          const float* vel_b, const float* velocity, void* tok, float drop_p, const uint64_t* rng_state,
                          uint32_t rng_stream, void* stream);
 int mmfn_tokens_bwd_bf16(void* gtok, int B, int T, int C, const float* velocity, float* dpos, float* dvel_w, float* dvel_b,
                          float drop_p, const uint64_t* rng_state, uint32_t rng_stream, void* workspace, void* stream);
-int mmfn_upsample_add_fwd_bf16(const void* feat, const void* tok, void* out, int B, int S, int C, int T, int m, void* stream);
-int mmfn_upsample_adj_bf16(const void* G, void* gtok, int B, int S, int C, int T, int m, void* stream);
-int mmfn_pool_bcast_add_bf16(const void* G, const void* gtok, void* dF, int B, int S, int C, int T, int m, void* stream);
-int mmfn_gap_sum_fwd_bf16(const void* const* feats, int n, int B, int P, int C, float* out, void* stream);
-int mmfn_gap_sum_bwd_bf16(const float* g, void* const* outs, int n, int B, int P, int C, void* stream);
+int mmfn_upsample_add_fwd_bf16(const void* feat, const void* tok, void* out, int B, int S, int C, int T, int m, int frames, void* stream);
+int mmfn_upsample_adj_bf16(const void* G, void* gtok, int B, int S, int C, int T, int m, int frames, void* stream);
+int mmfn_pool_bcast_add_bf16(const void* G, const void* gtok, void* dF, int B, int S, int C, int T, int m, int frames, void* stream);
+int mmfn_gap_sum_fwd_bf16(const void* const* feats, int n, const int32_t* frames, int B, int P, int C, float* out, void* stream);
+int mmfn_gap_sum_bwd_bf16(const float* g, void* const* outs, int n, const int32_t* frames, int B, int P, int C, void* stream);
 /* [B, R, Cc] -> [B, Cc, R] across the precision boundary: VectorNet (fp32 inside) -> the bf16 map feature, and its gradient back */
 int mmfn_transpose_f32_to_bf16(const float* in, void* out, int B, int R, int Cc, void* stream);
 int mmfn_transpose_bf16_to_f32(const void* in, float* out, int B, int R, int Cc, void* stream);

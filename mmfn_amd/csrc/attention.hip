@@ -493,6 +493,7 @@ int dispatch_nkt(int which, const AttnArgs& a, hipStream_t s) {
   if (nkt <= 4) return launch_attn<HS, 4>(which, a, s);
   if (nkt <= 6) return launch_attn<HS, 6>(which, a, s);
   if (nkt <= 8) return launch_attn<HS, 8>(which, a, s);
+  if (nkt <= 12) return launch_attn<HS, 12>(which, a, s);   // seq_len / n_views > 1: (n_views + 2) * seq_len * 64 tokens
   return MMFN_EINVAL;
 }
 
@@ -509,7 +510,7 @@ bool bf16_mfma_off() {
 }
 
 int dispatch(int which, int hs, const AttnArgs& a, hipStream_t s) {
-  if (a.B <= 0 || a.T <= 0 || a.T > 256 || a.NH <= 0) return MMFN_EINVAL;
+  if (a.B <= 0 || a.T <= 0 || a.T > 384 || a.NH <= 0) return MMFN_EINVAL;
   if ((a.ld & 3) || (a.ldo & 3) || ((uintptr_t)a.q & 15) || ((uintptr_t)a.k & 15) || ((uintptr_t)a.v & 15)) return MMFN_EINVAL;
   if (a.io_bf16 && !bf16_mfma_off()) {   // bf16 mode: bf16 MFMA kernels (attention16.hip)
     const int rc = mmfn_attn16_launch(which, hs, a, s);

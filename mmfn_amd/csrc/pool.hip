@@ -84,6 +84,20 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ g
 }
 
 // ---------------------------------------------------------------- token assembly
+// Token groups (64 tokens = one 8x8 pooled frame each), in the order GPT.forward concatenates them (model_vec.py:226-231):
+// the frames of modality 0 (n_views * seq_len camera frames per sample), then modality 1 (seq_len LiDAR frames), ...
+// cnt[m] = frames per sample of modality m, base[m] = its first group.  seq_len = n_views = 1: cnt = 1, base[m] = m.
+struct GroupMap { int cnt[4]; int base[4]; };
+static GroupMap make_groups(int n_modal, const int32_t* frames) {
+  GroupMap g;
+  int b = 0;
+  for (int m = 0; m < 4; ++m) {
+    g.cnt[m] = m < n_modal ? (frames ? frames[m] : 1) : 0;
+    g.base[m] = b;
+    b += g.cnt[m];
+  }
+  return g;
+}
 template <typename T> struct FeatPtrsT { const T* p[4]; };
 template <typename T> struct GradPtrsT { T* p[4]; };
 typedef FeatPtrsT<float> FeatPtrs;
@@ -91,7 +105,7 @@ typedef GradPtrsT<float> GradPtrs;
 
 // tok[b, m*64 + ay*8+ax, c] = drop( pos[t,c] + mean_{kxk}(F_m[b, ay*k.., ax*k.., c]) + vel_w[c]*v[b] + vel_b[c] )
 template <typename TT>
-__global__ __launch_bounds__(NT) void tokens_fwd_kernel(FeatPtrsT<TT> feats, int n_modal, int B, int S, int C,
+__global__ __launch_bounds__(NT) void tokens_fwd_kernel(FeatPtrsT<TT> feats, GroupMap gm, int n_modal, int B, int S, int C,
                                                         const float* __restrict__ pos, const float* __restrict__ vel_w,
                                                         const float* __restrict__ vel_b, const float* __restrict__ velocity,
                                                         TT* __restrict__ tok, float drop_p,
@@ -99,7 +113,7 @@ __global__ __launch_bounds__(NT) void tokens_fwd_kernel(FeatPtrsT<TT> feats, int
   const int cq = C >> 2;
   const int k = S >> 3;
   const float inv = 1.0f / (float)(k * k);
-  const int T = n_modal * 64;
+  const int T = (gm.base[n_modal - 1] + gm.cnt[n_modal - 1]) * 64;
   const int64_t total = (int64_t)B * T * cq;
   uint64_t key = 0;
   if (drop_p > 0.f) key = mmfn_rng_key(rng_state, rng_stream);
@@ -107,8 +121,13 @@ __global__ __launch_bounds__(NT) void tokens_fwd_kernel(FeatPtrsT<TT> feats, int
     const int c4 = (int)(i % cq) * 4;
     const int64_t row = i / cq;  // b*T + t
     const int t = (int)(row % T), b = (int)(row / T);
-    const int m = t >> 6, a = t & 63, ay = a >> 3, ax = a & 7;
-    const TT* f = feats.p[m] + ((size_t)(b * S + ay * k) * S + ax * k) * C + c4;
+    const int grp = t >> 6, a = t & 63, ay = a >> 3, ax = a & 7;
+    int m = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+      if (i < n_modal && grp >= gm.base[i]) m = i;
+    const int img = b * gm.cnt[m] + (grp - gm.base[m]);     // frame index inside modality m's (enlarged) batch
+    const TT* f = feats.p[m] + ((size_t)(img * S + ay * k) * S + ax * k) * C + c4;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     for (int dy = 0; dy < k; ++dy)
       for (int dx = 0; dx < k; ++dx) {
@@ -187,7 +206,8 @@ __global__ __launch_bounds__(TF_COLS * TF_LANES) void tokens_bwd_finalize_kernel
 // out[b,y,x,c] = F[b,y,x,c] + bilinear(tok[b, m*64 + 8x8 grid, c])   (tok row stride = C)
 template <typename TT>
 __global__ __launch_bounds__(NT) void upsample_add_fwd_kernel(const TT* __restrict__ feat, const TT* __restrict__ tok,
-                                                              TT* __restrict__ out, int B, int S, int C, int T, int m) {
+                                                              TT* __restrict__ out, int B, int S, int C, int T, int m, int frames) {
+  // B: frames of this modality over the whole batch (samples * frames); token group of frame i: m + i % frames of sample i / frames
   const int cq = C >> 2;
   const int64_t total = (int64_t)B * S * S * cq;
   const float r = (S > 1) ? (float)(8 - 1) / (float)(S - 1) : 0.f;
@@ -200,7 +220,7 @@ __global__ __launch_bounds__(NT) void upsample_add_fwd_kernel(const TT* __restri
     const f32x4 f = ldx4(feat + (size_t)(i / cq) * C + c4);
     f32x4 o;
     if (S == 8) {
-      const f32x4 t = ldx4(tok + ((size_t)b * T + m * 64 + y * 8 + x) * C + c4);
+      const f32x4 t = ldx4(tok + ((size_t)(b / frames) * T + (m + b % frames) * 64 + y * 8 + x) * C + c4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = f[e] + t[e];
     } else {
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(NT) void upsample_add_fwd_kernel(const TT* __restri
       const int h1p = (h1 < 7) ? 1 : 0, w1p = (w1 < 7) ? 1 : 0;
       const float h1l = h1r - (float)h1, h0l = 1.f - h1l;
       const float w1l = w1r - (float)w1, w0l = 1.f - w1l;
-      const TT* base = tok + ((size_t)b * T + m * 64 + h1 * 8 + w1) * C + c4;
+      const TT* base = tok + ((size_t)(b / frames) * T + (m + b % frames) * 64 + h1 * 8 + w1) * C + c4;
       const f32x4 v00 = ldx4(base);
       const f32x4 v01 = ldx4(base + (size_t)w1p * C);
       const f32x4 v10 = ldx4(base + (size_t)h1p * 8 * C);
@@ -227,7 +247,7 @@ __global__ __launch_bounds__(NT) void upsample_add_fwd_kernel(const TT* __restri
 // xor shuffles in a fixed order); with one thread per output the 64x64 maps ran 128 blocks of ~300 serial loads each.
 template <int YS, typename TT>
 __global__ __launch_bounds__(NT) void upsample_adj_kernel(const TT* __restrict__ G, TT* __restrict__ gtok, int B, int S,
-                                                          int C, int T, int m) {
+                                                          int C, int T, int m, int frames) {
   const int cq = C >> 2;
   const int64_t total = (int64_t)B * 64 * cq * YS;
   const float r = (S > 1) ? (float)(8 - 1) / (float)(S - 1) : 0.f;
@@ -278,13 +298,13 @@ __global__ __launch_bounds__(NT) void upsample_adj_kernel(const TT* __restrict__
   for (int d = 1; d < YS; d <<= 1)
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], d, 64);
-  if (live && ys == 0) stx4(gtok + ((size_t)b * T + m * 64 + a) * C + c4, acc);
+  if (live && ys == 0) stx4(gtok + ((size_t)(b / frames) * T + (m + b % frames) * 64 + a) * C + c4, acc);
 }
 
 // dF[b,y,x,c] = G[b,y,x,c] + gtok[b, m*64 + (y/k)*8 + x/k, c] / k^2      (avgpool adjoint + identity)
 template <typename TT>
 __global__ __launch_bounds__(NT) void pool_bcast_add_kernel(const TT* __restrict__ G, const TT* __restrict__ gtok,
-                                                            TT* __restrict__ dF, int B, int S, int C, int T, int m) {
+                                                            TT* __restrict__ dF, int B, int S, int C, int T, int m, int frames) {
   const int cq = C >> 2;
   const int k = S >> 3;
   const float inv = 1.0f / (float)(k * k);
@@ -296,7 +316,7 @@ __global__ __launch_bounds__(NT) void pool_bcast_add_kernel(const TT* __restrict
     const int y = (int)(p % S);
     const int b = (int)(p / S);
     const f32x4 g = ldx4(G + (size_t)(i / cq) * C + c4);
-    const f32x4 t = ldx4(gtok + ((size_t)b * T + m * 64 + (y / k) * 8 + x / k) * C + c4);
+    const f32x4 t = ldx4(gtok + ((size_t)(b / frames) * T + (m + b % frames) * 64 + (y / k) * 8 + x / k) * C + c4);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = g[e] + t[e] * inv;
@@ -306,30 +326,32 @@ __global__ __launch_bounds__(NT) void pool_bcast_add_kernel(const TT* __restrict
 
 // ---------------------------------------------------------------- global avgpool + branch sum
 template <typename T>
-__global__ __launch_bounds__(NT) void gap_sum_fwd_kernel(FeatPtrsT<T> feats, int n, int B, int P, int C, float* __restrict__ out) {
+__global__ __launch_bounds__(NT) void gap_sum_fwd_kernel(FeatPtrsT<T> feats, GroupMap gm, int n, int B, int P, int C, float* __restrict__ out) {
   const int64_t total = (int64_t)B * C;
   const float inv = 1.0f / (float)P;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i % C), b = (int)(i / C);
     float tot = 0.f;
-    for (int m = 0; m < n; ++m) {
-      float s = 0.f;
-      const T* f = feats.p[m] + (size_t)b * P * C + c;
-      for (int p = 0; p < P; ++p) s += ldx1(f + (size_t)p * C);
-      tot += s * inv;
-    }
+    for (int m = 0; m < n; ++m)
+      for (int j = 0; j < gm.cnt[m]; ++j) {   // every frame of the modality (model_vec.py:585-596: view(bz, frames, -1), sum)
+        float s = 0.f;
+        const T* f = feats.p[m] + (size_t)(b * gm.cnt[m] + j) * P * C + c;
+        for (int p = 0; p < P; ++p) s += ldx1(f + (size_t)p * C);
+        tot += s * inv;
+      }
     out[i] = tot;
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(NT) void gap_sum_bwd_kernel(const float* __restrict__ g, GradPtrsT<T> outs, int n, int B, int P, int C) {
-  const int64_t total = (int64_t)B * P * C;
+__global__ __launch_bounds__(NT) void gap_sum_bwd_kernel(const float* __restrict__ g, GradPtrsT<T> outs, GroupMap gm, int n, int B, int P, int C) {
   const float inv = 1.0f / (float)P;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C), b = (int)(i / ((int64_t)P * C));
-    const float v = g[(size_t)b * C + c] * inv;
-    for (int m = 0; m < n; ++m) stx1(outs.p[m] + i, v);
+  for (int m = 0; m < n; ++m) {
+    const int64_t total = (int64_t)B * gm.cnt[m] * P * C;   // every frame of a sample receives the sample's gradient
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int c = (int)(i % C), img = (int)(i / ((int64_t)P * C));
+      stx1(outs.p[m] + i, g[(size_t)(img / gm.cnt[m]) * C + c] * inv);
+    }
   }
 }
 
@@ -376,14 +398,16 @@ int maxpool_bwd_launch(const T* gy, const uint8_t* idx, T* gx, int B, int H, int
   return 0;
 }
 template <typename T>
-int tokens_fwd_launch(const T* const* feats, int n_modal, int B, int S, int C, const float* pos, const float* vel_w,
+int tokens_fwd_launch(const T* const* feats, int n_modal, const int32_t* frames, int B, int S, int C, const float* pos, const float* vel_w,
                       const float* vel_b, const float* velocity, T* tok, float drop_p, const uint64_t* rng_state,
                       uint32_t rng_stream, void* stream) {
   if (C % 4 || S % 8 || n_modal < 1 || n_modal > 4) return MMFN_EINVAL;
   FeatPtrsT<T> fp;
   for (int i = 0; i < 4; ++i) fp.p[i] = i < n_modal ? feats[i] : nullptr;
-  hipLaunchKernelGGL(tokens_fwd_kernel<T>, dim3(grid_for((int64_t)B * n_modal * 64 * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
-                     fp, n_modal, B, S, C, pos, vel_w, vel_b, velocity, tok, drop_p, rng_state, rng_stream);
+  const GroupMap gm = make_groups(n_modal, frames);
+  const int groups = gm.base[n_modal - 1] + gm.cnt[n_modal - 1];
+  hipLaunchKernelGGL(tokens_fwd_kernel<T>, dim3(grid_for((int64_t)B * groups * 64 * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
+                     fp, gm, n_modal, B, S, C, pos, vel_w, vel_b, velocity, tok, drop_p, rng_state, rng_stream);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
@@ -401,49 +425,53 @@ int tokens_bwd_launch(T* gtok, int B, int Tn, int C, const float* velocity, floa
   return 0;
 }
 template <typename T>
-int upsample_add_fwd_launch(const T* feat, const T* tok, T* out, int B, int S, int C, int Tn, int m, void* stream) {
-  if (C % 4) return MMFN_EINVAL;
+int upsample_add_fwd_launch(const T* feat, const T* tok, T* out, int B, int S, int C, int Tn, int m, int frames, void* stream) {
+  if (C % 4 || frames < 1 || B % frames) return MMFN_EINVAL;
   hipLaunchKernelGGL(upsample_add_fwd_kernel<T>, dim3(grid_for((int64_t)B * S * S * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
-                     feat, tok, out, B, S, C, Tn, m);
+                     feat, tok, out, B, S, C, Tn, m, frames);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
 template <typename T>
-int upsample_adj_launch(const T* G, T* gtok, int B, int S, int C, int Tn, int m, void* stream) {
-  if (C % 4) return MMFN_EINVAL;
+int upsample_adj_launch(const T* G, T* gtok, int B, int S, int C, int Tn, int m, int frames, void* stream) {
+  if (C % 4 || frames < 1 || B % frames) return MMFN_EINVAL;
   const int64_t outs = (int64_t)B * 64 * (C / 4);
   if (S >= 32)
     hipLaunchKernelGGL((upsample_adj_kernel<8, T>), dim3((unsigned)((outs * 8 + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, G, gtok,
-                       B, S, C, Tn, m);
+                       B, S, C, Tn, m, frames);
   else
     hipLaunchKernelGGL((upsample_adj_kernel<1, T>), dim3((unsigned)((outs + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, G, gtok, B,
-                       S, C, Tn, m);
+                       S, C, Tn, m, frames);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
 template <typename T>
-int pool_bcast_add_launch(const T* G, const T* gtok, T* dF, int B, int S, int C, int Tn, int m, void* stream) {
-  if (C % 4 || S % 8) return MMFN_EINVAL;
+int pool_bcast_add_launch(const T* G, const T* gtok, T* dF, int B, int S, int C, int Tn, int m, int frames, void* stream) {
+  if (C % 4 || S % 8 || frames < 1 || B % frames) return MMFN_EINVAL;
   hipLaunchKernelGGL(pool_bcast_add_kernel<T>, dim3(grid_for((int64_t)B * S * S * (C / 4))), dim3(NT), 0, (hipStream_t)stream, G,
-                     gtok, dF, B, S, C, Tn, m);
+                     gtok, dF, B, S, C, Tn, m, frames);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
 template <typename T>
-int gap_sum_fwd_launch(const T* const* feats, int n, int B, int P, int C, float* out, void* stream) {
+int gap_sum_fwd_launch(const T* const* feats, int n, const int32_t* frames, int B, int P, int C, float* out, void* stream) {
   if (n < 1 || n > 4) return MMFN_EINVAL;
   FeatPtrsT<T> fp;
   for (int i = 0; i < 4; ++i) fp.p[i] = i < n ? feats[i] : nullptr;
-  hipLaunchKernelGGL(gap_sum_fwd_kernel<T>, dim3(grid_for((int64_t)B * C)), dim3(NT), 0, (hipStream_t)stream, fp, n, B, P, C, out);
+  hipLaunchKernelGGL(gap_sum_fwd_kernel<T>, dim3(grid_for((int64_t)B * C)), dim3(NT), 0, (hipStream_t)stream, fp, make_groups(n, frames), n, B, P, C,
+                     out);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
 template <typename T>
-int gap_sum_bwd_launch(const float* g, T* const* outs, int n, int B, int P, int C, void* stream) {
+int gap_sum_bwd_launch(const float* g, T* const* outs, int n, const int32_t* frames, int B, int P, int C, void* stream) {
   if (n < 1 || n > 4) return MMFN_EINVAL;
   GradPtrsT<T> gp;
   for (int i = 0; i < 4; ++i) gp.p[i] = i < n ? outs[i] : nullptr;
-  hipLaunchKernelGGL(gap_sum_bwd_kernel<T>, dim3(grid_for((int64_t)B * P * C)), dim3(NT), 0, (hipStream_t)stream, g, gp, n, B, P, C);
+  const GroupMap gm = make_groups(n, frames);
+  int most = 1;
+  for (int m = 0; m < n; ++m) most = std::max(most, gm.cnt[m]);
+  hipLaunchKernelGGL(gap_sum_bwd_kernel<T>, dim3(grid_for((int64_t)B * most * P * C)), dim3(NT), 0, (hipStream_t)stream, g, gp, gm, n, B, P, C);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
@@ -472,15 +500,15 @@ extern "C" int mmfn_maxpool3x3s2_bwd_bf16(const void* gy, const uint8_t* idx, vo
   return maxpool_bwd_launch((cbf)gy, idx, (mbf)gx, B, H, W, C, stream);
 }
 
-extern "C" int mmfn_tokens_fwd_f32(const float* const* feats, int n_modal, int B, int S, int C, const float* pos,
+extern "C" int mmfn_tokens_fwd_f32(const float* const* feats, int n_modal, const int32_t* frames, int B, int S, int C, const float* pos,
                                    const float* vel_w, const float* vel_b, const float* velocity, float* tok, float drop_p,
                                    const uint64_t* rng_state, uint32_t rng_stream, void* stream) {
-  return tokens_fwd_launch(feats, n_modal, B, S, C, pos, vel_w, vel_b, velocity, tok, drop_p, rng_state, rng_stream, stream);
+  return tokens_fwd_launch(feats, n_modal, frames, B, S, C, pos, vel_w, vel_b, velocity, tok, drop_p, rng_state, rng_stream, stream);
 }
-extern "C" int mmfn_tokens_fwd_bf16(const void* const* feats, int n_modal, int B, int S, int C, const float* pos,
+extern "C" int mmfn_tokens_fwd_bf16(const void* const* feats, int n_modal, const int32_t* frames, int B, int S, int C, const float* pos,
                                     const float* vel_w, const float* vel_b, const float* velocity, void* tok, float drop_p,
                                     const uint64_t* rng_state, uint32_t rng_stream, void* stream) {
-  return tokens_fwd_launch((const bf16_t* const*)feats, n_modal, B, S, C, pos, vel_w, vel_b, velocity, (mbf)tok, drop_p, rng_state,
+  return tokens_fwd_launch((const bf16_t* const*)feats, n_modal, frames, B, S, C, pos, vel_w, vel_b, velocity, (mbf)tok, drop_p, rng_state,
                            rng_stream, stream);
 }
 
@@ -497,43 +525,43 @@ extern "C" int mmfn_tokens_bwd_bf16(void* gtok, int B, int T, int C, const float
   return tokens_bwd_launch((mbf)gtok, B, T, C, velocity, dpos, dvel_w, dvel_b, drop_p, rng_state, rng_stream, workspace, stream);
 }
 
-extern "C" int mmfn_upsample_add_fwd_f32(const float* feat, const float* tok, float* out, int B, int S, int C, int T, int m,
-                                         void* stream) {
-  return upsample_add_fwd_launch(feat, tok, out, B, S, C, T, m, stream);
-}
-extern "C" int mmfn_upsample_add_fwd_bf16(const void* feat, const void* tok, void* out, int B, int S, int C, int T, int m,
-                                          void* stream) {
-  return upsample_add_fwd_launch((cbf)feat, (cbf)tok, (mbf)out, B, S, C, T, m, stream);
-}
-
-extern "C" int mmfn_upsample_adj_f32(const float* G, float* gtok, int B, int S, int C, int T, int m, void* stream) {
-  return upsample_adj_launch(G, gtok, B, S, C, T, m, stream);
-}
-extern "C" int mmfn_upsample_adj_bf16(const void* G, void* gtok, int B, int S, int C, int T, int m, void* stream) {
-  return upsample_adj_launch((cbf)G, (mbf)gtok, B, S, C, T, m, stream);
-}
-
-extern "C" int mmfn_pool_bcast_add_f32(const float* G, const float* gtok, float* dF, int B, int S, int C, int T, int m,
+extern "C" int mmfn_upsample_add_fwd_f32(const float* feat, const float* tok, float* out, int B, int S, int C, int T, int m, int frames,
                                        void* stream) {
-  return pool_bcast_add_launch(G, gtok, dF, B, S, C, T, m, stream);
+  return upsample_add_fwd_launch(feat, tok, out, B, S, C, T, m, frames, stream);
 }
-extern "C" int mmfn_pool_bcast_add_bf16(const void* G, const void* gtok, void* dF, int B, int S, int C, int T, int m,
+extern "C" int mmfn_upsample_add_fwd_bf16(const void* feat, const void* tok, void* out, int B, int S, int C, int T, int m, int frames,
                                         void* stream) {
-  return pool_bcast_add_launch((cbf)G, (cbf)gtok, (mbf)dF, B, S, C, T, m, stream);
+  return upsample_add_fwd_launch((cbf)feat, (cbf)tok, (mbf)out, B, S, C, T, m, frames, stream);
 }
 
-extern "C" int mmfn_gap_sum_fwd_f32(const float* const* feats, int n, int B, int P, int C, float* out, void* stream) {
-  return gap_sum_fwd_launch(feats, n, B, P, C, out, stream);
+extern "C" int mmfn_upsample_adj_f32(const float* G, float* gtok, int B, int S, int C, int T, int m, int frames, void* stream) {
+  return upsample_adj_launch(G, gtok, B, S, C, T, m, frames, stream);
 }
-extern "C" int mmfn_gap_sum_fwd_bf16(const void* const* feats, int n, int B, int P, int C, float* out, void* stream) {
-  return gap_sum_fwd_launch((const bf16_t* const*)feats, n, B, P, C, out, stream);
+extern "C" int mmfn_upsample_adj_bf16(const void* G, void* gtok, int B, int S, int C, int T, int m, int frames, void* stream) {
+  return upsample_adj_launch((cbf)G, (mbf)gtok, B, S, C, T, m, frames, stream);
 }
 
-extern "C" int mmfn_gap_sum_bwd_f32(const float* g, float* const* outs, int n, int B, int P, int C, void* stream) {
-  return gap_sum_bwd_launch(g, outs, n, B, P, C, stream);
+extern "C" int mmfn_pool_bcast_add_f32(const float* G, const float* gtok, float* dF, int B, int S, int C, int T, int m, int frames,
+                                       void* stream) {
+  return pool_bcast_add_launch(G, gtok, dF, B, S, C, T, m, frames, stream);
 }
-extern "C" int mmfn_gap_sum_bwd_bf16(const float* g, void* const* outs, int n, int B, int P, int C, void* stream) {
-  return gap_sum_bwd_launch(g, (bf16_t* const*)outs, n, B, P, C, stream);
+extern "C" int mmfn_pool_bcast_add_bf16(const void* G, const void* gtok, void* dF, int B, int S, int C, int T, int m, int frames,
+                                        void* stream) {
+  return pool_bcast_add_launch((cbf)G, (cbf)gtok, (mbf)dF, B, S, C, T, m, frames, stream);
+}
+
+extern "C" int mmfn_gap_sum_fwd_f32(const float* const* feats, int n, const int32_t* frames, int B, int P, int C, float* out, void* stream) {
+  return gap_sum_fwd_launch(feats, n, frames, B, P, C, out, stream);
+}
+extern "C" int mmfn_gap_sum_fwd_bf16(const void* const* feats, int n, const int32_t* frames, int B, int P, int C, float* out, void* stream) {
+  return gap_sum_fwd_launch((const bf16_t* const*)feats, n, frames, B, P, C, out, stream);
+}
+
+extern "C" int mmfn_gap_sum_bwd_f32(const float* g, float* const* outs, int n, const int32_t* frames, int B, int P, int C, void* stream) {
+  return gap_sum_bwd_launch(g, outs, n, frames, B, P, C, stream);
+}
+extern "C" int mmfn_gap_sum_bwd_bf16(const float* g, void* const* outs, int n, const int32_t* frames, int B, int P, int C, void* stream) {
+  return gap_sum_bwd_launch(g, (bf16_t* const*)outs, n, frames, B, P, C, stream);
 }
 
 extern "C" int mmfn_transpose_f32(const float* in, float* out, int B, int R, int Cc, void* stream) {

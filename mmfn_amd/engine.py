@@ -557,7 +557,7 @@ class GPT(object):
         self.grouped = self.block_stride is not None and GPT_GROUP_MIN_C <= self.C <= GPT_GROUP_MAX_C
 
     def fwd(self, ctx, feats, velocity):
-        B = feats[0].shape[0]
+        B = velocity.shape[0]
         T, C, nh, hs = self.T, self.C, self.nh, self.hs
         M = B * T
         bufs, nm = ctx.bufs, self.name
@@ -566,7 +566,7 @@ class GPT(object):
         Wf = (lambda lin: lin.w16) if ctx.bf16 else (lambda lin: lin.w)      # forward operand of a Linear
         x = bufs.get(nm + ".x0", (B, T, C), adt)
         ops.tokens_fwd(feats, self.pos.view(T, C), self.vel.w.view(C), self.vel.b, velocity, x, p_embd, ctx.rng_state,
-                       self.stream_base)
+                       self.stream_base, frames=self.frames)
         self.velocity = velocity
         x = x.view(M, C)
         self.acts = []
@@ -1056,19 +1056,36 @@ class Engine(object):
     """Forward / backward / optimizer step of one MMFN replica on one GPU.
 
     Orchestration restates Encoder.forward (model_vec.py:488-598; model_img.py:310-423) and
-    MMFN.forward (model_vec.py:653-682) for seq_len = 1, n_views = 1 (the reference's only
-    configuration, config.py:6,11)."""
+    MMFN.forward (model_vec.py:653-682).  seq_len = 1, n_views = 1 is the reference's configuration (config.py:6,11) and the
+    tuned one; other values run the same kernels with more frames per sample: a sample's n_views * seq_len camera frames,
+    seq_len LiDAR frames and seq_len map frames are batch entries of their branch and token groups of one sequence
+    (self.frames / self.group_base; model_img.py:211-246, :410-423)."""
 
     def __init__(self, module, layout, variant):
         cfg = module.config
-        if cfg.seq_len != 1 or cfg.n_views != 1:
-            raise NotImplementedError("only seq_len=1, n_views=1 (the reference configuration) is built")
         self.module, self.layout, self.variant, self.cfg = module, layout, variant, cfg
         self.device = layout.device
         self.act_dtype = {"f32": torch.float32, "bf16": torch.bfloat16}[getattr(cfg, "act_dtype", "f32")]
         if self.act_dtype == torch.bfloat16 and variant == "rad":
             raise NotImplementedError("the bf16 training mode covers the vec and img variants (the rad variant's T = 256 attention and "
                                       "radar GAT have no bf16 kernels)")
+        S, V = int(cfg.seq_len), int(cfg.n_views)
+        if S < 1 or V < 1:
+            raise ValueError("seq_len and n_views must be >= 1, got %d and %d" % (S, V))
+        if variant != "img" and S != 1:
+            # the reference cannot either: its VectorNet / radar encoders emit one feature map per SAMPLE, which
+            # GPT.forward's view(bz, seq_len, ...) rejects for seq_len > 1 (model_vec.py:223-229)
+            raise NotImplementedError("seq_len > 1 exists for the image-map model only (the vector-map and radar encoders produce one "
+                                      "frame per sample, as in the reference)")
+        # frames per sample of each fused modality, in token order, and each modality's first 64-token group
+        self.frames = [V * S, S, S]
+        self.group_base = [0, V * S, (V + 1) * S]
+        tokens = 64 * ((V + 2) * S + (1 if variant == "rad" else 0))
+        if tokens > 384:
+            raise NotImplementedError("(n_views + 2) * seq_len * 64%s = %d tokens: the attention kernels hold at most 384 keys" % (
+                " + 64" if variant == "rad" else "", tokens))
+        if self.act_dtype == torch.bfloat16 and (S, V) != (1, 1):
+            raise NotImplementedError("the bf16 training mode is built for seq_len = n_views = 1 (its attention kernels take 64 / 128 / 192 tokens)")
         if self.device.type != "cuda":
             raise ops._lib.MMFNLibraryError("the MMFN HIP path needs a GPU device (got %s); there is no CPU fallback" % self.device)
         enc = module.encoder
@@ -1084,6 +1101,11 @@ class Engine(object):
         self.rad = RadarGAT("rad", layout, "encoder.radar_encoder", enc.radar_encoder) if variant == "rad" else None
         self.gpts = [GPT("gpt%d" % (i + 1), layout, "encoder.transformer%d" % (i + 1), getattr(enc, "transformer%d" % (i + 1)),
                          cfg, 100 * (i + 1)) for i in range(4)]
+        for i, g in enumerate(self.gpts):
+            g.frames = self.frames + ([1] if (variant == "rad" and i == 3) else [])
+            if g.T != 64 * sum(g.frames):
+                raise ValueError("%s.pos_emb holds %d tokens; seq_len %d / n_views %d need %d (config changed after the module was built?)"
+                                 % (g.name, g.T, S, V, 64 * sum(g.frames)))
         self.head = Head(layout, cfg.pred_len)
         self.bufs = {}
         dev = self.device
@@ -1196,14 +1218,15 @@ class Engine(object):
             B = x.shape[0]
             img = ops.nchw_to_nhwc(x, bufs.get("in.img", (B, x.shape[2], x.shape[3], 3)), self.norm_mean, self.norm_inv_std)
         if "lidar_pts" in inp:
-            lid = ops.lidar_splat(inp["lidar_pts"], bufs.get("in.lid", (B, 256, 256, 2)), flip_y=bool(inp.get("lidar_flip_y", False)))
+            lid = ops.lidar_splat(inp["lidar_pts"], bufs.get("in.lid", (inp["lidar_pts"].shape[0], 256, 256, 2)),
+                                  flip_y=bool(inp.get("lidar_flip_y", False)))
         else:
             x = inp["lidar"]
-            lid = ops.nchw_to_nhwc(x, bufs.get("in.lid", (B, x.shape[2], x.shape[3], x.shape[1])))
+            lid = ops.nchw_to_nhwc(x, bufs.get("in.lid", (x.shape[0], x.shape[2], x.shape[3], x.shape[1])))
         mp = None
         if self.variant == "img":
             x = inp["map"]
-            mp = ops.nchw_to_nhwc(x, bufs.get("in.map", (B, x.shape[2], x.shape[3], 3)))  # NOT normalised (model_img.py:337)
+            mp = ops.nchw_to_nhwc(x, bufs.get("in.map", (x.shape[0], x.shape[2], x.shape[3], 3)))  # NOT normalised (model_img.py:337)
         return img, lid, mp
 
     # ------------------------------------------------------------------ branch concurrency
@@ -1311,13 +1334,16 @@ class Engine(object):
         self.taps = {"stage1": tuple(feats)}
         self.pre_add = []
         tok = None
+        # token groups: the modality's first 64-token group and its frames per sample (radar: one frame after the others)
+        frames, base = self.frames + [1], self.group_base + [sum(self.frames)]
         for s in range(4):
             if s > 0:
                 # per branch: add the previous scale's fusion output, then the next ResNet stage
                 prev, ptok = feats, tok
 
                 def stage(m, prev=prev, ptok=ptok, s=s):
-                    f = ops.upsample_add_fwd(prev[m], ptok, ctx.bufs.get("fuse%d.%d" % (s - 1, m), prev[m].shape, prev[m].dtype), m)
+                    f = ops.upsample_add_fwd(prev[m], ptok, ctx.bufs.get("fuse%d.%d" % (s - 1, m), prev[m].shape, prev[m].dtype),
+                                             base[m], frames[m])
                     return trunks[m].layer_fwd(ctx, s + 1, f)
 
                 feats = self._branches([lambda m=m: stage(m) for m in range(3)])
@@ -1326,8 +1352,8 @@ class Engine(object):
             tok = self.gpts[s].fwd(ctx, feats, vel)
             self.taps["gpt%d" % (s + 1)] = tok
             self.pre_add.append(feats)
-        feats = [ops.upsample_add_fwd(f, tok, ctx.bufs.get("fuse3.%d" % m, f.shape, f.dtype), m) for m, f in enumerate(feats)]
-        fused = ops.gap_sum_fwd(feats, ctx.bufs.get("fused", (B, 512)))
+        feats = [ops.upsample_add_fwd(f, tok, ctx.bufs.get("fuse3.%d" % m, f.shape, f.dtype), base[m], frames[m]) for m, f in enumerate(feats)]
+        fused = ops.gap_sum_fwd(feats, ctx.bufs.get("fused", (B, 512)), frames=frames[:len(feats)])
         self.taps["fused"] = fused
         pred, loss = self.head.fwd(ctx, fused, inp["target_point"], gt)
         return pred, loss
@@ -1360,7 +1386,7 @@ class Engine(object):
             self._ready(on_ready, 0, "head")
         shapes = [f.shape for f in self.pre_add[3]]
         self._G = [bufs.get("G3.%d" % m, shp, ctx.adt) for m, shp in enumerate(shapes)]
-        ops.gap_sum_bwd(g_fused, self._G)
+        ops.gap_sum_bwd(g_fused, self._G, frames=(self.frames + [1])[:len(self._G)])
 
     @_in_precision
     def backward_scale(self, s, on_ready=None):
@@ -1373,14 +1399,15 @@ class Engine(object):
         trunks = [self.img, self.lid, self.map]
         G = self._G
         gpt = self.gpts[s]
+        frames, base = self.frames + [1], self.group_base + [sum(self.frames)]
         gtok = bufs.get("gtok%d" % s, (B, gpt.T, gpt.C), ctx.adt)
         for m, g in enumerate(G):
             if not (self._adj_done and m < 3):   # the three branch lanes of the previous scale already spread their gradient
-                ops.upsample_adj(g, gtok, m)
+                ops.upsample_adj(g, gtok, base[m], frames[m])
         gin = gpt.bwd(ctx, gtok)
         self._ready(on_ready, st, "gpt")
         if s == 3 and self.rad is not None:
-            dF3 = ops.pool_bcast_add(G[3], gin, bufs.get("dF3.3", G[3].shape), 3)
+            dF3 = ops.pool_bcast_add(G[3], gin, bufs.get("dF3.3", G[3].shape), base[3], 1)
             self.rad.bwd(ctx, dF3)
             self._ready(on_ready, 0, "head")
         # inside lane graphs (graphs.Recorder split mode) a lane is a linear graph of its own: the hooks run after the join
@@ -1390,14 +1417,14 @@ class Engine(object):
             gtok_next = bufs.get("gtok%d" % (s - 1), (B, nxt.T, nxt.C), ctx.adt)
 
             def stage(m):
-                d = ops.pool_bcast_add(G[m], gin, bufs.get("dF%d.%d" % (s, m), G[m].shape, G[m].dtype), m)
+                d = ops.pool_bcast_add(G[m], gin, bufs.get("dF%d.%d" % (s, m), G[m].shape, G[m].dtype), base[m], frames[m])
                 g = trunks[m].layer_bwd(ctx, s + 1, d)
                 if in_lane_ok:
                     self._ready(on_ready, st, names[m])
                 if LANE_TAIL_ADJOINT:
                     # the adjoint of the next scale's upsample-add for this branch (its own 64 token rows of gtok) at the tail of
                     # the lane, beside the other lanes, instead of three launches on the main stream ahead of the transformer
-                    ops.upsample_adj(g, gtok_next, m)
+                    ops.upsample_adj(g, gtok_next, base[m], frames[m])
                 return g
 
             self._G = self._branches([lambda m=m: stage(m) for m in range(3)])
@@ -1408,19 +1435,19 @@ class Engine(object):
             return
 
         def img_tail():
-            d = ops.pool_bcast_add(G[0], gin, bufs.get("dF0.0", G[0].shape, G[0].dtype), 0)
+            d = ops.pool_bcast_add(G[0], gin, bufs.get("dF0.0", G[0].shape, G[0].dtype), base[0], frames[0])
             self.img.stem_bwd(ctx, self.img.layer_bwd(ctx, 1, d))
             if in_lane_ok:
                 self._ready(on_ready, st, "img")
 
         def lid_tail():
-            d = ops.pool_bcast_add(G[1], gin, bufs.get("dF0.1", G[1].shape, G[1].dtype), 1)
+            d = ops.pool_bcast_add(G[1], gin, bufs.get("dF0.1", G[1].shape, G[1].dtype), base[1], frames[1])
             self.lid.stem_bwd(ctx, self.lid.layer_bwd(ctx, 1, d))
             if in_lane_ok:
                 self._ready(on_ready, st, "lid")
 
         def map_tail():
-            d = ops.pool_bcast_add(G[2], gin, bufs.get("dF0.2", G[2].shape, G[2].dtype), 2)
+            d = ops.pool_bcast_add(G[2], gin, bufs.get("dF0.2", G[2].shape, G[2].dtype), base[2], frames[2])
             if self.variant == "img":
                 self.map.stem_bwd(ctx, self.map.layer_bwd(ctx, 1, d))
             else:

@@ -121,14 +121,25 @@ class MMFN(nn.Module):
         dev = self._layout.device
         f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
         cfg = self.config
-        if len(image_list) != cfg.seq_len or len(lidar_list) != cfg.seq_len:
-            raise NotImplementedError("only seq_len=1, n_views=1 inputs are supported")
-        cfg.n_views = len(image_list) // cfg.seq_len  # the reference mutates config here (model_vec.py:504)
-        inp = {"image": f32(image_list[0]), "lidar": f32(lidar_list[0]), "target_point": f32(target_point),
+        S = cfg.seq_len
+        if len(lidar_list) != S or not image_list or len(image_list) % S:
+            raise ValueError("expected seq_len = %d LiDAR frames and a multiple of that many camera frames, got %d and %d"
+                             % (S, len(lidar_list), len(image_list)))
+        cfg.n_views = len(image_list) // S  # the reference mutates config here (model_vec.py:504)
+        tokens = self.encoder.transformer1.pos_emb.shape[1]
+        if (cfg.n_views + 2) * S * 64 != tokens:
+            # the reference fails on the same input, later: pos_emb + token_embeddings do not broadcast (model_vec.py:235)
+            raise ValueError("%d camera frames per sample, but the position embeddings were built for n_views = %d"
+                             % (len(image_list), tokens // (64 * S) - 2))
+        # frames of one sample are consecutive batch entries: torch.stack(list, dim=1).view(bz * n, ...) (model_vec.py:506-508)
+        frames = lambda lst: f32(lst[0]) if len(lst) == 1 else torch.stack([f32(t) for t in lst], dim=1).flatten(0, 1)
+        inp = {"image": frames(image_list), "lidar": frames(lidar_list), "target_point": f32(target_point),
                "velocity": f32(velocity).view(-1)}
         assert inp["image"].shape[2:] == inp["lidar"].shape[2:], "image and LiDAR BEV must share H x W (model_vec.py:500,506)"
         if self.variant == "img":
-            inp["map"] = f32(maps_list[0])
+            if len(maps_list) != S:
+                raise ValueError("expected seq_len = %d map frames, got %d" % (S, len(maps_list)))
+            inp["map"] = frames(maps_list)
         else:
             lane = vectormaps_list[0][0]
             lane_num = vectormaps_list[1][0]

@@ -836,11 +836,27 @@ def maxpool_bwd(gy, idx, gx):
     return gx
 
 
-def tokens_fwd(feats, pos, vel_w, vel_b, velocity, tok, drop_p=0.0, rng_state=None, rng_stream=0):
-    B, S, _, C = feats[0].shape
+def _frames(frames, n):
+    """Host int32[n] of frames per sample for each modality (None: one each - seq_len = n_views = 1)."""
+    if frames is None:
+        return None
+    if len(frames) != n or min(frames) < 1:
+        raise ValueError("frames must hold one positive count per modality, got %r for %d modalities" % (frames, n))
+    return (ctypes.c_int32 * n)(*[int(f) for f in frames])
+
+
+def tokens_fwd(feats, pos, vel_w, vel_b, velocity, tok, drop_p=0.0, rng_state=None, rng_stream=0, frames=None):
+    """feats[m] is [B * frames[m], S, S, C]; tok is [B, sum(frames) * 64, C]."""
+    B = tok.shape[0]
+    _, S, _, C = feats[0].shape
+    for m, f in enumerate(feats):
+        if f.shape[0] != B * (1 if frames is None else frames[m]):
+            raise ValueError("modality %d holds %d frames for %d samples, expected %d per sample" % (m, f.shape[0], B, 1 if frames is None else frames[m]))
+    if tok.shape[1] != 64 * (len(feats) if frames is None else sum(frames)):
+        raise ValueError("token buffer has %d tokens, the frames need %d" % (tok.shape[1], 64 * (len(feats) if frames is None else sum(frames))))
     arr = _ptr_array(feats)
-    _call("mmfn_tokens_fwd_bf16" if tok.dtype == BF16 else "mmfn_tokens_fwd_f32", arr, len(feats), B, S, C, ptr(pos), ptr(vel_w), ptr(vel_b), ptr(velocity), ptr(tok),
-          float(drop_p), ptr(rng_state), rng_stream, stream())
+    _call("mmfn_tokens_fwd_bf16" if tok.dtype == BF16 else "mmfn_tokens_fwd_f32", arr, len(feats), _frames(frames, len(feats)), B, S, C, ptr(pos), ptr(vel_w),
+          ptr(vel_b), ptr(velocity), ptr(tok), float(drop_p), ptr(rng_state), rng_stream, stream())
     return tok
 
 
@@ -851,35 +867,49 @@ def tokens_bwd(gtok, velocity, dpos, dvel_w, dvel_b, drop_p=0.0, rng_state=None,
           ptr(rng_state), rng_stream, ptr(norm_workspace(gtok.device, need)), stream())
 
 
-def upsample_add_fwd(feat, tok, out, m):
+def _groups_ok(n_img, n_tok, T, m, frames):
+    if frames < 1 or n_img != n_tok * frames or (m + frames) * 64 > T:
+        raise ValueError("%d frames / %d samples / %d tokens do not fit token groups [%d, %d)" % (n_img, n_tok, T, m, m + frames))
+
+
+def upsample_add_fwd(feat, tok, out, m, frames=1):
+    """m: the modality's first token group, frames: its frames per sample (feat holds samples * frames maps)."""
     B, S, _, C = feat.shape
     T = tok.shape[1]
-    _call("mmfn_upsample_add_fwd_bf16" if feat.dtype == BF16 else "mmfn_upsample_add_fwd_f32", ptr(feat), ptr(tok), ptr(out), B, S, C, T, m, stream())
+    _groups_ok(B, tok.shape[0], T, m, frames)
+    _call("mmfn_upsample_add_fwd_bf16" if feat.dtype == BF16 else "mmfn_upsample_add_fwd_f32", ptr(feat), ptr(tok), ptr(out), B, S, C, T, m, frames, stream())
     return out
 
 
-def upsample_adj(G, gtok, m):
+def upsample_adj(G, gtok, m, frames=1):
     B, S, _, C = G.shape
     T = gtok.shape[1]
-    _call("mmfn_upsample_adj_bf16" if G.dtype == BF16 else "mmfn_upsample_adj_f32", ptr(G), ptr(gtok), B, S, C, T, m, stream())
+    _groups_ok(B, gtok.shape[0], T, m, frames)
+    _call("mmfn_upsample_adj_bf16" if G.dtype == BF16 else "mmfn_upsample_adj_f32", ptr(G), ptr(gtok), B, S, C, T, m, frames, stream())
 
 
-def pool_bcast_add(G, gtok, dF, m):
+def pool_bcast_add(G, gtok, dF, m, frames=1):
     B, S, _, C = G.shape
     T = gtok.shape[1]
-    _call("mmfn_pool_bcast_add_bf16" if G.dtype == BF16 else "mmfn_pool_bcast_add_f32", ptr(G), ptr(gtok), ptr(dF), B, S, C, T, m, stream())
+    _groups_ok(B, gtok.shape[0], T, m, frames)
+    _call("mmfn_pool_bcast_add_bf16" if G.dtype == BF16 else "mmfn_pool_bcast_add_f32", ptr(G), ptr(gtok), ptr(dF), B, S, C, T, m, frames, stream())
     return dF
 
 
-def gap_sum_fwd(feats, out):
-    B, H, W, C = feats[0].shape
-    _call("mmfn_gap_sum_fwd_bf16" if feats[0].dtype == BF16 else "mmfn_gap_sum_fwd_f32", _ptr_array(feats), len(feats), B, H * W, C, ptr(out), stream())
+def gap_sum_fwd(feats, out, frames=None):
+    """out[B, C] = sum over modalities and over each sample's frames of the spatial mean."""
+    _, H, W, C = feats[0].shape
+    B = out.shape[0]
+    _call("mmfn_gap_sum_fwd_bf16" if feats[0].dtype == BF16 else "mmfn_gap_sum_fwd_f32", _ptr_array(feats), len(feats), _frames(frames, len(feats)), B, H * W, C,
+          ptr(out), stream())
     return out
 
 
-def gap_sum_bwd(g, outs):
-    B, H, W, C = outs[0].shape
-    _call("mmfn_gap_sum_bwd_bf16" if outs[0].dtype == BF16 else "mmfn_gap_sum_bwd_f32", ptr(g), _ptr_array(outs), len(outs), B, H * W, C, stream())
+def gap_sum_bwd(g, outs, frames=None):
+    _, H, W, C = outs[0].shape
+    B = g.shape[0]
+    _call("mmfn_gap_sum_bwd_bf16" if outs[0].dtype == BF16 else "mmfn_gap_sum_bwd_f32", ptr(g), _ptr_array(outs), len(outs), _frames(frames, len(outs)), B, H * W, C,
+          stream())
 
 
 def transpose(inp, out, B, R, Cc):

@@ -17,6 +17,17 @@ def forward_args(batch, variant="vec"):
             batch["target_point"], batch["velocity"])
 
 
+def frames_args(seq_len, n_views, batch=2, variant="img", lanes=4):
+    """Inputs with several frames per sample: frame j of every modality is synthetic_batch(seed=42 + j); labels, target
+    point and velocity come from seed 42.  Returns (batches, forward() arguments, gt_wp)."""
+    batches = [fixtures.synthetic_batch(batch, variant, seed=42 + j, lanes=lanes) for j in range(seq_len * n_views)]
+    per = [forward_args(b, variant) for b in batches]
+    first = per[0]
+    args = ([a[0][0] for a in per], [a[1][0] for a in per[:seq_len]], [a[2][0] for a in per[:seq_len]],
+            first[3], first[4], first[5], first[6], first[7])
+    return batches, args, batches[0]["gt_wp"]
+
+
 def build_oracle(variant="vec", dropout=0.0, **cfg_kw):
     cfg = OracleConfig(embd_pdrop=dropout, attn_pdrop=dropout, resid_pdrop=dropout, **cfg_kw)
     model = OracleMMFN(cfg, "cpu", variant)

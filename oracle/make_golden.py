@@ -175,6 +175,68 @@ def run_variant(variant, ref_models, ref_dl, ref_cfg, out_dir):
           "eval_loss", res["eval_loss"], "train_loss", res["train_loss"])
 
 
+def run_frames(ref_models, ref_dl, ref_cfg, out_dir):
+    """The image model with more than one frame per sample: (seq_len, n_views) = (2, 1) and (1, 2).  The reference's GPT
+    concatenates the n_views*seq_len camera frames, the seq_len LiDAR frames and the seq_len map frames of a sample into
+    one token sequence (model_img.py:211-246) and the encoder sums the pooled features of all of them (:410-423).  Frame j
+    of every modality comes from fixtures.synthetic_batch(seed=42 + j); labels from seed 42 (harness.frames_args)."""
+    res = {}
+    for seq_len, n_views in ((2, 1), (1, 2)):
+        tag = "s%dv%d_" % (seq_len, n_views)
+        torch.manual_seed(0)
+        cfg = ref_cfg.GlobalConfig()
+        cfg.seq_len, cfg.n_views = seq_len, n_views
+        model = ref_models.model_img.MMFN(cfg, "cpu")
+        fixtures.fill_module(model)
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        batches = [fixtures.synthetic_batch(2, "img", seed=42 + j, n_lidar=16384, lanes=4) for j in range(seq_len * n_views)]
+        pre = [reference_inputs(b, ref_dl) for b in batches]
+        b0 = batches[0]
+        args = ([f for f, _ in pre], [bev for _, bev in pre[:seq_len]], [b["map_u8"].float() for b in batches[:seq_len]],
+                [[b0["lane"]], [b0["lane_num"].float()], int(b0["lane_num"].max())], [b0["radar"]], [b0["radar_adj"]],
+                b0["target_point"], b0["velocity"])
+        gt = batches[0]["gt_wp"]
+        res[tag + "pos_emb_shapes"] = np.array([list(getattr(model.encoder, "transformer%d" % i).pos_emb.shape) for i in range(1, 5)])
+        bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        for m in bns:
+            m.momentum = 1.0
+        model.train()
+        with torch.no_grad():
+            model(*args)
+        model.eval()
+        with torch.no_grad():
+            res[tag + "eval_pred_wp"] = model(*args).numpy()
+        for m in bns:
+            m.momentum = 0.1
+        fixtures.fill_module(model)
+        model.train()
+        taps = {}
+        h = model.encoder.register_forward_hook(lambda m, i, o: taps.__setitem__("fused", o.detach().clone()))
+        pred = model(*args)
+        loss = torch.nn.functional.l1_loss(pred, gt, reduction="none").mean()
+        loss.backward()
+        h.remove()
+        res[tag + "train_pred_wp"] = pred.detach().numpy()
+        res[tag + "train_loss"] = np.float32(loss.item())
+        res[tag + "fused"] = taps["fused"].numpy()
+        names, gnorm, ghead = [], [], []
+        for k, p_ in model.named_parameters():
+            names.append(k)
+            gnorm.append(float(p_.grad.double().norm().item()))
+            h8 = np.zeros(8, np.float32)
+            flat = p_.grad.flatten()[:8].numpy()
+            h8[:flat.size] = flat
+            ghead.append(h8)
+        res[tag + "param_names"] = np.array(names)
+        res[tag + "grad_norm"] = np.array(gnorm, np.float64)
+        res[tag + "grad_head"] = np.stack(ghead)
+        print("img frames seq_len %d n_views %d: tokens %d, eval wp[0,0] %s, train_loss %s" % (
+            seq_len, n_views, res[tag + "pos_emb_shapes"][0][1], res[tag + "eval_pred_wp"][0, 0], res[tag + "train_loss"]))
+    np.savez_compressed(os.path.join(out_dir, "mmfn_img_frames.npz"), **res)
+
+
 def preprocessing_vectors(ref_dl, ref_du, out_dir):
     res = {}
     # histogram edge cases: bin edges, z == -2.0 boundary, clip > 5, out of range, right-closed last bin
@@ -319,6 +381,12 @@ def main():
         return
     install_shims()
     import importlib
+    if "--only-frames" in sys.argv:
+        torch.set_num_threads(8)
+        run_frames(types.SimpleNamespace(model_img=importlib.import_module("mmfn_utils.models.model_img")),
+                   importlib.import_module("mmfn_utils.datasets.dataloader"), importlib.import_module("mmfn_utils.datasets.config"),
+                   os.path.join(ROOT, "tests", "golden"))
+        return
     ref_models = types.SimpleNamespace(
         model_vec=importlib.import_module("mmfn_utils.models.model_vec"),
         model_img=importlib.import_module("mmfn_utils.models.model_img"),
@@ -337,6 +405,7 @@ def main():
     pid_vectors(ref_models, ref_cfg, out_dir)
     for variant in ("vec", "img", "rad"):
         run_variant(variant, ref_models, ref_dl, ref_cfg, out_dir)
+    run_frames(ref_models, ref_dl, ref_cfg, out_dir)
 
 
 if __name__ == "__main__":

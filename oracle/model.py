@@ -157,13 +157,22 @@ class _GPT(nn.Module):
                 nn.init.zeros_(m.bias)
 
     def forward(self, maps, velocity):
-        """maps: list of [B,C,8,8] pooled feature maps (token order = list order)."""
-        b = maps[0].shape[0]
-        tok = torch.cat([m.flatten(2).transpose(1, 2) for m in maps], dim=1)  # [B, n*64, C]
+        """maps: list of [B*frames_m,C,8,8] pooled feature maps, one entry per modality; a sample's frames_m frames
+        (n_views*seq_len camera frames, seq_len of the others) are consecutive.  Token order = modality order, then
+        frame order (GPT.forward, model_vec.py:223-246 / model_img.py:211-246)."""
+        b = velocity.shape[0]
+        gh, gw = self.grid
+        frames = [m.shape[0] // b for m in maps]
+        tok = torch.cat([m.reshape(b, f, self.n_embd, gh, gw) for m, f in zip(maps, frames)], dim=1)
+        tok = tok.permute(0, 1, 3, 4, 2).reshape(b, -1, self.n_embd)  # [B, sum(frames)*64, C]
         x = self.drop(self.pos_emb + tok + self.vel_emb(velocity.unsqueeze(1)).unsqueeze(1))
         x = self.ln_f(self.blocks(x))
-        x = x.view(b, len(maps), self.grid[0], self.grid[1], self.n_embd).permute(0, 1, 4, 2, 3)
-        return [x[:, i].contiguous() for i in range(len(maps))]
+        x = x.view(b, sum(frames), gh, gw, self.n_embd).permute(0, 1, 4, 2, 3)
+        outs, first = [], 0
+        for f in frames:
+            outs.append(x[:, first:first + f].reshape(b * f, self.n_embd, gh, gw))
+            first += f
+        return outs
 
 
 # --------------------------------------------------------------------------
@@ -355,11 +364,12 @@ class _Encoder(nn.Module):
                 f_rad = f_rad + outs[3]
             if taps is not None:
                 taps["fused%d" % (s + 1)] = (f_img, f_lid, f_map)
-        gap = lambda net, f: torch.flatten(net.avgpool(f), 1)
+        # every frame of every modality is pooled and summed (model_vec.py:585-596, model_img.py:410-423)
+        gap = lambda net, f: torch.flatten(net.avgpool(f), 1).view(bz, f.shape[0] // bz, -1)
         feats = [gap(img_net, f_img), gap(lid_net, f_lid), gap(map_net, f_map)]
         if f_rad is not None:
             feats.append(gap(self.radar_encoder, f_rad))
-        return torch.stack(feats, dim=1).sum(dim=1)
+        return torch.cat(feats, dim=1).sum(dim=1)
 
 
 class PIDController(object):

@@ -93,3 +93,30 @@ def test_model_against_reference(golden_dir, variant):
     sd = model.state_dict()
     got_bn = np.stack([sd[k].flatten()[:8].numpy() for k in g["bn_keys"]])
     np.testing.assert_allclose(got_bn, g["bn_head_after_step"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("seq_len,n_views", [(2, 1), (1, 2)])
+def test_image_model_with_several_frames_against_reference(golden_dir, seq_len, n_views):
+    """seq_len > 1 / n_views > 1 (model_img.py:211-246, :410-423): each sample's frames share one token sequence."""
+    g = _load(golden_dir, "mmfn_img_frames.npz")
+    tag = "s%dv%d_" % (seq_len, n_views)
+    torch.set_num_threads(8)
+    model = harness.build_oracle("img", seq_len=seq_len, n_views=n_views)
+    shapes = [list(getattr(model.encoder, "transformer%d" % i).pos_emb.shape) for i in range(1, 5)]
+    assert shapes == g[tag + "pos_emb_shapes"].tolist()
+    assert shapes[0][1] == (n_views + 2) * seq_len * 64
+    assert [k for k, _ in model.named_parameters()] == list(g[tag + "param_names"])
+    _, args, gt = harness.frames_args(seq_len, n_views)
+    harness.calibrate_bn(model, args)
+    with torch.no_grad():
+        np.testing.assert_allclose(model(*args).numpy(), g[tag + "eval_pred_wp"], rtol=0, atol=1e-6)
+    fixtures.fill_module(model)
+    taps = {}
+    model.train()
+    pred = model(*args, taps=taps)
+    np.testing.assert_allclose(taps["fused"].detach().numpy(), g[tag + "fused"], rtol=1e-5, atol=1e-5)
+    pred, loss, grads = harness.train_step(model, args, gt)
+    np.testing.assert_allclose(pred.numpy(), g[tag + "train_pred_wp"], rtol=0, atol=1e-6)
+    assert abs(float(loss) - float(g[tag + "train_loss"])) <= 1e-6
+    norms = np.array([float(grads[k].double().norm()) for k in g[tag + "param_names"]])
+    np.testing.assert_allclose(norms, g[tag + "grad_norm"], rtol=2e-3, atol=1e-7)

@@ -89,7 +89,9 @@ def test_checkpoint_files_and_resume(store, tmp_path):
     for f in ("recent.log", "best_model.pth", "best_optim.pth", "model.pth", "recent_optim.pth"):
         assert os.path.isfile(os.path.join(logdir, f)), f
     table = json.load(open(os.path.join(logdir, "recent.log")))
-    assert set(table) == {"epoch", "iter", "bestval", "bestval_epoch", "train_loss", "val_loss"} and table["epoch"] == 1
+    # the reference's six keys (phase2_train_net.py:165-176) plus this trainer's checkpoint stamps
+    assert set(table) == {"epoch", "iter", "bestval", "bestval_epoch", "train_loss", "val_loss", "files"} and table["epoch"] == 1
+    assert set(table["files"]) == {"model.pth", "recent_optim.pth", "best_model.pth", "best_optim.pth"}
 
     # the optimizer file is a torch.optim.AdamW state dict: torch loads it onto the same parameter list
     osd = torch.load(os.path.join(logdir, "best_optim.pth"))
