@@ -41,13 +41,16 @@ PRESETS = {
 }
 
 
-def synth_inputs(B, device, seed, lanes=64, n_lidar=16384, variant="vec", lane_format="10x5"):
+def synth_inputs(B, device, seed, lanes=64, n_lidar=16384, variant="vec", lane_format="10x5", seq_len=1, n_views=1):
+    """B samples; with seq_len / n_views > 1 a sample's n_views*seq_len camera frames, seq_len sweeps and seq_len maps are
+    consecutive batch entries (torch.stack(list, dim=1).view(bz * n, ...), model_vec.py:506-508)."""
     g = torch.Generator().manual_seed(seed)
-    rgb = torch.randint(0, 256, (B, 300, 400, 3), generator=g, dtype=torch.uint8)
-    pts = torch.empty(B, n_lidar, 4)
-    pts[..., 0:2] = torch.rand(B, n_lidar, 2, generator=g) * 40.0 - 20.0
-    pts[..., 2] = torch.rand(B, n_lidar, generator=g) * 4.0 - 3.0
-    pts[..., 3] = torch.rand(B, n_lidar, generator=g)
+    Bi, Bs = B * n_views * seq_len, B * seq_len
+    rgb = torch.randint(0, 256, (Bi, 300, 400, 3), generator=g, dtype=torch.uint8)
+    pts = torch.empty(Bs, n_lidar, 4)
+    pts[..., 0:2] = torch.rand(Bs, n_lidar, 2, generator=g) * 40.0 - 20.0
+    pts[..., 2] = torch.rand(Bs, n_lidar, generator=g) * 4.0 - 3.0
+    pts[..., 3] = torch.rand(Bs, n_lidar, generator=g)
     pts[:, n_lidar - n_lidar // 16:, 0] = 1e6
     lane = torch.zeros(B, lanes, 10, 5)
     lane[..., 0:2] = torch.randn(B, lanes, 10, 2, generator=g) * 8.0
@@ -67,7 +70,7 @@ def synth_inputs(B, device, seed, lanes=64, n_lidar=16384, variant="vec", lane_f
     gt = torch.randn(B, 4, 2, generator=g) * 5.0
     if variant == "img":  # raster map instead of lanes (model_img.py:337: not normalised)
         del inp["lane"], inp["lane_num"]
-        inp["map"] = torch.randint(0, 256, (B, 3, 256, 256), generator=g, dtype=torch.uint8).float()
+        inp["map"] = torch.randint(0, 256, (Bs, 3, 256, 256), generator=g, dtype=torch.uint8).float()
     if variant == "rad":
         radar = torch.randn(B, 81, 5, generator=g)
         radar[..., 3] = radar[..., 3].abs() + 0.5
@@ -332,6 +335,8 @@ def main():
     ap.add_argument("--workload", default="train", choices=["train", "image-only"],
                     help="train = full step (BASELINE configs[1]); image-only = ResNet-34 branch fwd+bwd (configs[3])")
     ap.add_argument("--n-lidar", type=int, default=16384, help="LiDAR points per sample (configs[4]: 65536)")
+    ap.add_argument("--seq-len", type=int, default=1, help="frames per sample and modality (image-map model only; the reference trains with 1)")
+    ap.add_argument("--n-views", type=int, default=1, help="camera views per frame (the reference trains with 1)")
     ap.add_argument("--lane-format", default="10x5", choices=["10x5", "19x8"],
                     help="10x5 = the reference's lane nodes (parity format, default); 19x8 = north_star's perf-only pre-vectorised "
                          "polylines [B,64,19,8] (VectorNet with lane_channels=8; no reference checkpoint has this shape)")
@@ -391,10 +396,14 @@ def main():
 
     torch.manual_seed(42)  # init_torch(): run_steps/utils.py:77-84
     net = {"vec": MMFN, "img": MMFNImg, "rad": MMFNRad}[args.variant](GlobalConfig(gemm_dtype="bf16" if args.dtype == "bf16-operands" else "f32", act_dtype="bf16" if args.dtype == "bf16" else "f32",
-                                                                       lane_channels=8 if args.lane_format == "19x8" else 7), dev)
+                                                                       lane_channels=8 if args.lane_format == "19x8" else 7, seq_len=args.seq_len, n_views=args.n_views), dev)
     net.train()
     B = args.batch
-    inp, gt = synth_inputs(B, dev, seed=42 + rank, n_lidar=args.n_lidar, variant=args.variant, lane_format=args.lane_format)
+    inp, gt = synth_inputs(B, dev, seed=42 + rank, n_lidar=args.n_lidar, variant=args.variant, lane_format=args.lane_format,
+                           seq_len=args.seq_len, n_views=args.n_views)
+    several_frames = (args.seq_len, args.n_views) != (1, 1)
+    if several_frames:   # the oracle check and the CPU baseline below are wired for the one-frame workloads
+        args.no_oracle_check = args.no_cpu_baseline = True
     comm_capi, transport_note = None, None
     want = os.environ.get("MMFN_DP_TRANSPORT", "auto")   # auto | capi | torch
     if world > 1 and want != "torch":
@@ -557,6 +566,9 @@ def main():
                 % (args.variant, {"vec": "VectorNet", "img": "ResNet34 raster map", "rad": "VectorNet + radar GAT"}[args.variant], B,
                    args.n_lidar, "256x256x3 raster map" if args.variant == "img" else ("64x19x8 pre-vectorised polylines" if args.lane_format == "19x8" else "64x10x5 lanes")
                    + (" + 81x5 radar" if args.variant == "rad" else "")))
+    if several_frames:
+        workload += "; seq_len %d, n_views %d: %d camera + %d LiDAR + %d map frames per sample" % (
+            args.seq_len, args.n_views, args.seq_len * args.n_views, args.seq_len, args.seq_len)
     if image_only:
         workload = "ResNet-34 camera branch alone, fwd+bwd (no optimizer), batch %d, 400x300x3 u8 RGB" % B
 

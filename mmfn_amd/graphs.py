@@ -29,6 +29,45 @@ import os
 import torch
 
 
+# Retired captures.  Measured on ROCm 7.0 (tools/experiments/segv_bisect.sh): destroying a hipGraphExec at the moment
+# Python's garbage collector happens to reach it - while another captured step is replaying - can leave the runtime's
+# graph-launch streams dangling, and a later hipGraphLaunch of an unrelated graph dies in hip::Graph::UpdateStreams.  So a
+# dropped Graph parks its CUDAGraph here, and the parked ones are destroyed at a safe point only: device idle, nothing
+# capturing (drain_graveyard: before every capture and when the trainer evicts a shape).
+_graveyard = []
+_KEEP_FOREVER = os.environ.get("MMFN_KEEP_GRAPHS") == "1"   # experiment: never destroy a captured graph
+
+
+class Graph(object):
+    """torch.cuda.CUDAGraph with deferred destruction (see _graveyard)."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = torch.cuda.CUDAGraph()
+
+    def capture_begin(self, *a, **kw):
+        self.g.capture_begin(*a, **kw)
+
+    def capture_end(self):
+        self.g.capture_end()
+
+    def replay(self):
+        self.g.replay()
+
+    def __del__(self):
+        g, self.g = self.g, None
+        if g is not None and _graveyard is not None:   # (None: interpreter shutdown)
+            _graveyard.append(g)
+
+
+def drain_graveyard():
+    """Destroy the retired captures.  Call with no capture in progress; waits for the device first."""
+    if _graveyard and not _KEEP_FOREVER:
+        torch.cuda.synchronize()
+        del _graveyard[:]
+        torch.cuda.synchronize()
+
+
 class Recorder(object):
     def __init__(self, engine, split_lanes=None):
         self.engine = engine
@@ -42,7 +81,7 @@ class Recorder(object):
 
     # ------------------------------------------------------------------ capture
     def _begin(self):
-        self._g = torch.cuda.CUDAGraph()
+        self._g = Graph()
         self._g.capture_begin(capture_error_mode="thread_local")   # RCCL's watchdog thread may poll events meanwhile
 
     def _end(self):
@@ -60,6 +99,7 @@ class Recorder(object):
             raise RuntimeError("a lane-graph capture is already in progress on this engine")
         torch.cuda.synchronize()
         gc.collect()
+        drain_graveyard()
         self._stream = torch.cuda.Stream(device=eng.device)
         self._stream.wait_stream(torch.cuda.current_stream())
         eng._recorder = self
@@ -136,7 +176,7 @@ class Recorder(object):
         lanes, outs = [], []
         side_outs = []
         for lane_id, (st, fns) in enumerate(groups[1:], start=1):
-            g = torch.cuda.CUDAGraph()
+            g = Graph()
             with torch.cuda.stream(st), ops.lane(lane_id):
                 side_outs.append(self._captured(g, lambda fns=fns: [f() for f in fns]))
             lanes.append((st, g, torch.cuda.Event()))
@@ -159,7 +199,7 @@ class Recorder(object):
         the chain to another hardware queue (10-16 us idle per hop); an eager event between two linear graphs is exact."""
         from . import ops
         self._end()
-        g = torch.cuda.CUDAGraph()
+        g = Graph()
         with torch.cuda.stream(stream), ops.lane(lane_id):
             self._captured(g, fn)
         self.n_graphs += 1

@@ -54,7 +54,9 @@ class DrivingSession(object):
             self.pred, _ = self.eng.forward(self.inp, False, None, folded=self.fold)  # sizes every buffer
             torch.cuda.synchronize()
             if use_graph:
-                g = torch.cuda.CUDAGraph()
+                from . import graphs
+                graphs.drain_graveyard()
+                g = graphs.Graph()
                 with torch.cuda.graph(g):
                     self.pred, _ = self.eng.forward(self.inp, False, None, folded=self.fold)
                 self.graph = g

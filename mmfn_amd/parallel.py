@@ -262,8 +262,10 @@ class StaticEvalStep(object):
         self.engine = engine
         self.inp = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
         self.gt = gt.clone()
+        from . import graphs
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
+        graphs.drain_graveyard()
+        self.graph = graphs.Graph()
         with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.pred, self.loss = engine.forward(self.inp, False, self.gt)
 

@@ -31,9 +31,11 @@ def _release(state):
     if isinstance(state, str) or state is None:
         return
     import gc
+    from . import graphs
     torch.cuda.synchronize()
     del state
     gc.collect()
+    graphs.drain_graveyard()   # the capture's hipGraphExecs are destroyed here, with the device idle
 
 
 class Trainer(object):

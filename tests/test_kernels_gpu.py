@@ -179,6 +179,63 @@ def test_tokens_and_upsample(S, C):
         _close(dF.permute(0, 3, 1, 2), G + fr[m].grad, 1e-5, "pool bcast add")
 
 
+@pytest.mark.parametrize("S,C", [(64, 64), (16, 256), (8, 512)])
+@pytest.mark.parametrize("frames", [[2, 2, 2], [2, 1, 1], [3, 1, 2]])
+def test_tokens_and_upsample_with_several_frames(S, C, frames):
+    """seq_len / n_views > 1: modality m holds frames[m] maps per sample, each its own 64-token group
+    (GPT.forward, model_img.py:211-246); references built with the reference's view / cat / slice recipe."""
+    from mmfn_amd import ops
+    g = _g(S + C + sum(frames))
+    B, n, ng = 2, len(frames), sum(frames)
+    base = [sum(frames[:m]) for m in range(n)]
+    feats = [torch.randn(B * f, C, S, S, generator=g) for f in frames]
+    pos = torch.randn(1, ng * 64, C, generator=g)
+    vw, vb, vel = torch.randn(C, 1, generator=g), torch.randn(C, generator=g), torch.rand(B, generator=g) * 8
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    pooled = [F.adaptive_avg_pool2d(f, (8, 8)).view(B, k, C, 8, 8) for f, k in zip(fr, frames)]
+    tok_ref = torch.cat(pooled, dim=1).permute(0, 1, 3, 4, 2).contiguous().view(B, -1, C)
+    tok_ref = pos + tok_ref + F.linear(vel.unsqueeze(1), vw, vb).unsqueeze(1)
+    gt = torch.randn(tok_ref.shape, generator=g)
+    tok_ref.backward(gt)
+    fd = [f.permute(0, 2, 3, 1).contiguous().to(DEV) for f in feats]
+    tok = ops.tokens_fwd(fd, pos[0].contiguous().to(DEV), vw[:, 0].contiguous().to(DEV), vb.to(DEV), vel.to(DEV),
+                         torch.empty(B, ng * 64, C, device=DEV), frames=frames)
+    _close(tok, tok_ref, 1e-5, "tokens fwd")
+    with pytest.raises(ValueError):
+        ops.tokens_fwd(fd, pos[0].contiguous().to(DEV), vw[:, 0].contiguous().to(DEV), vb.to(DEV), vel.to(DEV),
+                       torch.empty(B, ng * 64, C, device=DEV), frames=[f + 1 for f in frames])
+    for m in range(n):
+        k = frames[m]
+        t = torch.randn(B, ng * 64, C, generator=g)
+        tr = t.clone().requires_grad_(True)
+        fm = feats[m].clone().requires_grad_(True)
+        x = tr.view(B, ng, 8, 8, C).permute(0, 1, 4, 2, 3)
+        grid = x[:, base[m]:base[m] + k].contiguous().view(B * k, C, 8, 8)
+        up = grid if S == 8 else F.interpolate(grid, scale_factor=S // 8, mode="bilinear", align_corners=True)
+        out_ref = fm + up
+        G = torch.randn(out_ref.shape, generator=g)
+        out_ref.backward(G)
+        out = ops.upsample_add_fwd(fd[m], t.to(DEV), torch.empty_like(fd[m]), base[m], k)
+        _close(out.permute(0, 3, 1, 2), out_ref, 1e-5, "upsample fwd")
+        Gd = G.permute(0, 2, 3, 1).contiguous().to(DEV)
+        gtok = torch.zeros(B, ng * 64, C, device=DEV)
+        ops.upsample_adj(Gd, gtok, base[m], k)
+        _close(gtok, tr.grad, 2e-5, "upsample adjoint")   # the other modalities' groups stay zero
+        dF = ops.pool_bcast_add(Gd, gt.to(DEV), torch.empty_like(Gd), base[m], k)
+        _close(dF.permute(0, 3, 1, 2), G + fr[m].grad, 1e-5, "pool bcast add")
+    # the final global-average-pool + sum over every frame of every modality (model_img.py:410-423)
+    f8 = [torch.randn(B * k, 512, 8, 8, generator=g).requires_grad_(True) for k in frames]
+    ref = torch.cat([f.mean(dim=(2, 3)).view(B, k, -1) for f, k in zip(f8, frames)], dim=1).sum(dim=1)
+    gg = torch.randn(B, 512, generator=g)
+    ref.backward(gg)
+    f8d = [f.detach().permute(0, 2, 3, 1).contiguous().to(DEV) for f in f8]
+    _close(ops.gap_sum_fwd(f8d, torch.empty(B, 512, device=DEV), frames=frames), ref, 1e-5)
+    outs = [torch.full_like(f, float("nan")) for f in f8d]
+    ops.gap_sum_bwd(gg.to(DEV), outs, frames=frames)
+    for o, f in zip(outs, f8):
+        _close(o.permute(0, 3, 1, 2), f.grad, 1e-6)
+
+
 def test_gap_and_transpose():
     from mmfn_amd import ops
     g = _g(9)
@@ -197,7 +254,8 @@ def test_gap_and_transpose():
 
 # ------------------------------------------------------------------ attention
 @pytest.mark.parametrize("T,NH,HS", [(192, 4, 16), (192, 4, 32), (192, 4, 64), (192, 4, 128), (256, 4, 128),
-                                     (128, 2, 64), (128, 4, 128), (64, 2, 64), (64, 3, 32), (9, 2, 64), (50, 2, 64)])
+                                     (128, 2, 64), (128, 4, 128), (64, 2, 64), (64, 3, 32), (9, 2, 64), (50, 2, 64),
+                                     (384, 4, 16), (384, 4, 32), (320, 4, 64), (384, 4, 128)])   # seq_len / n_views > 1
 @pytest.mark.parametrize("masked", [False, True])
 def test_attention(T, NH, HS, masked):
     from mmfn_amd import ops
