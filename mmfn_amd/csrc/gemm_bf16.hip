@@ -90,8 +90,22 @@ struct NtCfg {
   static constexpr int SMEM = NS * STAGE > EPI ? NS * STAGE : EPI;
 };
 
+// Stride-2 data gradient by output-pixel parity.  An input pixel (ih, iw) receives only the taps with kh == (ih + pad) mod 2,
+// kw == (iw + pad) mod 2: of the nine taps of a 3x3 filter one, two, two or four, of a 1x1 filter one or none - gathered
+// naively, 3/4 of the k-tiles multiply the zero page.  So the rows of such a launch are taken in parity-pure tiles: row tile
+// t holds BM pixels of class t & 3 (classes interleaved, so that the contiguous run of tiles an XCD gets and the dispatch order
+// both mix heavy and light classes), and its k-loop visits the live taps only.
+__device__ __forceinline__ int parity_pixel_row(const mmfn_gemm16_desc& d, int cls, int local) {
+  const int w2 = d.W >> 1, hw2 = (d.H >> 1) * w2;
+  const int b = local / hw2, rem = local - b * hw2;
+  const int i = rem / w2, j = rem - i * w2;
+  return (b * d.H + 2 * i + (cls >> 1)) * d.W + 2 * j + (cls & 1);
+}
+
 template <int FORM, int BM, int BN, int NS>
-__global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d, const int tiles_n, const int tap_shift) {
+__global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d, const int tiles_n, const int tap_arg) {
+  const int tap_shift = tap_arg & 255;
+  const bool par = FORM == 2 && (tap_arg >> 8) != 0;
   constexpr int TM = BM / 64, TN = BN / 64;      // 32x32 accumulator tiles per wave (2 x 2 waves)
   constexpr int PA = BM / 32, PB = BN / 32;      // 1 KB pieces (8 rows) per wave per stage
   constexpr int STAGE = NtCfg<BM, BN, NS>::STAGE;
@@ -101,8 +115,21 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
-  const int nkt = d.K / BK;
+  const int tile_m = bid / tiles_n;
+  const int n0 = (bid % tiles_n) * BN;
+  // par: m0 counts the rows of the tile's parity class (local rows), Mlim = pixels per class
+  const int pcls = par ? (tile_m & 3) : 0;
+  const int m0 = (par ? (tile_m >> 2) : tile_m) * BM;
+  const int Mlim = par ? (d.M >> 2) : d.M;
+  int nkt = d.K / BK;
+  unsigned long long live_taps = 0;   // par: 4 bits per live tap, in tap order
+  if (par) {
+    const int py = pcls >> 1, px = pcls & 1;
+    int nlive = 0;
+    for (int kh = (py + d.pad) & 1; kh < d.KH; kh += 2)
+      for (int kw = (px + d.pad) & 1; kw < d.KW; kw += 2) live_taps |= (unsigned long long)(kh * d.KW + kw) << (4 * nlive++);
+    nkt = nlive << tap_shift;
+  }
   const bf16_t* A = reinterpret_cast<const bf16_t*>(d.A);
   const bf16_t* Bp = reinterpret_cast<const bf16_t*>(d.B);
   const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero16);
@@ -116,7 +143,8 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
   for (int i = 0; i < PA; ++i) {
     const int r = (wave + 4 * i) * 8 + lr;
     const int c = ls ^ nt_swz(r);
-    const int m = min(m0 + r, d.M - 1);
+    int m = min(m0 + r, Mlim - 1);
+    if (par) m = parity_pixel_row(d, pcls, m);
     ay[i] = ax[i] = 0;
     if (FORM == 0) {
       pa[i] = A + (size_t)m * d.lda + c * 8;
@@ -147,10 +175,15 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
     unsigned char* As = smem + buf * STAGE;
     unsigned char* Bs = As + BM * 128;
     const bool live = kt < nkt;   // past the end: the same number of (dummy) loads, so the counted waits stay constant
-    int kh = 0, kw = 0, c0 = 0;
+    int kh = 0, kw = 0, c0 = 0, ktb = kt;   // ktb: this k-tile's position in the filter operand
     if (FORM != 0) {   // wave-uniform tap of this k-tile (channels % 64 == 0: a k-tile never straddles a tap)
-      const int tap = kt >> tap_shift;
-      c0 = (kt - (tap << tap_shift)) * BK;
+      int tap = kt >> tap_shift;
+      const int chunk = kt - (tap << tap_shift);
+      if (par) {
+        tap = (int)((live_taps >> (4 * tap)) & 15);
+        ktb = (tap << tap_shift) + chunk;
+      }
+      c0 = chunk * BK;
       kh = tap / d.KW;
       kw = tap - kh * d.KW;
     }
@@ -180,7 +213,7 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
       glds16(src, As + (wave + 4 * i) * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < PB; ++i) glds16(live ? pb[i] + (size_t)kt * BK : zero, Bs + (wave + 4 * i) * 1024);
+    for (int i = 0; i < PB; ++i) glds16(live ? pb[i] + (size_t)ktb * BK : zero, Bs + (wave + 4 * i) * 1024);
   };
 
   f32x16 acc[TM][TN];
@@ -278,8 +311,9 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
 #pragma unroll
   for (int p = 0; p < TM * 32 / RPP; ++p) {
     const int rl = p * RPP + lane / LPR;
-    const int row = m0 + wm * TM * 32 + rl;
-    if (row >= d.M || !col_ok) continue;
+    const int lrow = m0 + wm * TM * 32 + rl;
+    if (lrow >= Mlim || !col_ok) continue;
+    const int row = par ? parity_pixel_row(d, pcls, lrow) : lrow;
     float v[8];
     {
       const int sw = (rl >> 1) & 1, q0 = cl >> 2;
@@ -380,7 +414,7 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
       for (int o = LPR; o < 64; o <<= 1) { s1[e] += __shfl_xor(s1[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
     }
     if (lane < LPR && col_ok) {
-      double* p = d.stats + ((size_t)(bid / tiles_n) * 2 + wm) * 2 * d.N;
+      double* p = d.stats + ((size_t)tile_m * 2 + wm) * 2 * d.N;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { p[col + e] = (double)s1[e]; p[d.N + col + e] = (double)s2[e]; }
     }
@@ -619,6 +653,15 @@ extern "C" int mmfn_gemm_bf16_stats_rows(const mmfn_gemm16_desc* d) {
   return 2 * ceil_div(d->M, bm);
 }
 
+// stride-2 data gradients run by pixel parity (parity_pixel_row) when every row tile can be parity-pure; MMFN_G16_PARITY=0:
+// the plain gather (A/B runs)
+bool parity_dgrad_ok(const mmfn_gemm16_desc& d, int bm) {
+  static const bool on = [] { const char* e = getenv("MMFN_G16_PARITY"); return !(e && e[0] == '0'); }();
+  if (!on || d.form != 2 || d.stride != 2 || (d.H & 1) || (d.W & 1) || d.KH * d.KW > 9 || d.H <= 0 || d.W <= 0) return false;
+  if (d.M % (d.H * d.W) || (d.M / 4) % bm) return false;
+  return true;
+}
+
 template <int F, int BM_, int BN_, int NS_>
 int launch_nt_ns(const mmfn_gemm16_desc& d, int tap_shift, hipStream_t s) {
   constexpr int smem = NtCfg<BM_, BN_, NS_>::SMEM;
@@ -629,8 +672,10 @@ int launch_nt_ns(const mmfn_gemm16_desc& d, int tap_shift, hipStream_t s) {
       return MMFN_EINVAL;
     ready = true;
   }
+  int tap_arg = tap_shift;
+  if (F == 2 && parity_dgrad_ok(d, BM_)) tap_arg |= 1 << 8;
   hipLaunchKernelGGL((gemm16_nt_kernel<F, BM_, BN_, NS_>), dim3(ceil_div(d.M, BM_) * ceil_div(d.N, BN_)), dim3(NT), smem, s, d,
-                     ceil_div(d.N, BN_), tap_shift);
+                     ceil_div(d.N, BN_), tap_arg);
   return 0;
 }
 template <int F, int BM_, int BN_>

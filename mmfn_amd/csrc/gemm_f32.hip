@@ -428,7 +428,9 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
   const bool dgp = (AM == MMFN_A_DGRAD) && d.dg_parity;
   int py = 0, px = 0, kh0 = 0, kw0 = 0, nkw = d.KW, Mloc = d.M, Kloc = d.K;
   if (dgp) {
-    py = blockIdx.z >> 1; px = blockIdx.z & 1;
+    // heaviest class first: with pad 1 (every 3x3 here) class (py, px) = (1, 1) has four taps and (0, 0) one; blocks are
+    // dispatched z-major, and the long blocks must not be the ones left for the tail
+    py = 1 - (int)(blockIdx.z >> 1); px = 1 - (int)(blockIdx.z & 1);
     kh0 = (py + d.pad) & 1; kw0 = (px + d.pad) & 1;
     const int nkh = (d.KH - kh0 + 1) >> 1;
     nkw = (d.KW - kw0 + 1) >> 1;

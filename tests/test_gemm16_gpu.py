@@ -118,7 +118,8 @@ def test_convolution_forward_dgrad_wgrad(B, H, W, Ci, Co, k, s, p):
     _close(dw, wt.grad.permute(0, 2, 3, 1), tol=3e-3)
 
 
-def test_epilogue_partial_sums_bias_gradient_and_batchnorm_backward_reductions():
+@pytest.mark.parametrize("stride", [1, 2])   # 2: the data gradient runs in parity-pure row tiles (gemm_bf16.hip parity_pixel_row)
+def test_epilogue_partial_sums_bias_gradient_and_batchnorm_backward_reductions(stride):
     """stats_mode 1: column sums of the FINAL epilogue value (the bias gradient of the Linear whose dX the launch computes);
     stats_mode 2: the two reductions of the BatchNorm backward that the launch's output gradient enters, with the consumer's
     ReLU mask - against mmfn_bn_bwd_bf16's own reduction pass on the stored tensors."""
@@ -134,7 +135,7 @@ def test_epilogue_partial_sums_bias_gradient_and_batchnorm_backward_reductions()
     assert torch.allclose(got, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
     # BatchNorm-backward reductions from a data-gradient epilogue
     B, H, W, Ci, Co = 2, 16, 16, 128, 128
-    dyc = _rnd(B, H, W, Co, seed=4)
+    dyc = _rnd(B, H // stride, W // stride, Co, seed=4)
     w_t = _rnd(Ci, 3, 3, Co, scale=0.05, seed=5)
     res = _rnd(B, H, W, Ci, seed=6)
     y_c, x_c = _rnd(B, H, W, Ci, seed=7), _rnd(B, H, W, Ci, seed=8, scale=2.0)
@@ -142,9 +143,13 @@ def test_epilogue_partial_sums_bias_gradient_and_batchnorm_backward_reductions()
     Mx = B * H * W
     part = torch.zeros(ops16.max_stats_rows(Mx), 2, Ci, dtype=torch.float64, device=DEV)
     dx = torch.empty(B, H, W, Ci, dtype=torch.bfloat16, device=DEV)
-    ops16.conv2d_dgrad(dyc, w_t, (B, H, W, Ci), (Co, 3, 3, Ci), 1, 1, dx, res=res.view(-1, Ci), ldr=Ci, stats=part, stats_mode=2,
+    ops16.conv2d_dgrad(dyc, w_t, (B, H, W, Ci), (Co, 3, 3, Ci), stride, 1, dx, res=res.view(-1, Ci), ldr=Ci, stats=part, stats_mode=2,
                        bn=(y_c, x_c, mean, rstd))
-    g_, _ = ops.conv_geom((B, H, W, Ci), (Co, 3, 3, Ci), 1, 1)
+    # the data gradient itself (+ residual) against torch
+    xt = torch.zeros(B, Ci, H, W, device=DEV, requires_grad=True)
+    F.conv2d(xt, w_t.float().permute(3, 0, 1, 2), stride=stride, padding=1).backward(dyc.float().permute(0, 3, 1, 2))
+    _close(dx, xt.grad.permute(0, 2, 3, 1) + res.float())
+    g_, _ = ops.conv_geom((B, H, W, Ci), (Co, 3, 3, Ci), stride, 1)
     rows = ops16.gemm_stats_rows(ops16.G16_CONV_DGRAD, Mx, Ci, 9 * Co, g_)
     wgt = torch.rand(Ci, device=DEV) + 0.5
     outs = []
