@@ -502,6 +502,11 @@ class _ForkEach(list):
         self.ctx.offload(fn)
 
 
+# AdamW per readiness group under the backward (Engine.backward_and_step).  OFF: measured slower than the single launch after the
+# backward - 1685-1690 vs 1745-1755 samples/s in the bf16 mode, 934 vs 951 in fp32 (and 1520 / 855 with the fork attached before
+# the writing stream's next kernel) - for any grid size of the per-group launches: the 17 extra branches of the replayed graph
+# cost more than the 0.5-0.6 ms of optimizer they hide.  Kept as a tested option (bit-identical results).
+OVERLAP_ADAMW = os.environ.get("MMFN_OVERLAP_ADAMW", "0") == "1"
 GPT_GROUP_MIN_C = int(os.environ.get("MMFN_GPT_GROUP_MIN_C", "0"))
 GPT_GROUP_MAX_C = int(os.environ.get("MMFN_GPT_GROUP_MAX_C", "0"))   # widest transformer whose weight gradients run as batched launches
 
@@ -1134,6 +1139,11 @@ class Engine(object):
         self.opt_hyper = torch.zeros(16, 8, dtype=torch.float32, device=dev)
         self._hyper_host = None
         self._hyper_pinned, self._hyper_slot = None, 0
+        self.opt_stream = None    # stream of the per-group AdamW launches (backward_and_step)
+        self._opt_ranges = None   # readiness group -> (begin, end) of the flat buffer, once checked to tile [0, tail)
+        self._opt_done = set()
+        self._opt_pending = []
+        self._opt_ngroups = 1
         self.n_lanes = int(os.environ.get("MMFN_BRANCH_LANES", "3"))
         self.offload_wgrad = os.environ.get("MMFN_OFFLOAD_WGRAD", "1") == "1"
 
@@ -1512,6 +1522,109 @@ class Engine(object):
         ops.adamw_groups(L.params, L.grads, L.exp_avg, L.exp_avg_sq, self.step_count, self.opt_hyper, len(groups),
                          group_of=self.opt_group_of if len(groups) > 1 else None, n=L.tail)
 
+    # ---- the optimizer of a fused step, range by range under the backward (option, see OVERLAP_ADAMW)
+    # AdamW is elementwise, and the gradients of a readiness group (params.FlatLayout.group_ranges) are final long before the
+    # backward ends - the deepest fusion transformer's 25 M parameters first.  With the option on, the step's AdamW is issued per
+    # group, on a stream of its own, once the group is reported complete (the same hook the data-parallel buckets use) instead of
+    # as one pass over 105 M parameters after the last backward kernel.  Data parallel on the C-ABI transport: a group's AdamW
+    # follows its all-reduce on the communication stream.  Same kernel, same operands per element: bit-identical results.
+    def overlapped_step_ok(self, dp=None):
+        if not OVERLAP_ADAMW or (self._recorder is not None and self._recorder.split_lanes):
+            return False
+        if dp is not None and dp.comm is None:
+            return False   # torch.distributed transport: the reductions complete on streams we do not own
+        if self._opt_ranges is None:
+            L = self.layout
+            spans = sorted(L.group_ranges.items(), key=lambda kv: kv[1][0])
+            pos, ok = 0, True
+            for _, (b, e) in spans:
+                e = min(e, L.tail)
+                ok = ok and b == pos and b % 4 == 0 and e % 4 == 0
+                pos = max(pos, e)
+            self._opt_ranges = {k: (b, min(e, L.tail)) for k, (b, e) in spans} if ok and pos == L.tail else {}
+        return bool(self._opt_ranges)
+
+    def _step_begin(self, lr, grad_scale, adam):
+        groups = self.hyper_rows(lr=lr, grad_scale=grad_scale, **adam)
+        self.set_hyper(groups)
+        self.module.weights_changed()
+        ops.step_advance(self.step_count)
+        self._opt_done = set()
+        self._opt_pending = []
+        self._opt_ngroups = len(groups)
+        if self.opt_stream is None:
+            self.opt_stream = torch.cuda.Stream(device=self.device)
+
+    def _step_range(self, key, on=None):
+        """AdamW over readiness group `key`, ordered after everything enqueued so far on the current stream (on=None: on the
+        optimizer stream) or simply enqueued on stream `on` (the communication stream, behind the group's all-reduce)."""
+        if key in self._opt_done or key not in self._opt_ranges:
+            return
+        self._opt_done.add(key)
+        b, e = self._opt_ranges[key]
+        if e <= b:
+            return
+        if on is not None:
+            self._adamw_span(b, e, on)
+            return
+        # The fork is issued one hook LATE: a captured graph keeps the first-captured child of a node on the node's hardware
+        # queue and moves later children to other queues (graphs.py), so the stream that wrote this group must capture its
+        # next kernel before the optimizer branch is attached to the same point - the event marks the point now, the wait on
+        # it (and the launch) follow at the next hook / at the end.
+        self._step_flush()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._opt_pending.append((b, e, ev))
+
+    def _adamw_span(self, b, e, st):
+        L = self.layout
+        with torch.cuda.stream(st):
+            ops.adamw_groups(L.params[b:e], L.grads[b:e], L.exp_avg[b:e], L.exp_avg_sq[b:e], self.step_count, self.opt_hyper,
+                             self._opt_ngroups, group_of=self.opt_group_of[b // 4:e // 4] if self._opt_ngroups > 1 else None, n=e - b)
+
+    def _step_flush(self):
+        for b, e, ev in self._opt_pending:
+            self.opt_stream.wait_event(ev)
+            self._adamw_span(b, e, self.opt_stream)
+        self._opt_pending = []
+
+    def _step_finish(self, on=None):
+        for key in sorted(self._opt_ranges, key=lambda k: self._opt_ranges[k][0]):   # groups this variant never reports
+            self._step_range(key, on=on)
+        if on is None:
+            self._step_flush()
+            done = torch.cuda.Event()
+            done.record(self.opt_stream)
+            torch.cuda.current_stream().wait_event(done)
+
+    def backward_and_step(self, dp=None, lr=1e-4, **adam):
+        """Backward of the last training forward + AdamW (+ the gradient all-reduces of `dp`)."""
+        if not self.overlapped_step_ok(dp):
+            if dp is None:
+                self.backward()
+                self.optimizer_step(lr=lr, **adam)
+            else:
+                self.backward(on_ready=dp.reduce)
+                dp.finish()
+                self.optimizer_step(lr=lr, grad_scale=1.0 / dp.world, **adam)
+            return
+        if dp is None:
+            self._step_begin(lr, 1.0, adam)
+            self.backward(on_ready=self._step_range)
+            self._step_finish()
+            return
+        self._step_begin(lr, 1.0 / dp.world, adam)
+
+        def hook(key):
+            dp.reduce(key)                                  # all-reduce on the communication stream ...
+            self._step_range(key, on=dp.comm_stream)        # ... and the group's AdamW right behind it
+
+        self.backward(on_ready=hook)
+        for key in dp.group_order:
+            hook(key)
+        self._step_finish(on=dp.comm_stream)
+        dp.finish()                                         # the compute stream waits for the communication stream
+
     def train_step(self, inp, gt, lr=1e-4, dp=None, **adam):
         """zero-grad (implicit: every gradient is overwritten) + forward + L1 + backward + AdamW
         (phase2_train_net.py:60-110).  `dp` (mmfn_amd.parallel.DataParallel) reduces the gradient
@@ -1519,11 +1632,5 @@ class Engine(object):
         weight_decay.  Returns the device loss scalar."""
         ops.rng_advance(self.rng_state)
         _, loss = self.forward(inp, True, gt)
-        if dp is None:
-            self.backward()
-            self.optimizer_step(lr=lr, **adam)
-        else:
-            self.backward(on_ready=dp.reduce)
-            dp.finish()
-            self.optimizer_step(lr=lr, grad_scale=1.0 / dp.world, **adam)
+        self.backward_and_step(dp, lr=lr, **adam)
         return loss

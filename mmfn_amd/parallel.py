@@ -174,6 +174,9 @@ class GraphedStep(object):
         rec = self.recorder = Recorder(eng, split_lanes=lane_graphs)   # None: MMFN_LANE_GRAPHS decides (default: forks inside the graphs)
         if dp is not None:
             rec.extra_streams.append(dp.comm_stream)
+        if eng.opt_stream is None:
+            eng.opt_stream = torch.cuda.Stream(device=eng.device)
+        rec.extra_streams.append(eng.opt_stream)
         if single_graph is None:
             single_graph = dp is not None and dp.comm is not None and not rec.split_lanes
         if single_graph and (dp is None or dp.comm is None):
@@ -184,13 +187,11 @@ class GraphedStep(object):
             from . import ops
             ops.rng_advance(eng.rng_state)
             eng.forward(inp, True, gt)
-            if dp is None:
-                eng.backward()
-            elif single_graph:
-                # collectives captured on the communication stream: forked from the stream that wrote each bucket, joined by
-                # finish() before the optimizer - no cut, one replay call per step
-                eng.backward(on_ready=dp.reduce)
-                dp.finish()
+            if dp is None or single_graph:
+                # single GPU, or collectives captured on the communication stream (forked from the stream that wrote each
+                # bucket, joined by finish()): no cut, one replay call per step; AdamW per readiness group under the backward
+                eng.backward_and_step(dp, lr=lr, **adam)
+                return
             else:
                 tags = []
                 eng.backward_begin(on_ready=tags.append)

@@ -367,6 +367,14 @@ def test_failed_capture_leaves_the_stream_usable(monkeypatch):
     with pytest.raises(RuntimeError, match="injected"):
         GraphedStep(net._engine_for(), None, inp, gt, warm=0)
     monkeypatch.setattr(E.Engine, "optimizer_step", real_opt)
+    # the per-group optimizer option: the failure strikes with the optimizer stream forked into the capture and not yet joined
+    real_fin = E.Engine._step_finish
+    monkeypatch.setattr(E, "OVERLAP_ADAMW", True)
+    monkeypatch.setattr(E.Engine, "_step_finish", boom_opt)
+    with pytest.raises(RuntimeError, match="injected"):
+        GraphedStep(net._engine_for(), None, inp, gt, warm=0)
+    monkeypatch.setattr(E.Engine, "_step_finish", real_fin)
+    monkeypatch.setattr(E, "OVERLAP_ADAMW", False)
     torch.cuda.synchronize()
     step = GraphedStep(net._engine_for(), None, inp, gt, warm=0)   # and a later capture works
     step()
@@ -484,3 +492,39 @@ def test_folded_batchnorm_session_matches_unfolded_and_follows_weight_changes():
     folded.refresh()
     a2, _ = both()
     assert (a2 - b1).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("variant", ["vec", "img"])
+def test_adamw_under_the_backward_equals_adamw_after_it(variant, monkeypatch):
+    """Engine.backward_and_step issues AdamW per readiness group while the backward still runs (its own stream, forked from
+    the stream that wrote the group): same kernel, same operands - parameters and moments must be bit-identical to the
+    one-launch optimizer step after the backward, eagerly and as a replayed hipGraph, dropout on."""
+    from mmfn_amd import engine as E
+    from mmfn_amd.parallel import GraphedStep
+    _, net_a, batch, args = _setup(variant, dropout=0.1)
+    _, net_b, _, _ = _setup(variant, dropout=0.1)
+    _, net_c, _, _ = _setup(variant, dropout=0.1)
+    dargs = _dev_args(args)
+    gt = batch["gt_wp"].to(DEV)
+    for n in (net_a, net_b, net_c):
+        n.train()
+    inp_a, inp_b, inp_c = net_a._pack(*dargs), net_b._pack(*dargs), net_c._pack(*dargs)
+    monkeypatch.setattr(E, "OVERLAP_ADAMW", False)
+    for _ in range(3):
+        loss_a = net_a.train_step(inp_a, gt)
+    monkeypatch.setattr(E, "OVERLAP_ADAMW", True)
+    assert net_b._engine_for().overlapped_step_ok()
+    for _ in range(3):
+        loss_b = net_b.train_step(inp_b, gt)
+    step = GraphedStep(net_c._engine_for(), None, inp_c, gt, warm=1)
+    for _ in range(2):
+        loss_c = step()
+    torch.cuda.synchronize()
+    assert loss_a.item() == loss_b.item() == loss_c.item()
+    La, Lb, Lc = net_a._layout, net_b._layout, net_c._layout
+    for name in ("params", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(getattr(La, name), getattr(Lb, name)), name
+        assert torch.equal(getattr(La, name), getattr(Lc, name)), name
+    eng = net_b._engine_for()
+    spans = sorted(eng._opt_ranges.values())
+    assert spans[0][0] == 0 and spans[-1][1] == Lb.tail and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
