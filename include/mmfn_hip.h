@@ -65,6 +65,14 @@ int mmfn_wino_outgrad_bn_f32(const float* g, const float* y, const float* x, con
  * 36-batch GEMM over the forward's own transformed filter) -> dx = overlap-add of B dV B^T over the tiles' 6x6 input patches
  * (+ res).  H, W multiples of 4; replaces cuDNN's backward-data for the BasicBlock 3x3 convolutions (model_vec.py:539-593). */
 int mmfn_wino_input_adjoint_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, void* stream);
+/* The same launch also emitting the two reductions of the BatchNorm backward that dx enters (dx is dL/d(output) of the BatchNorm
+ * + ReLU that produced this convolution's input): partials[rows][2][C] doubles = per-block (sum ge, sum ge * xhat) with
+ * ge = dx * (ey > 0) (ey NULL: no ReLU), xhat = (ex - emean) * erstd, ex = that BatchNorm's input (the producer's convolution
+ * output); rows = mmfn_wino_input_adjoint_emit_rows().  mmfn_bn_bwd_reduce_partials_f32 finishes them: the producer's
+ * native_batch_norm_backward then needs no reduction pass of its own over g, y and x. */
+int mmfn_wino_input_adjoint_emit_rows(int B, int H, int W, int C);
+int mmfn_wino_input_adjoint_emit_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, const float* ey,
+                                     const float* ex, const float* emean, const float* erstd, double* partials, void* stream);
 int mmfn_wino_wgrad_out_f32(const float* dU, float* dw, int Co, int Ci, void* stream);
 /* The 7x7 stride-2 stems (torchvision conv1, model_vec.py:509,515: 3 camera / 2 BEV channels) as explicit im2col + plain GEMM:
  * col[B*OH*OW][KP] (fp32, or bf16 with out_bf16) = the zero-padded patch matrix of x [B,H,W,Cin] (fp32, Cin <= 4), k = (kh, kw, ci),
@@ -238,6 +246,9 @@ int mmfn_bn_bwd_f32(const float* g, const float* y, const float* x, int64_t M, i
 /* The reductions of mmfn_bn_bwd_f32 without its apply pass: dweight, dbias, means[2][C] = (mean(ge), mean(ge * xhat)) */
 int mmfn_bn_bwd_reduce_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean,
                            const float* rstd, float* dweight, float* dbias, float* means, void* workspace, void* stream);
+/* ... from per-block partial sums [rows][2][C] (doubles) that another launch produced (mmfn_wino_input_adjoint_emit_f32) */
+int mmfn_bn_bwd_reduce_partials_f32(const double* partials, int rows, int64_t M, int C, float* dweight, float* dbias, float* means,
+                                    void* stream);
 /* LayerNorm over rows of x[M,C] (C % 64 == 0, C <= 512), optional fused activation on the output
  * (act: 0 none, 1 ReLU, 2 exact GELU).  Replaces aten native_layer_norm (+relu/gelu) of
  * model_vec.py:117-118,162 (GPT) and :252,335-336,345-346,352-353 (VectorNet). */

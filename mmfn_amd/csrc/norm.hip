@@ -579,6 +579,15 @@ extern "C" int mmfn_bn_bwd_reduce_f32(const float* g, const float* y, const floa
                        workspace, 1, 0, stream);
 }
 
+extern "C" int mmfn_bn_bwd_reduce_partials_f32(const double* partials, int rows, int64_t M, int C, float* dweight, float* dbias,
+                                               float* means, void* stream) {
+  if (!partials || rows <= 0 || C <= 0 || M <= 0 || !dweight || !dbias || !means) return MMFN_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, (hipStream_t)stream, partials, rows, M,
+                     C, dweight, dbias, means);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
 namespace {
 template <typename TA>
 int layernorm_fwd_launch(const TA* x, const float* weight, const float* bias, TA* y, float* mean, float* rstd, int M, int C, float eps,

@@ -397,14 +397,10 @@ __device__ __forceinline__ void f4_b(const T* v, T* o) {  // o = B v, 6 -> 6 (B 
 // what the eight neighbouring tiles' patches put on it.  Because rows 0 and 5 of B are 4*e0 and e5 (f4_b: o[0] = 4 v[0],
 // o[5] = v[5]), a neighbour's halo row / column needs only ONE row / column of its dV: 36 + 4*6 + 4 = 64 loads per thread
 // instead of 9*36, every addition in a fixed order.
-__global__ __launch_bounds__(NT) void wino4_input_adjoint_kernel(const float* __restrict__ dV, const float* __restrict__ res,
-                                                                 float* __restrict__ dx, int B, int H, int W, int C) {
-  const int cq = C >> 2, th = H >> 2, tw = W >> 2;
-  const int64_t T = (int64_t)B * th * tw, n = T * cq;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(idx % cq) * 4;
-    const int64_t tile = idx / cq;
-    const int tj = (int)(tile % tw), ti = (int)((tile / tw) % th), b = (int)(tile / ((int64_t)tw * th));
+// The 4x4 block of dx a thread owns: P[a][e], rows 4*ti + a, columns 4*tj + e, four channels from c4 (res not yet added).
+__device__ __forceinline__ void wino4_adjoint_block(const float* __restrict__ dV, int64_t T, int C, int th, int tw, int64_t tile, int c4,
+                                                    f32x4 (*P)[4]) {
+    const int tj = (int)(tile % tw), ti = (int)((tile / tw) % th);
     auto at = [&](int64_t tl, int a, int e) { return *reinterpret_cast<const f32x4*>(dV + ((size_t)(a * 6 + e) * T + tl) * C + c4); };
     f32x4 t[4][6];  // rows 1..4 of B dV, built column by column
 #pragma unroll
@@ -416,7 +412,7 @@ __global__ __launch_bounds__(NT) void wino4_input_adjoint_kernel(const float* __
 #pragma unroll
       for (int a = 0; a < 4; ++a) t[a][e] = o[a + 1];
     }
-    f32x4 P[4][4];  // interior of B dV B^T
+    // interior of B dV B^T
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       f32x4 o[6];
@@ -461,6 +457,18 @@ __global__ __launch_bounds__(NT) void wino4_input_adjoint_kernel(const float* __
     if (up && right) P[0][3] += 4.f * at(tile - tw + 1, 5, 0);
     if (down && left) P[3][0] += 4.f * at(tile + tw - 1, 0, 5);
     if (down && right) P[3][3] += 16.f * at(tile + tw + 1, 0, 0);
+}
+
+__global__ __launch_bounds__(NT) void wino4_input_adjoint_kernel(const float* __restrict__ dV, const float* __restrict__ res,
+                                                                 float* __restrict__ dx, int B, int H, int W, int C) {
+  const int cq = C >> 2, th = H >> 2, tw = W >> 2;
+  const int64_t T = (int64_t)B * th * tw, n = T * cq;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % cq) * 4;
+    const int64_t tile = idx / cq;
+    const int tj = (int)(tile % tw), ti = (int)((tile / tw) % th), b = (int)(tile / ((int64_t)tw * th));
+    f32x4 P[4][4];
+    wino4_adjoint_block(dV, T, C, th, tw, tile, c4, P);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const size_t off = (((size_t)b * H + 4 * ti + a) * W + 4 * tj) * C + c4;
@@ -471,6 +479,66 @@ __global__ __launch_bounds__(NT) void wino4_input_adjoint_kernel(const float* __
         *reinterpret_cast<f32x4*>(dx + off + (size_t)e * C) = v;
       }
     }
+  }
+}
+
+// The same, and - since dx is the gradient entering the PRODUCER's BatchNorm (dx = dL/d(BN output), the producer being the
+// convolution whose output this layer read) - the two reductions of that BatchNorm's backward as a by-product:
+//   partials[block][0][c] = sum ge,  partials[block][1][c] = sum ge * xhat,   ge = dx * (ey > 0) (ey != NULL), xhat = (ex - mean) * rstd
+// so the producer's backward skips its own reduction pass over g, y and x (col_partial_kernel<1>: three tensor reads and a launch).
+// Block layout as wino4_output_stats_kernel: thread = (tile lane, channel quad), one partial row per block.
+__global__ __launch_bounds__(NT) void wino4_input_adjoint_emit_kernel(const float* __restrict__ dV, const float* __restrict__ res,
+                                                                      float* __restrict__ dx, int B, int H, int W, int C,
+                                                                      const float* __restrict__ ey, const float* __restrict__ ex,
+                                                                      const float* __restrict__ emean, const float* __restrict__ erstd,
+                                                                      double* __restrict__ partials, int tiles_per_block) {
+  const int cq = C >> 2, th = H >> 2, tw = W >> 2;
+  const int64_t T = (int64_t)B * th * tw;
+  const int TL = NT / cq;
+  const int cqi = threadIdx.x % cq, tl = threadIdx.x / cq;
+  const int c4 = cqi * 4;
+  const int64_t t0 = (int64_t)blockIdx.x * tiles_per_block;
+  const int64_t t1 = (t0 + tiles_per_block < T) ? t0 + tiles_per_block : T;
+  const f32x4 mu = *reinterpret_cast<const f32x4*>(emean + c4), rs = *reinterpret_cast<const f32x4*>(erstd + c4);
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  for (int64_t tile = t0 + tl; tile < t1; tile += TL) {
+    const int tj = (int)(tile % tw), ti = (int)((tile / tw) % th), b = (int)(tile / ((int64_t)tw * th));
+    f32x4 P[4][4];
+    wino4_adjoint_block(dV, T, C, th, tw, tile, c4, P);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const size_t off = (((size_t)b * H + 4 * ti + a) * W + 4 * tj) * C + c4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f32x4 v = P[a][e];
+        if (res) v += *reinterpret_cast<const f32x4*>(res + off + (size_t)e * C);
+        *reinterpret_cast<f32x4*>(dx + off + (size_t)e * C) = v;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(ex + off + (size_t)e * C);
+        if (ey) {
+          const f32x4 yv = *reinterpret_cast<const f32x4*>(ey + off + (size_t)e * C);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = yv[q] > 0.0f ? v[q] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // the arithmetic of col_partial_kernel<1>, element for element
+          const float xh = (xv[q] - mu[q]) * rs[q];
+          s1[q] += (double)v[q];
+          s2[q] += (double)v[q] * (double)xh;
+        }
+      }
+    }
+  }
+  __shared__ double red[2][NT][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { red[0][threadIdx.x][q] = s1[q]; red[1][threadIdx.x][q] = s2[q]; }
+  __syncthreads();
+  if (tl == 0) {
+    for (int k = 1; k < TL; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { s1[q] += red[0][k * cq + cqi][q]; s2[q] += red[1][k * cq + cqi][q]; }
+    double* p = partials + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { p[c4 + q] = s1[q]; p[C + c4 + q] = s2[q]; }
   }
 }
 
@@ -628,6 +696,27 @@ extern "C" int mmfn_wino_input_adjoint_f32(const float* dV, const float* res, fl
   if (!dV || !dx || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
   hipLaunchKernelGGL(wino4_input_adjoint_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0,
                      (hipStream_t)stream, dV, res, dx, B, H, W, C);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_wino_input_adjoint_emit_rows(int B, int H, int W, int C) {
+  const int cq = C / 4;
+  if (B <= 0 || (H & 3) || (W & 3) || (C & 3) || cq > NT || NT % cq) return 0;
+  const int64_t T = (int64_t)B * (H / 4) * (W / 4);
+  const int TL = NT / cq;
+  const int tpb = (int)std::max<int64_t>(TL, (T + 511) / 512);
+  return (int)((T + tpb - 1) / tpb);
+}
+
+extern "C" int mmfn_wino_input_adjoint_emit_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, const float* ey,
+                                                const float* ex, const float* emean, const float* erstd, double* partials, void* stream) {
+  const int rows = mmfn_wino_input_adjoint_emit_rows(B, H, W, C);
+  if (!dV || !dx || !ex || !emean || !erstd || !partials || rows <= 0) return MMFN_EINVAL;
+  const int64_t T = (int64_t)B * (H / 4) * (W / 4);
+  const int tpb = (int)((T + rows - 1) / rows);
+  hipLaunchKernelGGL(wino4_input_adjoint_emit_kernel, dim3(rows), dim3(NT), 0, (hipStream_t)stream, dV, res, dx, B, H, W, C, ey, ex, emean,
+                     erstd, partials, std::max(tpb, NT / (C / 4)));
   MMFN_LAUNCH_CHECK();
   return 0;
 }

@@ -129,6 +129,10 @@ class Ctx(object):
 # ----------------------------------------------------------------------------- conv + BN
 FUSE_BN_BWD_APPLY = os.environ.get("MMFN_FUSE_BN_BWD", "1") == "1"   # A/B switch, see ConvBN.bwd
 FUSE_BN_BWD_REDUCE = os.environ.get("MMFN_FUSE_BN_REDUCE", "1") == "1"   # A/B switch, see ConvBN.bwd16 (bf16 mode)
+# fp32: the same reductions out of the Winograd adjoint transform (mmfn_wino_input_adjoint_emit_f32).  55 col_partial launches
+# less per step, but the adjoint launch with the reduction (256 VGPRs, <= 512 blocks walking their tiles serially) gives the time
+# back: 941 / 951 / 948 against 955 / 947 / 956 samples/s interleaved.  Off; a tested option.
+FUSE_BN_BWD_REDUCE32 = os.environ.get("MMFN_FUSE_BN_REDUCE32", "0") == "1"
 
 
 class ConvBN(object):
@@ -334,10 +338,25 @@ class ConvBN(object):
             # weight and data gradient together in the Winograd domain (shared A dy A^T), and dy = the BatchNorm backward of g
             # is formed inside that transform: only the two reductions run as kernels of their own, dy never goes to HBM
             means = ctx.bufs.get(self.name + ".bnmeans", (2, self.cout))
-            ops.bn_bwd_reduce(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.g_bn_w, self.g_bn_b, means)
+            pre, self._pre32 = getattr(self, "_pre32", None), None
+            if pre is not None and mask_y is None:
+                # the consumer's adjoint transform already summed (ge, ge * xhat) per block while it was storing g
+                ops.bn_bwd_reduce_partials(pre[0], pre[1], M, self.cout, self.g_bn_w, self.g_bn_b, means)
+            else:
+                ops.bn_bwd_reduce(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.g_bn_w, self.g_bn_b, means)
             dx = ctx.bufs.get(self.name + ".dx", x.shape)
+            em = None
+            if emit is not None and FUSE_BN_BWD_REDUCE32 and getattr(emit, "saved_u", None) is not None and emit.saved[1].dtype == torch.float32 \
+                    and tuple(emit.saved[1].shape) == tuple(x.shape):
+                # dx IS the gradient entering `emit`'s BatchNorm (emit produced x): its two reductions come out of this launch
+                _, eco, ey, emean, erstd, erelu = emit.saved
+                rows = ops.wino_adjoint_emit_rows(x.shape)
+                if rows > 0:
+                    part = ctx.bufs.get(emit.name + ".bnpart32", (rows, 2, x.shape[-1]), torch.float64)
+                    em = (ey if erelu else None, eco, emean, erstd, part)
+                    emit._pre32 = (part, rows)
             ops.conv2d_bwd_winograd(dco, x, u, self.gw, dx, v=getattr(self, "saved_v", None), res=dx_res,
-                                    bn=(g, None if ymask is None else ymask.view(g.shape), co, mean, rstd, self.bn_w, means, ge_out))
+                                    bn=(g, None if ymask is None else ymask.view(g.shape), co, mean, rstd, self.bn_w, means, ge_out), emit=em)
             return dx
         ops.bn_bwd(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.bn_w, dco.view(M, self.cout),
                    self.g_bn_w, self.g_bn_b, ge_out=None if ge_out is None else ge_out.view(M, self.cout))

@@ -610,14 +610,22 @@ def winograd_adjoint_ok(x_shape, w_shape, stride, pad):
     return WINOGRAD_ADJOINT_DGRAD and winograd_wgrad_ok(x_shape, w_shape, stride, pad)
 
 
-def conv2d_bwd_winograd(dy, x, u, dw_out, dx_out, v=None, res=None, bn=None):
+def wino_adjoint_emit_rows(x_shape):
+    B, H, W, C = x_shape
+    return lib().mmfn_wino_input_adjoint_emit_rows(B, H, W, C)
+
+
+def conv2d_bwd_winograd(dy, x, u, dw_out, dx_out, v=None, res=None, bn=None, emit=None):
     """Weight AND data gradient of a 3x3 stride-1 'same' convolution in the F(4x4,3x3) domain, sharing the transformed
     output gradient dM = A dy A^T:
         dw = G^T [ sum_tiles dM^T . V ] G          (V = B^T x B, kept by the forward or recomputed)
         dx = overlap-add( B (dM . U) B^T ) (+ res)  (U = G w G^T, kept by the forward: the ADJOINT of the forward pipeline,
                                                      no flipped filter, no second filter / input transform)
     bn = (g, ymask or None, conv_out, mean, rstd, weight, means, ge_out or None), all NHWC / [C]: dy is then the BatchNorm backward
-    of g (reductions already done by bn_bwd_reduce) formed on the fly inside the transform; the `dy` argument only gives the shape."""
+    of g (reductions already done by bn_bwd_reduce) formed on the fly inside the transform; the `dy` argument only gives the shape.
+    emit = (ey or None, ex, emean, erstd, partials [rows, 2, Ci] float64): dx enters the BatchNorm (+ ReLU, mask ey) that produced x
+    from ex; the adjoint transform then also writes that BatchNorm backward's two reductions as per-block partial sums
+    (wino_adjoint_emit_rows(x.shape) rows; finished by bn_bwd_reduce_partials)."""
     B, H, W, Ci = x.shape
     Co = dy.shape[3]
     T = B * (H // 4) * (W // 4)
@@ -634,7 +642,13 @@ def conv2d_bwd_winograd(dy, x, u, dw_out, dx_out, v=None, res=None, bn=None):
         dV = Vs  # the scratch V region is free again: with a kept V it was never used, otherwise the wgrad GEMM is done with it
         gemm(dMt, u.view(-1)[:36 * Co * Ci], dV, T, Ci, Co, Co, Ci, Ci, A_ROWMAJOR, B_KN, batch=36, strideA=T * Co, strideB=Co * Ci,
              strideC=T * Ci)
-        _call("mmfn_wino_input_adjoint_f32", ptr(dV), ptr(res), ptr(dx_out), B, H, W, Ci, st)
+        if emit is None:
+            _call("mmfn_wino_input_adjoint_f32", ptr(dV), ptr(res), ptr(dx_out), B, H, W, Ci, st)
+        else:
+            ey, ex, emean, erstd, part = emit
+            assert part.dtype == torch.float64 and part.numel() >= wino_adjoint_emit_rows(x.shape) * 2 * Ci and ex.shape == x.shape
+            _call("mmfn_wino_input_adjoint_emit_f32", ptr(dV), ptr(res), ptr(dx_out), B, H, W, Ci, ptr(ey), ptr(ex), ptr(emean), ptr(erstd),
+                  ptr(part), st)
     return dw_out, dx_out
 
 
@@ -745,6 +759,12 @@ def bn_bwd_reduce(g2d, y2d, x2d, mean, rstd, dweight, dbias, means):
     M, C = x2d.shape
     _call("mmfn_bn_bwd_reduce_f32", ptr(g2d), ptr(y2d), ptr(x2d), M, C, ptr(mean), ptr(rstd), ptr(dweight), ptr(dbias), ptr(means),
           ptr(norm_workspace(x2d.device)), stream())
+    return means
+
+
+def bn_bwd_reduce_partials(partials, rows, M, C, dweight, dbias, means):
+    """bn_bwd_reduce from per-block partial sums another launch left behind (conv2d_bwd_winograd(emit=...))."""
+    _call("mmfn_bn_bwd_reduce_partials_f32", ptr(partials), rows, M, C, ptr(dweight), ptr(dbias), ptr(means), stream())
     return means
 
 

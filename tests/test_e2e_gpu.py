@@ -528,3 +528,28 @@ def test_adamw_under_the_backward_equals_adamw_after_it(variant, monkeypatch):
     eng = net_b._engine_for()
     spans = sorted(eng._opt_ranges.values())
     assert spans[0][0] == 0 and spans[-1][1] == Lb.tail and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_fp32_batchnorm_reductions_from_the_winograd_adjoint(monkeypatch):
+    """MMFN_FUSE_BN_REDUCE32 (option): the BatchNorm-backward reductions of 55 layers come out of the consumer's Winograd adjoint
+    launch instead of a pass of their own: same gradients up to the summation order of the fp64 partial sums."""
+    from mmfn_amd import engine as E
+    _, net_a, batch, args = _setup("vec")
+    _, net_b, _, _ = _setup("vec")
+    dargs = _dev_args(args)
+    gt = batch["gt_wp"].to(DEV)
+    net_a.train(), net_b.train()
+    inp_a, inp_b = net_a._pack(*dargs), net_b._pack(*dargs)
+    ea, eb = net_a._engine_for(), net_b._engine_for()
+    ea.forward(inp_a, True, gt)
+    ea.backward()
+    monkeypatch.setattr(E, "FUSE_BN_BWD_REDUCE32", True)
+    eb.forward(inp_b, True, gt)
+    eb.backward()
+    torch.cuda.synchronize()
+    used = [k[0] for k in eb._bufs_for(2)._bufs if k[0].endswith(".bnpart32")]
+    assert len(used) >= 30, used   # the layers whose consumer is a stride-1 Winograd convolution
+    ga, gb = net_a._layout.grads[:net_a._layout.tail], net_b._layout.grads[:net_b._layout.tail]
+    err = (ga.double() - gb.double()).norm().item() / ga.double().norm().item()
+    # batch 2 through 85 train-mode BatchNorms amplifies a last-bit change of a reduction (test_train_step_matches_oracle)
+    assert err <= 1e-3, err

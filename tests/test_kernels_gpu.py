@@ -236,6 +236,42 @@ def test_tokens_and_upsample_with_several_frames(S, C, frames):
         _close(o.permute(0, 3, 1, 2), f.grad, 1e-6)
 
 
+@pytest.mark.parametrize("B,H,W,C,relu,with_res", [(2, 16, 16, 64, True, True), (3, 8, 8, 256, True, False), (1, 32, 32, 128, False, True),
+                                                    (2, 8, 8, 512, True, True)])
+def test_winograd_adjoint_emits_the_batchnorm_backward_reductions(B, H, W, C, relu, with_res):
+    """mmfn_wino_input_adjoint_emit_f32: the data gradient of the plain launch, bit for bit, plus per-block (sum ge, sum ge * xhat)
+    whose finished form equals mmfn_bn_bwd_reduce_f32 run on the stored gradient."""
+    from mmfn_amd import ops
+    from mmfn_amd.ops import _call, ptr, stream
+    g = _g(B * H + C)
+    T = B * (H // 4) * (W // 4)
+    M = B * H * W
+    dV = torch.randn(36, T, C, generator=g).to(DEV)
+    res = torch.randn(B, H, W, C, generator=g).to(DEV) if with_res else None
+    ey = torch.randn(B, H, W, C, generator=g).to(DEV)
+    ex = (torch.randn(B, H, W, C, generator=g) * 2 + 0.5).to(DEV)
+    mean, rstd = (torch.randn(C, generator=g) * 0.3).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    dx1, dx2 = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
+    _call("mmfn_wino_input_adjoint_f32", ptr(dV), ptr(res), ptr(dx1), B, H, W, C, stream())
+    rows = ops.wino_adjoint_emit_rows((B, H, W, C))
+    assert 0 < rows <= 512
+    part = torch.full((rows, 2, C), float("nan"), dtype=torch.float64, device=DEV)
+    _call("mmfn_wino_input_adjoint_emit_f32", ptr(dV), ptr(res), ptr(dx2), B, H, W, C, ptr(ey if relu else None), ptr(ex), ptr(mean),
+          ptr(rstd), ptr(part), stream())
+    assert torch.equal(dx1, dx2)
+    dw1, db1, m1 = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2, C, device=DEV)
+    dw2, db2, m2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2, C, device=DEV)
+    ops.bn_bwd_reduce(dx1.view(M, C), ey.view(M, C) if relu else None, ex.view(M, C), mean, rstd, dw1, db1, m1)
+    ops.bn_bwd_reduce_partials(part, rows, M, C, dw2, db2, m2)
+    ge = dx1.double() * ((ey > 0).double() if relu else 1.0)
+    xh = (ex.double() - mean.double()) * rstd.double()
+    ref_b, ref_w = ge.sum(dim=(0, 1, 2)), (ge * xh).sum(dim=(0, 1, 2))
+    for got, ref in ((db2, ref_b), (dw2, ref_w), (m2[0], ref_b / M), (m2[1], ref_w / M)):
+        assert torch.allclose(got.double(), ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+    for a_, b_ in ((dw1, dw2), (db1, db2), (m1, m2)):
+        assert torch.allclose(a_, b_, rtol=1e-5, atol=1e-6 * float(a_.abs().max()))
+
+
 def test_gap_and_transpose():
     from mmfn_amd import ops
     g = _g(9)
