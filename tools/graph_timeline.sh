@@ -2,6 +2,7 @@
 # Kernel trace of the hipGraph-replayed step -> timeline analysis of ONE steady-state step: how much of the wall time has a
 # GEMM-family kernel resident, how much only "glue" kernels (and which), how much nothing.  Output: gpurun_out/timeline/summary.txt
 R=$GRAFT_REPO_ROOT
+export EXTRA
 OUT=$R/gpurun_out/timeline
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -51,7 +52,7 @@ for t, d, f in pts:
     active[f] += d
     last = t
 wall = (w1 - w0)
-print("# one replayed training step (B=32 vec fp32; one hipGraph, 3 branch lanes + side stream forked inside): %d kernels, wall %.2f ms" % (len(win), wall / 1e6))
+print("# one replayed training step (B=32 vec %s; one hipGraph, 3 branch lanes + side stream forked inside): %d kernels, wall %.2f ms" % ("bf16 mode" if "bf16" in os.environ.get("EXTRA", "") else "fp32", len(win), wall / 1e6))
 print("a GEMM-family kernel is resident      %7.2f ms  (%4.1f %%)" % (gemm_any / 1e6, 100.0 * gemm_any / wall))
 print("nothing is resident (gaps)            %7.2f ms  (%4.1f %%)" % (idle / 1e6, 100.0 * idle / wall))
 print("only non-GEMM kernels are resident    %7.2f ms  (%4.1f %%), by family:" % (sum(alone.values()) / 1e6, 100.0 * sum(alone.values()) / wall))
