@@ -170,11 +170,76 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
     const int c = ls ^ nt_swz(r);
     pb[i] = Bp + (size_t)min(n0 + r, d.N - 1) * d.ldb + c * 8;
   }
+  // ---- lean gather (convolution forms whose source pixel is lane base + a per-tap constant: forward of any stride, data gradient
+  // of stride 1 or in parity tiles).  Measured on the first version (tools/experiments/conv16_pmc.sh): 61 VALU + 64 SALU
+  // instructions per wave and k-tile around 4 MFMAs, almost all of it address arithmetic redone per piece - tap decode with an
+  // integer division, two coordinates, four compares, a 64-bit multiply-add.  Here a lane keeps ONE pointer (its pixel at tap
+  // (0, 0)) and ONE bit mask (which taps fall inside the image) per piece; a k-tile adds a wave-uniform offset that changes only
+  // when the tap does, and tests one bit.
+  const int ntaps = d.KH * d.KW;
+  const bool lean = FORM != 0 && ntaps <= 32 && (FORM == 1 || d.stride == 1 || par);
+  const bf16_t* pl[PA];
+  unsigned vmask[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) { pl[i] = pa[i]; vmask[i] = 0; }
+  if (lean) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      // source pixel of tap (kh, kw): FORM 1: (ay + kh, ax + kw) of x;  FORM 2, stride 1: (ay - kh, ax - kw) of dY;
+      // FORM 2, parity tiles: lane pixel (2y + py, 2x + px) -> (y + (py + pad - kh) / 2, x + (px + pad - kw) / 2) of dY
+      int by = ay[i], bx = ax[i];
+      if (par) { by = (ay[i] - d.pad) >> 1; bx = (ax[i] - d.pad) >> 1; }
+      const int sh = FORM == 1 ? d.H : d.OH, sw = FORM == 1 ? d.W : d.OW, sc = FORM == 1 ? d.Cin : d.Cout;
+      pl[i] = pa[i] + ((ptrdiff_t)by * sw + bx) * sc;
+      unsigned mk = 0;
+      for (int t = 0; t < ntaps; ++t) {
+        const int kh = t / d.KW, kw = t - kh * d.KW;
+        int y, x;
+        if (FORM == 1) { y = by + kh; x = bx + kw; }
+        else if (!par) { y = by - kh; x = bx - kw; }
+        else {
+          const int dy = (pcls >> 1) + d.pad - kh, dx = (pcls & 1) + d.pad - kw;
+          if ((dy | dx) & 1) continue;              // not a tap of this parity class
+          y = by + dy / 2; x = bx + dx / 2;
+        }
+        if ((unsigned)y < (unsigned)sh && (unsigned)x < (unsigned)sw) mk |= 1u << t;
+      }
+      vmask[i] = mk;
+    }
+  }
+  // wave-uniform state of the NEXT k-tile to stage (stage() is called for k-tiles 0, 1, 2, ... in order)
+  int s_seq = 0, s_chunk = 0, s_tap = 0, s_toff = 0, s_ktb0 = 0;
+  auto set_tap = [&](int seq) {   // seq: index in the sequence of taps this block visits
+    s_tap = par ? (int)((live_taps >> (4 * seq)) & 15) : seq;
+    const int kh = s_tap / d.KW, kw = s_tap - kh * d.KW;
+    if (FORM == 1) s_toff = (kh * d.W + kw) * d.Cin;
+    else if (!par) s_toff = -(kh * d.OW + kw) * d.Cout;
+    else s_toff = ((((pcls >> 1) + d.pad - kh) / 2) * d.OW + ((pcls & 1) + d.pad - kw) / 2) * d.Cout;
+    s_ktb0 = s_tap << tap_shift;
+  };
+  if (lean) set_tap(0);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);   // (uniform by construction: the LDS-DMA destinations become scalars)
 
-  auto stage = [&](int kt, int buf) {
+  auto stage_lean = [&](int buf) {
     unsigned char* As = smem + buf * STAGE;
     unsigned char* Bs = As + BM * 128;
-    const bool live = kt < nkt;   // past the end: the same number of (dummy) loads, so the counted waits stay constant
+    const ptrdiff_t aoff = (ptrdiff_t)(s_toff + s_chunk * BK);
+    const int boff = (s_ktb0 + s_chunk) * BK;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      const bf16_t* src = ((vmask[i] >> s_tap) & 1u) ? pl[i] + aoff : zero;
+      glds16(src, As + (wave_u + 4 * i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) glds16(pb[i] + boff, Bs + (wave_u + 4 * i) * 1024);
+    if (++s_chunk == (1 << tap_shift)) { s_chunk = 0; set_tap(++s_seq); }
+  };
+
+  auto stage = [&](int kt, int buf) {
+    if (lean) { stage_lean(buf); return; }
+    unsigned char* As = smem + buf * STAGE;
+    unsigned char* Bs = As + BM * 128;
+    constexpr bool live = true;   // (stage() is only called for existing k-tiles: the tail's counted waits shrink instead)
     int kh = 0, kw = 0, c0 = 0, ktb = kt;   // ktb: this k-tile's position in the filter operand
     if (FORM != 0) {   // wave-uniform tap of this k-tile (channels % 64 == 0: a k-tile never straddles a tap)
       int tap = kt >> tap_shift;
@@ -210,10 +275,10 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
         ok = ok && oh < d.OH && ow < d.OW;
         src = ok ? pa[i] + ((size_t)oh * d.OW + ow) * d.Cout + c0 : zero;
       }
-      glds16(src, As + (wave + 4 * i) * 1024);
+      glds16(src, As + (wave_u + 4 * i) * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < PB; ++i) glds16(live ? pb[i] + (size_t)ktb * BK : zero, Bs + (wave + 4 * i) * 1024);
+    for (int i = 0; i < PB; ++i) glds16(live ? pb[i] + (size_t)ktb * BK : zero, Bs + (wave_u + 4 * i) * 1024);
   };
 
   f32x16 acc[TM][TN];
