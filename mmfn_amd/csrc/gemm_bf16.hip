@@ -292,50 +292,55 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
 #pragma unroll
   for (int s = 0; s < D; ++s)
     if (s < nkt) stage(s, s);
-  int cur = 0, nxt = D;
   if (NS == 2) {
     MMFN_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
   }
-  for (int kt = 0; kt < nkt; ++kt) {
-    // tiles kt+1 .. kt+D stay in flight; near the end fewer exist and the (immediate) wait count shrinks with them
-    const int ahead = nkt - 1 - kt;
-    if (ahead >= D) stage(kt + D, nxt);
-    if (NS > 2) {
-      if (ahead >= D) MMFN_WAIT_VMCNT((PA + PB) * D);     // this wave's pieces of tile kt have landed ...
-      else if (D > 1 && ahead == 1) MMFN_WAIT_VMCNT(PA + PB);
-      else MMFN_WAIT_VMCNT(0);
-      __builtin_amdgcn_s_barrier();                       // ... and everybody else's
-    }
-    const unsigned char* As = smem + cur * STAGE;
-    const unsigned char* Bs = As + BM * 128;
-    cur = cur + 1 == NS ? 0 : cur + 1;
-    nxt = nxt + 1 == NS ? 0 : nxt + 1;
-    // all fragment reads of the k-tile first (the compiler then retires them with counted lgkmcnt waits under the MFMAs)
-    bf16x8 a[BK / 16][TM], b[BK / 16][TN];
+  // The k-loop is unrolled over the NS stages, so the stage a k-tile is read from / staged into is a compile-time constant: the
+  // fragment reads take their stage as the instruction's immediate offset and the LDS-DMA destinations are literals (no per-tile
+  // buffer bookkeeping or address adds; -10 instructions per wave and k-tile).
+  for (int kt0 = 0; kt0 < nkt; kt0 += NS) {
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int c = ks * 2 + h;
+    for (int u = 0; u < NS; ++u) {
+      const int kt = kt0 + u;
+      if (kt >= nkt) break;
+      // tiles kt+1 .. kt+D stay in flight; near the end fewer exist and the (immediate) wait count shrinks with them
+      const int ahead = nkt - 1 - kt;
+      if (ahead >= D) stage(kt + D, (u + D) % NS);
+      if (NS > 2) {
+        if (ahead >= D) MMFN_WAIT_VMCNT((PA + PB) * D);     // this wave's pieces of tile kt have landed ...
+        else if (D > 1 && ahead == 1) MMFN_WAIT_VMCNT(PA + PB);
+        else MMFN_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();                       // ... and everybody else's
+      }
+      const unsigned char* As = smem + u * STAGE;
+      const unsigned char* Bs = As + BM * 128;
+      // all fragment reads of the k-tile first (the compiler then retires them with counted lgkmcnt waits under the MFMAs)
+      bf16x8 a[BK / 16][TM], b[BK / 16][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int r = wm * TM * 32 + i * 32 + l31;
-        a[ks][i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + ((c ^ nt_swz(r)) << 4));
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        const int c = ks * 2 + h;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int r = wm * TM * 32 + i * 32 + l31;
+          a[ks][i] = *reinterpret_cast<const bf16x8*>(As + r * 128 + ((c ^ nt_swz(r)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int r = wn * TN * 32 + j * 32 + l31;
+          b[ks][j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + ((c ^ nt_swz(r)) << 4));
+        }
       }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int r = wn * TN * 32 + j * 32 + l31;
-        b[ks][j] = *reinterpret_cast<const bf16x8*>(Bs + r * 128 + ((c ^ nt_swz(r)) << 4));
+      for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+      if (NS == 2) {   // tile kt+1 landed, and nobody still reads the stage the next iteration overwrites
+        MMFN_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
       }
-    }
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
-    if (NS == 2) {   // tile kt+1 landed, and nobody still reads the stage the next iteration overwrites
-      MMFN_WAIT_VMCNT(0);
-      __builtin_amdgcn_s_barrier();
     }
   }
   __syncthreads();      // nobody still reads operands: the stages become the epilogue's staging area
