@@ -704,6 +704,23 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
   const bool to_slab = d.splitk > 1;
   float* slab = to_slab ? d.workspace + ((size_t)blockIdx.y * max(1, d_in.batch) + (d_in.batch > 1 ? blockIdx.z : 0)) * d.M * d.N : nullptr;
+  // Plain stores of an interior tile (no epilogue operation, or a split slab): one pointer per lane and 16 * TM * TN stores at
+  // compile-time row multiples of the leading dimension.  The general loop below tests the tile edge and eight epilogue flags per
+  // ELEMENT; tools/experiments/gemm32_pmc.sh counts ~730 non-MFMA instructions per wave around a tile's k-loop, most of them there -
+  // more than the k-loop itself issues for the K = 64 ... 256 Winograd-domain GEMMs that are two thirds of the step's launches.
+  constexpr int EPI_OPS = MMFN_EPI_BIAS | MMFN_EPI_RELU | MMFN_EPI_GELU | MMFN_EPI_MASK_AUX | MMFN_EPI_DROPOUT | MMFN_EPI_RESIDUAL |
+                          MMFN_EPI_ACCUM | MMFN_EPI_RELU_LAST;
+  if (!dgp && m0 + BM <= d.M && n0 + BN <= d.N && (to_slab || !(d.flags & EPI_OPS))) {
+    const int ld = to_slab ? d.N : d.ldc;
+    float* p0 = (to_slab ? slab : d.C) + (size_t)(m0 + wm * TM * 32 + 4 * h) * ld + n0 + wn * TN * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < TN; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p0[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ld + q * 32] = acc[i][q][r];
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
