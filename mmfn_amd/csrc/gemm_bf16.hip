@@ -547,7 +547,60 @@ __global__ __launch_bounds__(NT) void gemm16_tn_kernel(const mmfn_gemm16_desc d,
     bkw = tap - bkh * d.KW;
   }
 
+  // ---- lean staging (as in the NT kernel): a lane keeps one pointer per piece - its contraction row of k-tile 0 - and a k-tile
+  // adds a wave-uniform offset.  The convolution form's row is an output pixel: with power-of-two OW and OH * OW >= 64 the 64
+  // pixels of a k-tile are 64 / OW whole rows (or a 64-pixel stretch of one row) of ONE image, so the pixel splits into a uniform
+  // part (image, first row / column of the group) and a lane part that never changes.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bool whole = (d.K & 63) == 0;                                  // no ragged last k-tile
+  const bool lean = whole && (FORM == 0 || log2_ohw >= 6);
+  const bf16_t* paL[PA];
+  const bf16_t* pbL[PB];
+  int lys[PB], lxs[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int kl = (wave + 4 * i) * RA + ar;
+    paL[i] = A + (size_t)kl * d.lda + min(m0 + (as ^ tn_swz<BM>(kl)) * 8, d.M - 8);
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int kl = (wave + 4 * i) * RB + br;
+    const int c = bs ^ tn_swz<BN>(kl);
+    lys[i] = lxs[i] = 0;
+    if (FORM == 0) {
+      pbL[i] = Bp + (size_t)kl * d.ldb + min(n0 + c * 8, d.N - 8);
+    } else {
+      const int ly = log2_ow < 6 ? (kl >> log2_ow) : 0, lx = log2_ow < 6 ? (kl & ((1 << log2_ow) - 1)) : kl;
+      lys[i] = ly * d.stride;
+      lxs[i] = lx * d.stride;
+      pbL[i] = Bp + ((ptrdiff_t)lys[i] * d.W + lxs[i]) * d.Cin + bci + c * 8;
+    }
+  }
+  auto stage_lean = [&](int kt, int buf) {
+    unsigned char* As = smem + buf * STAGE;
+    unsigned char* Bs = As + 64 * BM * 2;
+    const ptrdiff_t aoff = (ptrdiff_t)kt * 64 * d.lda;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) glds16(paL[i] + aoff, As + (wave_u + 4 * i) * 1024);
+    if (FORM == 0) {
+      const ptrdiff_t boff = (ptrdiff_t)kt * 64 * d.ldb;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) glds16(pbL[i] + boff, Bs + (wave_u + 4 * i) * 1024);
+    } else {
+      const int gshift = log2_ohw - 6;                                  // 64-pixel groups per image = 1 << gshift
+      const int b = kt >> gshift, p0 = (kt & ((1 << gshift) - 1)) << 6;    // image, first pixel of the group inside it
+      const int uy = (p0 >> log2_ow) * d.stride - d.pad + bkh, ux = (p0 & ((1 << log2_ow) - 1)) * d.stride - d.pad + bkw;
+      const ptrdiff_t boff = (((ptrdiff_t)b * d.H + uy) * d.W + ux) * d.Cin;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const bool ok = (unsigned)(uy + lys[i]) < (unsigned)d.H && (unsigned)(ux + lxs[i]) < (unsigned)d.W;
+        glds16(ok ? pbL[i] + boff : zero, Bs + (wave_u + 4 * i) * 1024);
+      }
+    }
+  };
+
   auto stage = [&](int kt, int buf) {
+    if (lean) { stage_lean(kt, buf); return; }
     unsigned char* As = smem + buf * STAGE;
     unsigned char* Bs = As + 64 * BM * 2;
 #pragma unroll
@@ -592,47 +645,64 @@ __global__ __launch_bounds__(NT) void gemm16_tn_kernel(const mmfn_gemm16_desc d,
 #pragma unroll
   for (int s = 0; s < D; ++s)
     if (kt_begin + s < kt_end) stage(kt_begin + s, s);
-  int cur = 0, nxt = D;
   if (NS == 2) {
     MMFN_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
   }
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int ahead = kt_end - 1 - kt;
-    if (ahead >= D) stage(kt + D, nxt);
-    if (NS > 2) {
-      if (ahead >= D) MMFN_WAIT_VMCNT((PA + PB) * D);
-      else if (D > 1 && ahead == 1) MMFN_WAIT_VMCNT(PA + PB);
-      else MMFN_WAIT_VMCNT(0);
-      __builtin_amdgcn_s_barrier();
-    }
-    const unsigned char* As = smem + cur * STAGE;
-    const unsigned char* Bs = As + 64 * BM * 2;
-    cur = cur + 1 == NS ? 0 : cur + 1;
-    nxt = nxt + 1 == NS ? 0 : nxt + 1;
-    bf16x8 a[4][TM], b[4][TN];
+  // unrolled over the NS stages (compile-time stage offsets), as the NT kernel
+  for (int kt0 = kt_begin; kt0 < kt_end; kt0 += NS) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int u = 0; u < NS; ++u) {
+      const int kt = kt0 + u;
+      if (kt >= kt_end) break;
+      const int ahead = kt_end - 1 - kt;
+      if (ahead >= D) stage(kt + D, (u + D) % NS);
+      if (NS > 2) {
+        if (ahead >= D) MMFN_WAIT_VMCNT((PA + PB) * D);
+        else if (D > 1 && ahead == 1) MMFN_WAIT_VMCNT(PA + PB);
+        else MMFN_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+      }
+      const unsigned char* As = smem + u * STAGE;
+      const unsigned char* Bs = As + 64 * BM * 2;
+      bf16x8 a[4][TM], b[4][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[ks][i] = tn_fragment<BM>(As, wm * TM * 32 + i * 32, ks * 16, lane);
+      for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[ks][j] = tn_fragment<BN>(Bs, wn * TN * 32 + j * 32, ks * 16, lane);
-    }
+        for (int i = 0; i < TM; ++i) a[ks][i] = tn_fragment<BM>(As, wm * TM * 32 + i * 32, ks * 16, lane);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+        for (int j = 0; j < TN; ++j) b[ks][j] = tn_fragment<BN>(Bs, wn * TN * 32 + j * 32, ks * 16, lane);
+      }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
-    if (NS == 2) {
-      MMFN_WAIT_VMCNT(0);
-      __builtin_amdgcn_s_barrier();
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+      if (NS == 2) {
+        MMFN_WAIT_VMCNT(0);
+        __builtin_amdgcn_s_barrier();
+      }
     }
   }
   // fp32 output (a gradient) or a split slab; 32 consecutive columns per store instruction
   const bool to_slab = gridDim.y > 1;
   float* out = to_slab ? d.workspace + (size_t)blockIdx.y * d.M * d.N : reinterpret_cast<float*>(d.C);
   const int ldo = to_slab ? d.N : d.ldc;
+  if (m0 + BM <= d.M && n0 + BN <= d.N) {   // interior tile: one pointer per lane, stores at compile-time row multiples of ldo
+    float* p0 = out + (size_t)(m0 + wm * TM * 32 + 4 * h) * ldo + n0 + wn * TN * 32 + l31;
+    const bool accum = !to_slab && (d.flags & MMFN_EPI_ACCUM);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* p = p0 + (size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ldo + j * 32;
+          *p = accum ? acc[i][j][r] + *p : acc[i][j][r];
+        }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
