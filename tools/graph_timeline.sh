@@ -14,6 +14,13 @@ rows = list(csv.DictReader(open(out + '/g_kernel_trace.csv')))
 ev = []
 for r in rows:
     k = r['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
+    if k.startswith('_ZN12_GLOBAL__N_1'):   # a template instance rocprofv3 left mangled: _ZN12_GLOBAL__N_1<len><name>I...
+        rest = k[len('_ZN12_GLOBAL__N_1'):]
+        n = 0
+        while n < len(rest) and rest[n].isdigit():
+            n += 1
+        if n:
+            k = rest[n:n + int(rest[:n])] + '<' + rest[n + int(rest[:n]):][:24] + '>'
     ev.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), k))
 ev.sort()
 # steady-state step = the window between the 4th and 5th adamw launches (graph replays; the profiled eager steps come last)
