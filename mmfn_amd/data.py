@@ -273,11 +273,15 @@ class RawFrameStore(torch.utils.data.Dataset):
 
     Unlike the reference, a sample carries the RAW sensor frames - the uint8 camera image as recorded and the XYZI
     point list - because crop / normalise / y-flip / histogram run on the GPU inside the network's ingest kernels
-    (csrc/ingest.hip); the host only decodes files and does the O(10) pose arithmetic.  seq_len must be 1."""
+    (csrc/ingest.hip); the host only decodes files and does the O(10) pose arithmetic.
+
+    seq_len > 1: a sample carries seq_len camera / map / lane / radar frames, and seq_len LiDAR sweeps, each moved into the ego
+    frame of the LAST one (y flip + `ego_transform` = the reference's transform_2d_points, dataloader.py:225-231, 311-334) on the
+    host in float64 - `lidar_pts` is then a list and `lidar_in_ego_frame` tells the device side not to flip again.  The reference
+    itself runs that block once, after its frame loop, and so returns only the last sweep's histogram (its seq_len > 1 samples
+    do not fit its own model); `lidar_reference_frame` = seq_len - 1 names that one."""
 
     def __init__(self, roots, config):
-        if config.seq_len != 1:
-            raise NotImplementedError("raw-route reader is built for seq_len = 1 (the reference's configuration)")
         self.seq_len, self.pred_len = config.seq_len, config.pred_len
         self.frames = []
         for sub_root in ([roots] if isinstance(roots, str) else list(roots)):
@@ -294,12 +298,13 @@ class RawFrameStore(torch.utils.data.Dataset):
                     # (the reference zeroes a NaN heading only for the future frames at scan time and for the current
                     # ones at load time, dataloader.py:133-137,224-226: same effect)
                     thetas = [0.0 if np.isnan(t) else t for t in thetas]
+                    now = ids[:self.seq_len]
                     self.frames.append({
-                        "rgb": os.path.join(route_dir, "rgb_front", ids[0] + ".png"),
-                        "map": os.path.join(route_dir, "maps", ids[0] + ".png"),
-                        "lidar": os.path.join(route_dir, "lidar", ids[0] + ".npy"),
-                        "radar": os.path.join(route_dir, "radar", ids[0] + ".npy"),
-                        "vectormap": os.path.join(route_dir, "vectormap", ids[0] + ".npy"),
+                        "rgb": [os.path.join(route_dir, "rgb_front", k + ".png") for k in now],
+                        "map": [os.path.join(route_dir, "maps", k + ".png") for k in now],
+                        "lidar": [os.path.join(route_dir, "lidar", k + ".npy") for k in now],
+                        "radar": [os.path.join(route_dir, "radar", k + ".npy") for k in now],
+                        "vectormap": [os.path.join(route_dir, "vectormap", k + ".npy") for k in now],
                         "x": [m["x"] for m in meas], "y": [m["y"] for m in meas], "theta": thetas,
                         "x_command": cur["x_command"], "y_command": cur["y_command"], "steer": cur["steer"],
                         "throttle": cur["throttle"], "brake": cur["brake"], "command": cur["command"], "velocity": cur["speed"],
@@ -311,23 +316,45 @@ class RawFrameStore(torch.utils.data.Dataset):
     def __getitem__(self, i):
         from PIL import Image
         f = self.frames[i]
-        vm = f["vectormap"]
-        j = i
-        while not os.path.exists(vm):  # frames recorded without a lane file borrow a neighbour's (dataloader.py:199-207)
-            j = j - 1 if j - 1 >= 0 else j + 1
-            vm = self.frames[j]["vectormap"]
-        ego = self.seq_len - 1
+        S = self.seq_len
+        ego = S - 1
+        lanes = []
+        for t in range(S):
+            vm, j = f["vectormap"][t], i
+            while not os.path.exists(vm):  # frames recorded without a lane file borrow a neighbour's (dataloader.py:199-207)
+                j = j - 1 if j - 1 >= 0 else j + 1
+                vm = self.frames[j]["vectormap"][t]
+            lanes.append(torch.from_numpy(np.load(vm)))
+        rgbs = [torch.from_numpy(np.array(Image.open(p).convert("RGB"), dtype=np.uint8)) for p in f["rgb"]]
         sample = {
-            "rgb_u8": torch.from_numpy(np.ascontiguousarray(np.asarray(Image.open(f["rgb"]).convert("RGB"), dtype=np.uint8))),
-            "lidar_pts": torch.from_numpy(np.load(f["lidar"]).astype(np.float32)[:, :4]),
-            "vectormaps": [torch.from_numpy(np.load(vm))],
-            "radar": [radar_to_size(np.load(f["radar"]))],
+            "vectormaps": lanes,
+            "radar": [radar_to_size(np.load(p)) for p in f["radar"]],
             "waypoints": local_waypoints(f["x"], f["y"], f["theta"], ego),
             "target_point": local_target_point(f["x_command"], f["y_command"], f["x"][ego], f["y"][ego], f["theta"][ego]),
             "steer": f["steer"], "throttle": f["throttle"], "brake": f["brake"], "command": f["command"], "velocity": f["velocity"],
         }
-        if os.path.exists(f["map"]):
-            sample["maps"] = [torch.from_numpy(np.ascontiguousarray(np.transpose(np.asarray(Image.open(f["map"])), (2, 0, 1))))]
+        if S == 1:
+            sample["rgb_u8"] = rgbs[0]
+            sample["lidar_pts"] = torch.from_numpy(np.load(f["lidar"][0]).astype(np.float32)[:, :4])
+        else:
+            sample["rgb_u8"] = torch.stack(rgbs, 0)
+            sweeps = []
+            for t in range(S):
+                raw = np.load(f["lidar"][t])
+                xyz = raw[..., :3].astype(np.float64)
+                xyz[:, 1] *= -1                                              # dataloader.py:227
+                xyz = ego_transform(xyz, np.pi / 2 - f["theta"][t], -f["x"][t], -f["y"][t],
+                                    np.pi / 2 - f["theta"][ego], -f["x"][ego], -f["y"][ego])
+                pts = np.zeros((len(xyz), 4), np.float64)
+                pts[:, :3] = xyz
+                if raw.shape[1] > 3:
+                    pts[:, 3] = raw[:, 3]
+                sweeps.append(pts)
+            sample["lidar_pts"] = sweeps          # float64 [N_t, 4] each, already in the ego frame
+            sample["lidar_in_ego_frame"] = True
+            sample["lidar_reference_frame"] = ego
+        if all(os.path.exists(p) for p in f["map"]):
+            sample["maps"] = [torch.from_numpy(np.ascontiguousarray(np.transpose(np.asarray(Image.open(p)), (2, 0, 1)))) for p in f["map"]]
         sample["radar_adj"] = radar_adjacency(sample["radar"][0])
         return sample
 
@@ -344,17 +371,23 @@ FAR_POINT = 1.0e6  # padding x coordinate: outside every histogram bin (np.histo
 def collate_raw(samples):
     """RawFrameStore samples -> batch with `rgb_u8` [B,H,W,3] u8 and `lidar_pts` [B,Nmax,4] padded with far points;
     everything else as `collate`."""
-    rest = [{k: v for k, v in s.items() if k not in ("rgb_u8", "lidar_pts")} for s in samples]
+    skip = ("rgb_u8", "lidar_pts", "lidar_in_ego_frame", "lidar_reference_frame")
+    rest = [{k: v for k, v in s.items() if k not in skip} for s in samples]
     out = collate(rest)
-    out["rgb_u8"] = torch.stack([s["rgb_u8"] for s in samples], 0)
-    nmax = max(int(s["lidar_pts"].shape[0]) for s in samples)
+    out["rgb_u8"] = torch.stack([s["rgb_u8"] for s in samples], 0)          # [B, H, W, 3] or, seq_len > 1, [B, S, H, W, 3]
+    several = isinstance(samples[0]["lidar_pts"], (list, tuple))
+    sweeps = [s["lidar_pts"] if several else [s["lidar_pts"]] for s in samples]
+    S = len(sweeps[0])
+    nmax = max(int(p.shape[0]) for sw in sweeps for p in sw)
     nmax = (nmax + 1023) // 1024 * 1024  # few distinct shapes -> few buffer sets / graph captures downstream
-    pts = torch.zeros(len(samples), nmax, 4, dtype=torch.float32)
-    pts[:, :, 0] = FAR_POINT
-    for b, s in enumerate(samples):
-        p = s["lidar_pts"]
-        pts[b, :p.shape[0], :p.shape[1]] = p
-    out["lidar_pts"] = pts
+    pts = torch.zeros(len(samples), S, nmax, 4, dtype=torch.float32)
+    pts[:, :, :, 0] = FAR_POINT
+    for b, sw in enumerate(sweeps):
+        for t, p in enumerate(sw):
+            p = torch.as_tensor(np.asarray(p)).to(torch.float32)
+            pts[b, t, :p.shape[0], :p.shape[1]] = p
+    out["lidar_pts"] = pts if several else pts[:, 0]                      # [B, S, N, 4] (ego frame already) / [B, N, 4] (raw)
+    out["lidar_in_ego_frame"] = bool(samples[0].get("lidar_in_ego_frame", False))
     return out
 
 
@@ -364,13 +397,17 @@ def stage_raw_batch(data, device, config, variant="vec", non_blocking=True):
     dev = torch.device(device)
     to = lambda t, dt=None: torch.as_tensor(t).to(dt or torch.as_tensor(t).dtype).to(dev, non_blocking=non_blocking)
     lane, lane_num, _ = data["vectormaps"][0]
+    rgb, pts = to(data["rgb_u8"]), to(data["lidar_pts"])
+    if rgb.dim() == 5:   # seq_len > 1: a sample's frames become consecutive batch entries (model_vec.py:506-508)
+        rgb, pts = rgb.flatten(0, 1), pts.flatten(0, 1)
     inp = {
-        "rgb_u8": to(data["rgb_u8"]), "lidar_pts": to(data["lidar_pts"]), "lidar_flip_y": True,
+        "rgb_u8": rgb, "lidar_pts": pts, "lidar_flip_y": not data.get("lidar_in_ego_frame", False),
         "target_point": to(torch.stack(list(data["target_point"]), dim=1), torch.float32),
         "velocity": to(data["velocity"], torch.float32),
     }
     if variant == "img":
-        inp["map"] = to(data["maps"][0]).to(torch.float32)
+        maps = [to(m).to(torch.float32) for m in data["maps"][:config.seq_len]]
+        inp["map"] = maps[0] if len(maps) == 1 else torch.stack(maps, dim=1).flatten(0, 1)
     else:
         inp["lane"] = to(lane, torch.float32)
         inp["lane_num"] = to(lane_num, torch.int32)
@@ -394,16 +431,22 @@ def preprocess_routes(store, out_dir, device, batch_size=16):
         samples = [store[i] for i in range(start, min(len(store), start + batch_size))]
         batch = collate_raw(samples)
         pts = batch["lidar_pts"].to(dev)
-        bev = ops.lidar_splat(pts, torch.empty(len(samples), 256, 256, 2, device=dev), flip_y=True).permute(0, 3, 1, 2).cpu().numpy()
+        S = 1
+        if pts.dim() == 4:   # seq_len > 1: [B, S, N, 4], already in the ego frame (no y flip on the device)
+            S = pts.shape[1]
+            pts = pts.flatten(0, 1)
+        bev = ops.lidar_splat(pts, torch.empty(len(samples) * S, 256, 256, 2, device=dev), flip_y=not batch["lidar_in_ego_frame"])
+        bev = bev.permute(0, 3, 1, 2).cpu().numpy().reshape(len(samples), S, 2, 256, 256)
         for k, s in enumerate(samples):
-            rgb = s["rgb_u8"].numpy()
-            H, W = rgb.shape[:2]
-            crop = rgb[H // 2 - 128:H // 2 + 128, W // 2 - 128:W // 2 + 128]
+            frames = s["rgb_u8"].numpy()
+            frames = frames[None] if frames.ndim == 3 else frames
+            H, W = frames.shape[1:3]
             rec = {key: s[key] for key in ("vectormaps", "radar", "waypoints", "target_point", "steer", "throttle", "brake", "command",
                                            "velocity") if key in s}
-            rec["fronts"] = [torch.from_numpy(np.ascontiguousarray(np.transpose(crop, (2, 0, 1))))]
-            rec["lidars"] = [np.ascontiguousarray(bev[k])]
-            rec["maps"] = s.get("maps", [torch.zeros(3, 256, 256, dtype=torch.uint8)])
+            rec["fronts"] = [torch.from_numpy(np.ascontiguousarray(np.transpose(fr[H // 2 - 128:H // 2 + 128, W // 2 - 128:W // 2 + 128], (2, 0, 1))))
+                             for fr in frames]
+            rec["lidars"] = [np.ascontiguousarray(bev[k, t]) for t in range(S)]
+            rec["maps"] = s.get("maps", [torch.zeros(3, 256, 256, dtype=torch.uint8) for _ in range(S)])
             with open(os.path.join(out_dir, "%d.pkl" % (start + k)), "wb") as fd:
                 pickle.dump(rec, fd)
             n += 1

@@ -351,6 +351,36 @@ def raw_route_vectors(ref_dl, ref_cfg, out_dir):
             res["waypoints%d" % i] = np.array(s["waypoints"])
             res["target%d" % i] = np.array(s["target_point"])
             res["labels%d" % i] = np.array([s["steer"], s["throttle"], float(s["brake"]), float(s["command"]), s["velocity"]])
+        # ---- seq_len = 2.  CARLA_Data's frame loop ends BEFORE the sweep is transformed and appended (dataloader.py:225-232 sit
+        # outside `for i in range(self.seq_len)`), so the reference sample carries seq_len camera / map / lane / radar frames and
+        # ONE histogram - the last frame's.  Recorded as it is (key prefix s2_), together with what that block computes when it is
+        # applied to every frame (s2_lidars_all: the reference's own transform_2d_points + lidar_to_histogram_features, frame by
+        # frame): the past sweep moved into the ego frame of the last one.
+        cfg2 = ref_cfg.GlobalConfig()
+        cfg2.seq_len = 2
+        ds2 = ref_dl.CARLA_Data([tmp], cfg2)
+        res["s2_n"] = np.int64(len(ds2))
+        for i in range(len(ds2)):
+            s = ds2[i]
+            assert len(s["fronts"]) == 2 and len(s["lidars"]) == 1
+            for j in range(2):
+                res["s2_fronts%d_%d_sha" % (i, j)] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(s["fronts"][j].numpy()).tobytes()).digest(), dtype=np.uint8)
+                res["s2_maps%d_%d_sha" % (i, j)] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(s["maps"][j].numpy()).tobytes()).digest(), dtype=np.uint8)
+                res["s2_lanes%d_%d" % (i, j)] = s["vectormaps"][j].numpy()
+                res["s2_radar%d_%d" % (i, j)] = s["radar"][j]
+            res["s2_lidar_last%d" % i] = s["lidars"][0]
+            res["s2_waypoints%d" % i] = np.array(s["waypoints"])
+            res["s2_target%d" % i] = np.array(s["target_point"])
+            res["s2_labels%d" % i] = np.array([s["steer"], s["throttle"], float(s["brake"]), float(s["command"]), s["velocity"]])
+            xs, ys, th = ds2.x[i], ds2.y[i], [0.0 if np.isnan(t) else t for t in ds2.theta[i]]
+            per_frame = []
+            for j in range(2):
+                pts = np.load(ds2.lidar[i][j])[..., :3]
+                pts[:, 1] *= -1
+                pts = ref_dl.transform_2d_points(pts, np.pi / 2 - th[j], -xs[j], -ys[j], np.pi / 2 - th[1], -xs[1], -ys[1])
+                per_frame.append(ref_dl.lidar_to_histogram_features(pts, crop=256))
+            res["s2_lidars_all%d" % i] = np.stack(per_frame)
+            assert np.array_equal(per_frame[1], s["lidars"][0])
     np.savez_compressed(os.path.join(out_dir, "raw_route.npz"), **res)
 
 

@@ -92,3 +92,42 @@ def test_frame_store_and_staging(tmp_path, io):
     # the prefetcher hands out the same thing
     (args2, gt2), = list(D.DevicePrefetcher(loader, "cpu", cfg))
     assert torch.equal(gt2, gt) and torch.equal(args2[0][0], fronts[0])
+
+
+def test_raw_route_reader_with_two_frames_per_sample(tmp_path, golden_dir):
+    """RawFrameStore at seq_len = 2 against the reference's CARLA_Data on the same synthetic route (raw_route.npz, s2_*): camera /
+    map / lane / radar frames, labels, waypoints, and the LiDAR sweeps moved into the ego frame of the last one.  The reference
+    keeps only the last sweep (its transform block sits outside the frame loop, dataloader.py:225-232): that one must be
+    bit-identical; the earlier sweep is pinned against the reference's own transform_2d_points + histogram applied to it."""
+    import hashlib
+    from oracle import fixtures, preprocess
+    from mmfn_amd import data as D
+    from mmfn_amd.config import GlobalConfig
+    g = np.load(os.path.join(golden_dir, "raw_route.npz"))
+    root = str(tmp_path / "routes")
+    fixtures.write_synthetic_route(root)
+    store = D.RawFrameStore([root], GlobalConfig(seq_len=2))
+    assert len(store) == int(g["s2_n"]) == 1
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), dtype=np.uint8)
+    s = store[0]
+    assert s["rgb_u8"].shape == (2, 300, 400, 3) and s["lidar_in_ego_frame"] and s["lidar_reference_frame"] == 1
+    for j in range(2):
+        crop = s["rgb_u8"][j].numpy()[150 - 128:150 + 128, 200 - 128:200 + 128]
+        assert np.array_equal(sha(np.transpose(crop, (2, 0, 1))), g["s2_fronts0_%d_sha" % j])
+        assert np.array_equal(sha(s["maps"][j].numpy()), g["s2_maps0_%d_sha" % j])
+        assert np.array_equal(s["vectormaps"][j].numpy(), g["s2_lanes0_%d" % j])
+        assert np.array_equal(s["radar"][j], g["s2_radar0_%d" % j])
+        hist = preprocess.lidar_histogram(np.asarray(s["lidar_pts"][j])[:, :3])
+        assert np.array_equal(hist, g["s2_lidars_all0"][j]), j
+    assert np.array_equal(preprocess.lidar_histogram(np.asarray(s["lidar_pts"][1])[:, :3]), g["s2_lidar_last0"])
+    assert np.abs(np.array(s["waypoints"]) - g["s2_waypoints0"]).max() <= 1e-12 and len(s["waypoints"]) == 6
+    assert np.abs(np.array(s["target_point"]) - g["s2_target0"]).max() <= 1e-12
+    lab = np.array([s["steer"], s["throttle"], float(s["brake"]), float(s["command"]), s["velocity"]])
+    assert np.array_equal(lab, g["s2_labels0"])
+    # collated: frames and sweeps stacked per sample, padded with far points
+    b = D.collate_raw([s, s])
+    assert b["rgb_u8"].shape == (2, 2, 300, 400, 3) and b["lidar_pts"].shape[:2] == (2, 2) and b["lidar_in_ego_frame"] is True
+    assert len(b["maps"]) == 2 and b["maps"][0].shape == (2, 3, 256, 256) and len(b["vectormaps"]) == 2
+    # seq_len = 1 keeps its layout
+    s1 = D.RawFrameStore([root], GlobalConfig())[0]
+    assert s1["rgb_u8"].shape == (300, 400, 3) and not isinstance(s1["lidar_pts"], list) and "lidar_in_ego_frame" not in s1

@@ -80,3 +80,45 @@ def test_training_from_raw_frames_equals_training_from_pickles(route, tmp_path):
     assert nets[0][0] == nets[1][0]
     for k in nets[0][1]:
         assert torch.equal(nets[0][1][k], nets[1][1][k]), k
+
+
+def test_two_frames_per_sample_from_raw_routes(tmp_path):
+    """seq_len = 2 with the image-map model: (a) RawFrameStore -> GPU ingest inside the step (sweeps already in the ego frame, no
+    device-side flip) and (b) GPU phase 1 -> PRE_Data pickles with frame lists -> stage_batch / MMFN._pack: identical loss and
+    weights after one fused step; the phase-1 histograms equal the reference's per-frame transform + histogram."""
+    from mmfn_amd import data as D
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd.model import MMFNImg
+    from mmfn_amd.optim import FusedAdamW
+    from mmfn_amd.trainer import Trainer
+    from oracle import fixtures, harness
+    golden = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raw_route.npz"))
+    root = str(tmp_path / "routes")
+    fixtures.write_synthetic_route(root)                       # one seq_len = 2 sample ...
+    fixtures.write_synthetic_route(root, seed=22, route="route01")   # ... and a second route: batch of two
+    cfg = GlobalConfig(embd_pdrop=0.0, attn_pdrop=0.0, resid_pdrop=0.0, seq_len=2)
+    oracle = harness.build_oracle("img", dropout=0.0, seq_len=2)
+    store = D.RawFrameStore([root], cfg)
+    assert len(store) == 2
+    out = str(tmp_path / "pro")
+    assert D.preprocess_routes(store, out, DEV) == 2
+    pre = D.PRE_Data(out, cfg, "train")
+    order = [int(os.path.basename(f).split(".")[0]) for f in pre.files]
+    first = pre[order.index(0)]
+    assert len(first["fronts"]) == 2 and len(first["lidars"]) == 2 and len(first["maps"]) == 2
+    # the float32 copy of the transformed sweeps may move a point that sits within 1e-7 of a bin edge: allow a handful of cells
+    for t in range(2):
+        diff = np.abs(first["lidars"][t] - golden["s2_lidars_all0"][t])
+        assert (diff > 0).sum() <= 4 and diff.max() <= 0.2, (t, int((diff > 0).sum()), float(diff.max()))
+    raw_loader = torch.utils.data.DataLoader(torch.utils.data.Subset(store, order), batch_size=2, collate_fn=D.collate_raw)
+    pre_loader = D.make_loader(pre, batch_size=2, num_workers=0)
+    nets = []
+    for loader in (raw_loader, pre_loader):
+        net = MMFNImg(cfg, DEV)
+        net.load_state_dict(oracle.state_dict(), strict=True)
+        tr = Trainer(DEV, None)
+        loss = tr.train(net, loader, cfg, FusedAdamW(net, lr=1e-4))
+        nets.append((loss, net.state_dict()))
+    assert np.isfinite(nets[0][0]) and nets[0][0] == nets[1][0]
+    for k in nets[0][1]:
+        assert torch.equal(nets[0][1][k], nets[1][1][k]), k
