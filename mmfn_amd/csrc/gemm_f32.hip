@@ -721,6 +721,36 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
         for (int r = 0; r < 16; ++r) p0[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ld + q * 32] = acc[i][q][r];
     return;
   }
+  // Interior tile with the common epilogue operations (bias, ReLU, ReLU-backward mask, dropout, residual, final ReLU): the same
+  // per-lane pointers; the flags are read once per tile instead of once per element, ReLU is a max against 0 or -inf.
+  if (!dgp && !to_slab && m0 + BM <= d.M && n0 + BN <= d.N && !(d.flags & (MMFN_EPI_GELU | MMFN_EPI_ACCUM))) {
+    const int f = d.flags;
+    const size_t lrow = (size_t)(m0 + wm * TM * 32 + 4 * h);
+    const int lcol = n0 + wn * TN * 32 + l31;
+    float* p0 = d.C + lrow * d.ldc + lcol;
+    const float* r0 = (f & MMFN_EPI_RESIDUAL) ? d.res + lrow * d.ldr + lcol : nullptr;
+    const float* a0 = (f & MMFN_EPI_MASK_AUX) ? d.aux + lrow * d.ldaux + lcol : nullptr;
+    const float floor1 = (f & MMFN_EPI_RELU) ? 0.0f : -INFINITY, floor2 = (f & MMFN_EPI_RELU_LAST) ? 0.0f : -INFINITY;
+    const bool drop = (f & MMFN_EPI_DROPOUT) != 0;
+    const float inv_keep = drop ? 1.0f / (1.0f - d.drop_p) : 1.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int q = 0; q < TN; ++q) {
+        const float bias = (f & MMFN_EPI_BIAS) ? d.bias[lcol + q * 32] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
+          float v = fmaxf(acc[i][q][r] + bias, floor1);
+          if (a0) v = a0[(size_t)dr * d.ldaux + q * 32] > 0.0f ? v : 0.0f;
+          if (drop)
+            v *= mmfn_dropout_scale(key, (uint64_t)(lrow + dr) * (uint64_t)d.N + (uint64_t)(lcol + q * 32), d.drop_p, inv_keep);
+          if (r0) v += r0[(size_t)dr * d.ldr + q * 32];
+          p0[(size_t)dr * d.ldc + q * 32] = fmaxf(v, floor2);
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
