@@ -191,19 +191,33 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
       if (par) { by = (ay[i] - d.pad) >> 1; bx = (ax[i] - d.pad) >> 1; }
       const int sh = FORM == 1 ? d.H : d.OH, sw = FORM == 1 ? d.W : d.OW, sc = FORM == 1 ? d.Cin : d.Cout;
       pl[i] = pa[i] + ((ptrdiff_t)by * sw + bx) * sc;
-      unsigned mk = 0;
-      for (int t = 0; t < ntaps; ++t) {
-        const int kh = t / d.KW, kw = t - kh * d.KW;
-        int y, x;
-        if (FORM == 1) { y = by + kh; x = bx + kw; }
-        else if (!par) { y = by - kh; x = bx - kw; }
+      // a tap (kh, kw) is inside iff its row is and its column is: KH + KW tests instead of KH * KW
+      unsigned mh = 0, mw = 0;
+      for (int kh = 0; kh < d.KH; ++kh) {
+        int y;
+        if (FORM == 1) y = by + kh;
+        else if (!par) y = by - kh;
         else {
-          const int dy = (pcls >> 1) + d.pad - kh, dx = (pcls & 1) + d.pad - kw;
-          if ((dy | dx) & 1) continue;              // not a tap of this parity class
-          y = by + dy / 2; x = bx + dx / 2;
+          const int dy = (pcls >> 1) + d.pad - kh;
+          if (dy & 1) continue;                     // not a tap row of this parity class
+          y = by + dy / 2;
         }
-        if ((unsigned)y < (unsigned)sh && (unsigned)x < (unsigned)sw) mk |= 1u << t;
+        if ((unsigned)y < (unsigned)sh) mh |= 1u << kh;
       }
+      for (int kw = 0; kw < d.KW; ++kw) {
+        int x;
+        if (FORM == 1) x = bx + kw;
+        else if (!par) x = bx - kw;
+        else {
+          const int dx = (pcls & 1) + d.pad - kw;
+          if (dx & 1) continue;
+          x = bx + dx / 2;
+        }
+        if ((unsigned)x < (unsigned)sw) mw |= 1u << kw;
+      }
+      unsigned mk = 0;
+      for (int kh = 0; kh < d.KH; ++kh)
+        if ((mh >> kh) & 1u) mk |= mw << (kh * d.KW);
       vmask[i] = mk;
     }
   }
