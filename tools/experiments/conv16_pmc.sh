@@ -10,7 +10,7 @@ import os, sys, torch
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
 from mmfn_amd import ops16
 DEV = "cuda:0"; BF = torch.bfloat16
-B, H, C = 32, 8, 512
+B, H, C = int(os.environ.get("PB", 32)), int(os.environ.get("PH", 8)), int(os.environ.get("PC", 512))
 x = torch.randn(B, H, H, C, device=DEV).to(BF); w = (torch.randn(C, 3, 3, C, device=DEV) * 0.05).to(BF)
 y = torch.empty(B, H, H, C, dtype=BF, device=DEV)
 M, N, K = B * H * H, C, 9 * C
