@@ -47,6 +47,13 @@ int mmfn_wino_weight_f32(const float* w, float* U, int Co, int Ci, int m, void* 
  * total = sum of Co*Ci.  U[l] receives [36][Co][Ci] exactly as mmfn_wino_weight_f32(m = 4) writes it. */
 int mmfn_wino_weight_group_f32(const void* table, int n_layers, int64_t total, void* stream);
 int mmfn_wino_input_f32(const float* x, float* V, int B, int H, int W, int C, int m, void* stream);
+/* F(4x4) input transform of d = [relu]( (x - mean) * rstd * weight + bias [+ res] ): the PRODUCER's BatchNorm apply
+ * (aten batch_norm's elementwise pass + add_ + relu_ between two convolutions of a torchvision BasicBlock chain,
+ * model_vec.py:509-593) runs inside the consumer's transform; x = the producer's convolution output, the zero padding pads d.
+ * y != NULL also receives d as an NHWC tensor (a block output that the next block's skip connection reads); y == NULL: d is
+ * never written, and the backward kernels recompute its ReLU sign from x (relu_bias arguments below). */
+int mmfn_wino_input_bn_f32(const float* x, const float* res, const float* mean, const float* rstd, const float* weight,
+                           const float* bias, int relu, float* y, float* V, int B, int H, int W, int C, void* stream);
 int mmfn_wino_output_f32(const float* Mt, const float* res, float* y, int B, int H, int W, int C, int m, void* stream);
 /* F(4x4) output transform that also writes the BatchNorm batch-statistics partial rows of y ([*nblk_out][2][C] doubles, at most
  * 512 rows; *nblk_out is a host int), to be finished by mmfn_bn_finalize_stats_f32 */
@@ -56,23 +63,17 @@ int mmfn_wino_output_stats_f32(const float* Mt, float* y, double* partials, int*
  *   dMt[36][tiles][Co] = A dy A^T per 4x4 patch;  dU[t] = dMt[t]^T . V[t] (batched GEMM);  dw[Co][3][3][Ci] = G^T dU G */
 int mmfn_wino_outgrad_f32(const float* dy, float* dMt, int B, int H, int W, int C, void* stream);
 /* The same transform of dy = BatchNorm-backward(g, y, x) formed on the fly (mmfn_bn_bwd_f32's apply pass fused in): g = dL/d(BN
- * output), y != NULL applies the ReLU mask (y > 0), x = the convolution output, means[2][C] from mmfn_bn_bwd_reduce_f32;
- * ge_out (optional) = masked g.  dy itself is never written: these layers only consume it in the Winograd domain. */
+ * output), y != NULL applies the ReLU mask (y > 0); y == NULL with relu_bias != NULL (the BatchNorm's bias) applies the mask
+ * recomputed from x (the output was consumed by mmfn_wino_input_bn_f32 and never written); x = the convolution output,
+ * means[2][C] from mmfn_bn_bwd_reduce_f32; ge_out (optional) = masked g.  dy itself is never written: these layers only consume
+ * it in the Winograd domain. */
 int mmfn_wino_outgrad_bn_f32(const float* g, const float* y, const float* x, const float* mean, const float* rstd,
-                             const float* weight, const float* means, float* ge_out, float* dMt, int B, int H, int W, int C,
-                             void* stream);
+                             const float* weight, const float* relu_bias, const float* means, float* ge_out, float* dMt, int B,
+                             int H, int W, int C, void* stream);
 /* Data gradient of the same convolution as the ADJOINT of its forward Winograd pipeline: dV [36][tiles][Ci] (= dM . U, one
  * 36-batch GEMM over the forward's own transformed filter) -> dx = overlap-add of B dV B^T over the tiles' 6x6 input patches
  * (+ res).  H, W multiples of 4; replaces cuDNN's backward-data for the BasicBlock 3x3 convolutions (model_vec.py:539-593). */
 int mmfn_wino_input_adjoint_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, void* stream);
-/* The same launch also emitting the two reductions of the BatchNorm backward that dx enters (dx is dL/d(output) of the BatchNorm
- * + ReLU that produced this convolution's input): partials[rows][2][C] doubles = per-block (sum ge, sum ge * xhat) with
- * ge = dx * (ey > 0) (ey NULL: no ReLU), xhat = (ex - emean) * erstd, ex = that BatchNorm's input (the producer's convolution
- * output); rows = mmfn_wino_input_adjoint_emit_rows().  mmfn_bn_bwd_reduce_partials_f32 finishes them: the producer's
- * native_batch_norm_backward then needs no reduction pass of its own over g, y and x. */
-int mmfn_wino_input_adjoint_emit_rows(int B, int H, int W, int C);
-int mmfn_wino_input_adjoint_emit_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, const float* ey,
-                                     const float* ex, const float* emean, const float* erstd, double* partials, void* stream);
 int mmfn_wino_wgrad_out_f32(const float* dU, float* dw, int Co, int Ci, void* stream);
 /* The 7x7 stride-2 stems (torchvision conv1, model_vec.py:509,515: 3 camera / 2 BEV channels) as explicit im2col + plain GEMM:
  * col[B*OH*OW][KP] (fp32, or bf16 with out_bf16) = the zero-padded patch matrix of x [B,H,W,Cin] (fp32, Cin <= 4), k = (kh, kw, ci),
@@ -238,17 +239,17 @@ int mmfn_bn_fold_f32(const float* w, int Cout, int K, const float* gamma, const 
                      const float* running_var, float eps, float* w_out, float* b_out, void* stream);
 int mmfn_bn_apply_f32(const float* x, const float* res, float* y, int64_t M, int C, const float* mean, const float* rstd,
                       const float* weight, const float* bias, int relu, void* stream);
-/* backward of y = relu?(bn(x) [+res]): g = dL/dy; if y != NULL the ReLU mask (y > 0) is applied first.
- * Writes dx, dweight, dbias and (optionally) ge_out = masked g, the gradient of the residual branch. */
+/* backward of y = relu?(bn(x) [+res]): g = dL/dy; if y != NULL the ReLU mask (y > 0) is applied first; y == NULL with
+ * relu_bias != NULL (the BatchNorm's bias; no residual): the mask (bn(x) > 0) is recomputed from x - the forward never wrote y
+ * (mmfn_wino_input_bn_f32).  Writes dx, dweight, dbias and (optionally) ge_out = masked g, the gradient of the residual branch. */
 int mmfn_bn_bwd_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean, const float* rstd,
-                    const float* weight, float* dx, float* ge_out, float* dweight, float* dbias, void* workspace,
-                    void* stream);
-/* The reductions of mmfn_bn_bwd_f32 without its apply pass: dweight, dbias, means[2][C] = (mean(ge), mean(ge * xhat)) */
+                    const float* weight, const float* relu_bias, float* dx, float* ge_out, float* dweight, float* dbias,
+                    void* workspace, void* stream);
+/* The reductions of mmfn_bn_bwd_f32 without its apply pass: dweight, dbias, means[2][C] = (mean(ge), mean(ge * xhat));
+ * relu_weight / relu_bias (both or neither): the recomputed mask as above */
 int mmfn_bn_bwd_reduce_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean,
-                           const float* rstd, float* dweight, float* dbias, float* means, void* workspace, void* stream);
-/* ... from per-block partial sums [rows][2][C] (doubles) that another launch produced (mmfn_wino_input_adjoint_emit_f32) */
-int mmfn_bn_bwd_reduce_partials_f32(const double* partials, int rows, int64_t M, int C, float* dweight, float* dbias, float* means,
-                                    void* stream);
+                           const float* rstd, const float* relu_weight, const float* relu_bias, float* dweight, float* dbias,
+                           float* means, void* workspace, void* stream);
 /* LayerNorm over rows of x[M,C] (C % 64 == 0, C <= 512), optional fused activation on the output
  * (act: 0 none, 1 ReLU, 2 exact GELU).  Replaces aten native_layer_norm (+relu/gelu) of
  * model_vec.py:117-118,162 (GPT) and :252,335-336,345-346,352-353 (VectorNet). */

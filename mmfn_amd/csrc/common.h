@@ -66,6 +66,14 @@ template <typename T> struct VecIO<1, T> {
   static __device__ __forceinline__ void st(T* p, vec v) { stx1(p, v[0]); }
 };
 
+// BatchNorm apply y = x * alpha + beta with alpha = w * rstd, beta = b - mean * alpha: ONE spelling (explicit fma) for every
+// kernel that evaluates it - the apply pass (norm.hip), the Winograd input transform that applies the producer's BatchNorm on the
+// fly (winograd.hip) and the backward kernels that recompute the ReLU mask of an output that was never written to HBM - so
+// that a recomputed sign is the forward's sign bit for bit.
+__device__ __forceinline__ float mmfn_bn_alpha(float w, float rstd) { return w * rstd; }
+__device__ __forceinline__ float mmfn_bn_beta(float b, float mean, float alpha) { return fmaf(-mean, alpha, b); }
+__device__ __forceinline__ float mmfn_bn_affine(float x, float alpha, float beta) { return fmaf(x, alpha, beta); }
+
 #define MMFN_LAUNCH_CHECK()                        \
   do {                                             \
     hipError_t e__ = hipGetLastError();            \

@@ -17,13 +17,16 @@ constexpr int NT = 256;
 // ------------------------------------------------------------------ column statistics
 // MODE 0: s1 = sum x,        s2 = sum x^2                      (BN forward statistics)
 // MODE 1: s1 = sum ge,       s2 = sum ge * xhat                (BN backward reductions)
-//         ge = g * (y > 0) when y != null else g;  xhat = (x - mean) * rstd
+//         ge = g * (y > 0) when y != null; g * (bn(x) > 0) when y == null and zb != null (the BatchNorm + ReLU output was never
+//         written: its sign is recomputed from x with the forward's own expression, zw / zb = the BatchNorm's weight / bias);
+//         else g;  xhat = (x - mean) * rstd
 // TX: element type of x (the convolution output), TA: of the activation-side tensors g, y (fp32 path: both float; bf16 mode:
 // both bf16, except the fp32 stems whose convolution output stays fp32)
 template <int MODE, typename TX, typename TA>
 __global__ __launch_bounds__(NT) void col_partial_kernel(const TX* __restrict__ x, const TA* __restrict__ g,
                                                          const TA* __restrict__ y, const float* __restrict__ mean,
-                                                         const float* __restrict__ rstd, int64_t M, int C,
+                                                         const float* __restrict__ rstd, const float* __restrict__ zw,
+                                                         const float* __restrict__ zb, int64_t M, int C,
                                                          int64_t rows_per_block, double* __restrict__ partials) {
   const int cq = C >> 2;           // float4 columns
   const int tid = threadIdx.x;
@@ -33,10 +36,15 @@ __global__ __launch_bounds__(NT) void col_partial_kernel(const TX* __restrict__ 
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  f32x4 mu = {0, 0, 0, 0}, rs = {0, 0, 0, 0};
+  f32x4 mu = {0, 0, 0, 0}, rs = {0, 0, 0, 0}, al = {0, 0, 0, 0}, be = {0, 0, 0, 0};
+  const bool zmask = MODE == 1 && !y && zb;
   if (MODE == 1) {
     mu = *reinterpret_cast<const f32x4*>(mean + col4 * 4);
     rs = *reinterpret_cast<const f32x4*>(rstd + col4 * 4);
+    if (zmask) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { al[e] = mmfn_bn_alpha(zw[col4 * 4 + e], rs[e]); be[e] = mmfn_bn_beta(zb[col4 * 4 + e], mu[e], al[e]); }
+    }
   }
   for (int64_t r = r0 + rl; r < r1; r += RL) {
     const size_t off = (size_t)r * C + col4 * 4;
@@ -50,6 +58,9 @@ __global__ __launch_bounds__(NT) void col_partial_kernel(const TX* __restrict__ 
         const f32x4 yv = ldx4(y + off);
 #pragma unroll
         for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.0f ? gv[e] : 0.0f;
+      } else if (zmask) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[e] = mmfn_bn_affine(xv[e], al[e], be[e]) > 0.0f ? gv[e] : 0.0f;
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -181,9 +192,9 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const TX* __restrict__ x, 
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float alpha = w[c4 + e] * rstd[c4 + e];
-      const float beta = b[c4 + e] - mean[c4 + e] * alpha;
-      o[e] = xv[e] * alpha + beta;
+      float alpha, beta;
+      { alpha = mmfn_bn_alpha(w[c4 + e], rstd[c4 + e]); beta = mmfn_bn_beta(b[c4 + e], mean[c4 + e], alpha); }
+      o[e] = mmfn_bn_affine(xv[e], alpha, beta);
     }
     if (res) {
       const f32x4 rv = ldx4(res + i * 4);
@@ -220,17 +231,26 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const TA* __restrict__
                                                           const TX* __restrict__ x, TX* __restrict__ dx,
                                                           TA* __restrict__ ge_out, int64_t total4, int C,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          const float* __restrict__ w, const float* __restrict__ means) {
+                                                          const float* __restrict__ w, const float* __restrict__ zb,
+                                                          const float* __restrict__ means) {
   const int cq = C >> 2;
+  const bool zmask = !y && zb;   // ReLU mask recomputed from x (see col_partial_kernel)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % cq) * 4;
     f32x4 gv = ldx4(g + i * 4);
+    const f32x4 xv = ldx4(x + i * 4);
     if (y) {
       const f32x4 yv = ldx4(y + i * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.0f ? gv[e] : 0.0f;
+    } else if (zmask) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float alpha, beta;
+        { alpha = mmfn_bn_alpha(w[c4 + e], rstd[c4 + e]); beta = mmfn_bn_beta(zb[c4 + e], mean[c4 + e], alpha); }
+        gv[e] = mmfn_bn_affine(xv[e], alpha, beta) > 0.0f ? gv[e] : 0.0f;
+      }
     }
-    const f32x4 xv = ldx4(x + i * 4);
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -452,7 +472,8 @@ int bn_train_stats_launch(const TX* x, int64_t M, int C, float eps, float moment
   int64_t rpb;
   const int nblk = bn_grid(M, C, &rpb);
   hipLaunchKernelGGL((col_partial_kernel<0, TX, TX>), dim3(nblk), dim3(NT), 0, s, x, (const TX*)nullptr, (const TX*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, M, C, rpb, (double*)workspace);
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, rpb,
+                     (double*)workspace);
   MMFN_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, (const double*)workspace, nblk, M, C,
                      eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked);
@@ -515,17 +536,20 @@ int bn_apply_launch(const TX* x, const TA* res, TA* y, int64_t M, int C, const f
   return 0;
 }
 // reduce != 0: the two reductions (dweight, dbias, means);  apply != 0: the elementwise pass (dx, ge_out) from `means`
+// bias != NULL with y == NULL: the ReLU mask is recomputed from x (needs weight too)
 template <typename TX, typename TA>
 int bn_bwd_launch(const TA* g, const TA* y, const TX* x, int64_t M, int C, const float* mean, const float* rstd, const float* weight,
-                  TX* dx, TA* ge_out, float* dweight, float* dbias, float* means, void* workspace, int reduce, int apply, void* stream) {
-  if (C % 4 || C > 1024 || (NT % (C / 4)) || M <= 0 || !workspace) return MMFN_EINVAL;
+                  const float* bias, TX* dx, TA* ge_out, float* dweight, float* dbias, float* means, void* workspace, int reduce,
+                  int apply, void* stream) {
+  if (C % 4 || C > 1024 || (NT % (C / 4)) || M <= 0 || !workspace || (bias && !weight)) return MMFN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   int64_t rpb;
   const int nblk = bn_grid(M, C, &rpb);
   double* partials = (double*)workspace;
   if (!means) means = (float*)(partials + (size_t)nblk * 2 * C);
   if (reduce) {
-    hipLaunchKernelGGL((col_partial_kernel<1, TX, TA>), dim3(nblk), dim3(NT), 0, s, x, g, y, mean, rstd, M, C, rpb, partials);
+    hipLaunchKernelGGL((col_partial_kernel<1, TX, TA>), dim3(nblk), dim3(NT), 0, s, x, g, y, mean, rstd, weight, bias, M, C, rpb,
+                       partials);
     MMFN_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, partials, nblk, M, C, dweight, dbias,
                        means);
@@ -535,7 +559,7 @@ int bn_bwd_launch(const TA* g, const TA* y, const TX* x, int64_t M, int C, const
     const int64_t total4 = M * (C / 4);
     const int blocks = (int)std::min<int64_t>(ceil_div64(total4, NT), 8192);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<TX, TA>), dim3(blocks), dim3(NT), 0, s, g, y, x, dx, ge_out, total4, C, mean, rstd, weight,
-                       means);
+                       bias, means);
     MMFN_LAUNCH_CHECK();
   }
   return 0;
@@ -554,38 +578,30 @@ extern "C" int mmfn_bn_apply_bf16(const void* x, int x_is_f32, const void* res, 
 }
 
 extern "C" int mmfn_bn_bwd_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean,
-                               const float* rstd, const float* weight, float* dx, float* ge_out, float* dweight,
-                               float* dbias, void* workspace, void* stream) {
-  return bn_bwd_launch(g, y, x, M, C, mean, rstd, weight, dx, ge_out, dweight, dbias, (float*)nullptr, workspace, 1, 1, stream);
+                               const float* rstd, const float* weight, const float* relu_bias, float* dx, float* ge_out,
+                               float* dweight, float* dbias, void* workspace, void* stream) {
+  return bn_bwd_launch(g, y, x, M, C, mean, rstd, weight, relu_bias, dx, ge_out, dweight, dbias, (float*)nullptr, workspace, 1, 1,
+                       stream);
 }
 /* bf16 mode: g, y, ge_out bf16; x and dx (the convolution output and its gradient) bf16, or both fp32 when x_is_f32 (stems) */
 extern "C" int mmfn_bn_bwd_bf16(const void* g, const void* y, const void* x, int x_is_f32, int64_t M, int C, const float* mean,
                                 const float* rstd, const float* weight, void* dx, void* ge_out, float* dweight, float* dbias,
                                 void* workspace, void* stream) {
   if (x_is_f32)
-    return bn_bwd_launch((const bf16_t*)g, (const bf16_t*)y, (const float*)x, M, C, mean, rstd, weight, (float*)dx, (bf16_t*)ge_out,
-                         dweight, dbias, (float*)nullptr, workspace, 1, 1, stream);
-  return bn_bwd_launch((const bf16_t*)g, (const bf16_t*)y, (const bf16_t*)x, M, C, mean, rstd, weight, (bf16_t*)dx, (bf16_t*)ge_out,
-                       dweight, dbias, (float*)nullptr, workspace, 1, 1, stream);
+    return bn_bwd_launch((const bf16_t*)g, (const bf16_t*)y, (const float*)x, M, C, mean, rstd, weight, (const float*)nullptr, (float*)dx,
+                         (bf16_t*)ge_out, dweight, dbias, (float*)nullptr, workspace, 1, 1, stream);
+  return bn_bwd_launch((const bf16_t*)g, (const bf16_t*)y, (const bf16_t*)x, M, C, mean, rstd, weight, (const float*)nullptr, (bf16_t*)dx,
+                       (bf16_t*)ge_out, dweight, dbias, (float*)nullptr, workspace, 1, 1, stream);
 }
 
 // First two launches of mmfn_bn_bwd_f32 only: dweight, dbias and means[2][C] = (mean(ge), mean(ge * xhat)); the caller
 // applies them itself (mmfn_wino_outgrad_bn_f32 forms dx inside the Winograd output-gradient transform).
 extern "C" int mmfn_bn_bwd_reduce_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean,
-                                      const float* rstd, float* dweight, float* dbias, float* means, void* workspace,
-                                      void* stream) {
+                                      const float* rstd, const float* relu_weight, const float* relu_bias, float* dweight,
+                                      float* dbias, float* means, void* workspace, void* stream) {
   if (!means) return MMFN_EINVAL;
-  return bn_bwd_launch(g, y, x, M, C, mean, rstd, (const float*)nullptr, (float*)nullptr, (float*)nullptr, dweight, dbias, means,
+  return bn_bwd_launch(g, y, x, M, C, mean, rstd, relu_weight, relu_bias, (float*)nullptr, (float*)nullptr, dweight, dbias, means,
                        workspace, 1, 0, stream);
-}
-
-extern "C" int mmfn_bn_bwd_reduce_partials_f32(const double* partials, int rows, int64_t M, int C, float* dweight, float* dbias,
-                                               float* means, void* stream) {
-  if (!partials || rows <= 0 || C <= 0 || M <= 0 || !dweight || !dbias || !means) return MMFN_EINVAL;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, (hipStream_t)stream, partials, rows, M,
-                     C, dweight, dbias, means);
-  MMFN_LAUNCH_CHECK();
-  return 0;
 }
 
 namespace {
@@ -745,7 +761,7 @@ extern "C" int mmfn_bn_bwd_partials_bf16(const double* partials, int rows, const
   const int64_t total4 = M * (C / 4);
   const int blocks = (int)std::min<int64_t>(ceil_div64(total4, NT), 8192);
   hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(NT), 0, s, (const bf16_t*)g, (const bf16_t*)y, (const bf16_t*)x,
-                     (bf16_t*)dx, (bf16_t*)ge_out, total4, C, mean, rstd, weight, means);
+                     (bf16_t*)dx, (bf16_t*)ge_out, total4, C, mean, rstd, weight, (const float*)nullptr, means);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

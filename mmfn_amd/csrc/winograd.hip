@@ -206,6 +206,64 @@ __global__ __launch_bounds__(NT) void wino4_input_kernel(const float* __restrict
   }
 }
 
+// The same transform reading the PRODUCER's convolution output and applying its BatchNorm (+ residual) (+ ReLU) on the fly:
+//   d = [relu]( bn(x) [+ res] ) inside the image, 0 in the padding ring (the padding pads the activation, not bn(0)),
+// so the BatchNorm apply pass between two convolutions of a BasicBlock chain (model_vec.py:509-593 -> torchvision BasicBlock:
+// bn1 -> relu -> conv2, bn2 -> +identity -> relu -> next conv1) is no kernel of its own and its output makes no round trip through
+// HBM.  y != NULL: the activation is needed as a tensor as well (the block output: the next block's skip connection); every
+// tile then writes the 4x4 interior of its 6x6 patch, which tiles the image exactly.  y == NULL: it is never written; the
+// backward recomputes the ReLU sign from x (col_partial_kernel / wino4_outgrad_bn_kernel, zmask).
+__global__ __launch_bounds__(NT) void wino4_input_bn_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            const float* __restrict__ bw, const float* __restrict__ bb, int relu,
+                                                            float* __restrict__ y, float* __restrict__ V, int B, int H, int W, int C) {
+  const int cq = C >> 2, th = H >> 2, tw = W >> 2;
+  const int64_t T = (int64_t)B * th * tw, n = T * cq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % cq) * 4;
+    const int64_t tile = i / cq;
+    const int j = (int)(tile % tw), ii = (int)((tile / tw) % th), b = (int)(tile / ((int64_t)tw * th));
+    f32x4 al, be;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { al[e] = mmfn_bn_alpha(bw[c4 + e], rstd[c4 + e]); be[e] = mmfn_bn_beta(bb[c4 + e], mean[c4 + e], al[e]); }
+    f32x4 r[6][6];
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+      const int xx = 4 * j - 1 + e;
+      f32x4 d[6], c[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        const int yy = 4 * ii - 1 + a;
+        const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          const size_t off = (((size_t)b * H + yy) * W + xx) * C + c4;
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = mmfn_bn_affine(xv[q], al[q], be[q]);
+          if (res) o += *reinterpret_cast<const f32x4*>(res + off);
+          if (relu) {   // fmaxf, as bn_apply_kernel
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = fmaxf(o[q], 0.0f);
+          }
+          if (y && a >= 1 && a <= 4 && e >= 1 && e <= 4) *reinterpret_cast<f32x4*>(y + off) = o;
+        }
+        d[a] = o;
+      }
+      f4_bt(d, c);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) r[a][e] = c[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      f32x4 v[6];
+      f4_bt(r[a], v);
+#pragma unroll
+      for (int e = 0; e < 6; ++e) *reinterpret_cast<f32x4*>(V + ((size_t)(a * 6 + e) * T + tile) * C + c4) = v[e];
+    }
+  }
+}
+
 __global__ __launch_bounds__(NT) void wino4_output_kernel(const float* __restrict__ Mt, const float* __restrict__ res,
                                                           float* __restrict__ y, int B, int H, int W, int C) {
   const int cq = C >> 2, th = H >> 2, tw = W >> 2;
@@ -331,10 +389,12 @@ __global__ __launch_bounds__(NT) void wino4_outgrad_kernel(const float* __restri
 __global__ __launch_bounds__(NT) void wino4_outgrad_bn_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                               const float* __restrict__ x, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const float* __restrict__ w,
-                                                              const float* __restrict__ means, float* __restrict__ ge_out,
-                                                              float* __restrict__ dMt, int B, int H, int W, int C) {
+                                                              const float* __restrict__ zb, const float* __restrict__ means,
+                                                              float* __restrict__ ge_out, float* __restrict__ dMt, int B, int H, int W,
+                                                              int C) {
   const int cq = C >> 2, th = H >> 2, tw = W >> 2;
   const int64_t T = (int64_t)B * th * tw, n = T * cq;
+  const bool zmask = !y && zb;   // the ReLU output was never written: its sign is recomputed from x (norm.hip col_partial_kernel)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % cq) * 4;
     const int64_t tile = i / cq;
@@ -342,6 +402,11 @@ __global__ __launch_bounds__(NT) void wino4_outgrad_bn_kernel(const float* __res
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4), rs = *reinterpret_cast<const f32x4*>(rstd + c4);
     const f32x4 wv = *reinterpret_cast<const f32x4*>(w + c4);
     const f32x4 m1 = *reinterpret_cast<const f32x4*>(means + c4), m2 = *reinterpret_cast<const f32x4*>(means + C + c4);
+    f32x4 al = {0.f, 0.f, 0.f, 0.f}, be = {0.f, 0.f, 0.f, 0.f};
+    if (zmask) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { al[e] = mmfn_bn_alpha(wv[e], rs[e]); be[e] = mmfn_bn_beta(zb[c4 + e], mu[e], al[e]); }
+    }
     f32x4 r[6][4];  // A dy, column by column
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -350,13 +415,16 @@ __global__ __launch_bounds__(NT) void wino4_outgrad_bn_kernel(const float* __res
       for (int p = 0; p < 4; ++p) {
         const size_t off = (((size_t)b * H + 4 * ii + p) * W + 4 * j + q) * C + c4;
         f32x4 gv = *reinterpret_cast<const f32x4*>(g + off);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
         if (y) {
           const f32x4 yv = *reinterpret_cast<const f32x4*>(y + off);
 #pragma unroll
           for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.0f ? gv[e] : 0.0f;
+        } else if (zmask) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gv[e] = mmfn_bn_affine(xv[e], al[e], be[e]) > 0.0f ? gv[e] : 0.0f;
         }
         if (ge_out) *reinterpret_cast<f32x4*>(ge_out + off) = gv;
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float xh = (xv[e] - mu[e]) * rs[e];
@@ -482,66 +550,6 @@ __global__ __launch_bounds__(NT) void wino4_input_adjoint_kernel(const float* __
   }
 }
 
-// The same, and - since dx is the gradient entering the PRODUCER's BatchNorm (dx = dL/d(BN output), the producer being the
-// convolution whose output this layer read) - the two reductions of that BatchNorm's backward as a by-product:
-//   partials[block][0][c] = sum ge,  partials[block][1][c] = sum ge * xhat,   ge = dx * (ey > 0) (ey != NULL), xhat = (ex - mean) * rstd
-// so the producer's backward skips its own reduction pass over g, y and x (col_partial_kernel<1>: three tensor reads and a launch).
-// Block layout as wino4_output_stats_kernel: thread = (tile lane, channel quad), one partial row per block.
-__global__ __launch_bounds__(NT) void wino4_input_adjoint_emit_kernel(const float* __restrict__ dV, const float* __restrict__ res,
-                                                                      float* __restrict__ dx, int B, int H, int W, int C,
-                                                                      const float* __restrict__ ey, const float* __restrict__ ex,
-                                                                      const float* __restrict__ emean, const float* __restrict__ erstd,
-                                                                      double* __restrict__ partials, int tiles_per_block) {
-  const int cq = C >> 2, th = H >> 2, tw = W >> 2;
-  const int64_t T = (int64_t)B * th * tw;
-  const int TL = NT / cq;
-  const int cqi = threadIdx.x % cq, tl = threadIdx.x / cq;
-  const int c4 = cqi * 4;
-  const int64_t t0 = (int64_t)blockIdx.x * tiles_per_block;
-  const int64_t t1 = (t0 + tiles_per_block < T) ? t0 + tiles_per_block : T;
-  const f32x4 mu = *reinterpret_cast<const f32x4*>(emean + c4), rs = *reinterpret_cast<const f32x4*>(erstd + c4);
-  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  for (int64_t tile = t0 + tl; tile < t1; tile += TL) {
-    const int tj = (int)(tile % tw), ti = (int)((tile / tw) % th), b = (int)(tile / ((int64_t)tw * th));
-    f32x4 P[4][4];
-    wino4_adjoint_block(dV, T, C, th, tw, tile, c4, P);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const size_t off = (((size_t)b * H + 4 * ti + a) * W + 4 * tj) * C + c4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        f32x4 v = P[a][e];
-        if (res) v += *reinterpret_cast<const f32x4*>(res + off + (size_t)e * C);
-        *reinterpret_cast<f32x4*>(dx + off + (size_t)e * C) = v;
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(ex + off + (size_t)e * C);
-        if (ey) {
-          const f32x4 yv = *reinterpret_cast<const f32x4*>(ey + off + (size_t)e * C);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = yv[q] > 0.0f ? v[q] : 0.0f;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {   // the arithmetic of col_partial_kernel<1>, element for element
-          const float xh = (xv[q] - mu[q]) * rs[q];
-          s1[q] += (double)v[q];
-          s2[q] += (double)v[q] * (double)xh;
-        }
-      }
-    }
-  }
-  __shared__ double red[2][NT][4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { red[0][threadIdx.x][q] = s1[q]; red[1][threadIdx.x][q] = s2[q]; }
-  __syncthreads();
-  if (tl == 0) {
-    for (int k = 1; k < TL; ++k)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { s1[q] += red[0][k * cq + cqi][q]; s2[q] += red[1][k * cq + cqi][q]; }
-    double* p = partials + (size_t)blockIdx.x * 2 * C;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { p[c4 + q] = s1[q]; p[C + c4 + q] = s2[q]; }
-  }
-}
-
 // dw[co][3][3][ci] = G^T dU[:, co, ci] G;  dU is [36][Co][Ci]
 __global__ __launch_bounds__(NT) void wino4_wgrad_out_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Co, int Ci) {
   const int64_t n = (int64_t)Co * Ci;
@@ -659,6 +667,15 @@ extern "C" int mmfn_wino_input_f32(const float* x, float* V, int B, int H, int W
   return 0;
 }
 
+extern "C" int mmfn_wino_input_bn_f32(const float* x, const float* res, const float* mean, const float* rstd, const float* weight,
+                                      const float* bias, int relu, float* y, float* V, int B, int H, int W, int C, void* stream) {
+  if (!x || !V || !mean || !rstd || !weight || !bias || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
+  hipLaunchKernelGGL(wino4_input_bn_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0, (hipStream_t)stream, x,
+                     res, mean, rstd, weight, bias, relu, y, V, B, H, W, C);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmfn_wino_output_f32(const float* Mt, const float* res, float* y, int B, int H, int W, int C, int m,
                                     void* stream) {
   if (!Mt || !y || (m != 2 && m != 4) || (H % m) || (W % m) || (C & 3) || B <= 0) return MMFN_EINVAL;
@@ -683,11 +700,11 @@ extern "C" int mmfn_wino_outgrad_f32(const float* dy, float* dMt, int B, int H, 
 }
 
 extern "C" int mmfn_wino_outgrad_bn_f32(const float* g, const float* y, const float* x, const float* mean, const float* rstd,
-                                        const float* weight, const float* means, float* ge_out, float* dMt, int B, int H, int W,
-                                        int C, void* stream) {
+                                        const float* weight, const float* relu_bias, const float* means, float* ge_out, float* dMt,
+                                        int B, int H, int W, int C, void* stream) {
   if (!g || !x || !mean || !rstd || !weight || !means || !dMt || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
   hipLaunchKernelGGL(wino4_outgrad_bn_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
-                     g, y, x, mean, rstd, weight, means, ge_out, dMt, B, H, W, C);
+                     g, y, x, mean, rstd, weight, relu_bias, means, ge_out, dMt, B, H, W, C);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
@@ -696,27 +713,6 @@ extern "C" int mmfn_wino_input_adjoint_f32(const float* dV, const float* res, fl
   if (!dV || !dx || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
   hipLaunchKernelGGL(wino4_input_adjoint_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0,
                      (hipStream_t)stream, dV, res, dx, B, H, W, C);
-  MMFN_LAUNCH_CHECK();
-  return 0;
-}
-
-extern "C" int mmfn_wino_input_adjoint_emit_rows(int B, int H, int W, int C) {
-  const int cq = C / 4;
-  if (B <= 0 || (H & 3) || (W & 3) || (C & 3) || cq > NT || NT % cq) return 0;
-  const int64_t T = (int64_t)B * (H / 4) * (W / 4);
-  const int TL = NT / cq;
-  const int tpb = (int)std::max<int64_t>(TL, (T + 511) / 512);
-  return (int)((T + tpb - 1) / tpb);
-}
-
-extern "C" int mmfn_wino_input_adjoint_emit_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, const float* ey,
-                                                const float* ex, const float* emean, const float* erstd, double* partials, void* stream) {
-  const int rows = mmfn_wino_input_adjoint_emit_rows(B, H, W, C);
-  if (!dV || !dx || !ex || !emean || !erstd || !partials || rows <= 0) return MMFN_EINVAL;
-  const int64_t T = (int64_t)B * (H / 4) * (W / 4);
-  const int tpb = (int)((T + rows - 1) / rows);
-  hipLaunchKernelGGL(wino4_input_adjoint_emit_kernel, dim3(rows), dim3(NT), 0, (hipStream_t)stream, dV, res, dx, B, H, W, C, ey, ex, emean,
-                     erstd, partials, std::max(tpb, NT / (C / 4)));
   MMFN_LAUNCH_CHECK();
   return 0;
 }

@@ -127,12 +127,53 @@ class Ctx(object):
 
 
 # ----------------------------------------------------------------------------- conv + BN
-FUSE_BN_BWD_APPLY = os.environ.get("MMFN_FUSE_BN_BWD", "1") == "1"   # A/B switch, see ConvBN.bwd
 FUSE_BN_BWD_REDUCE = os.environ.get("MMFN_FUSE_BN_REDUCE", "1") == "1"   # A/B switch, see ConvBN.bwd16 (bf16 mode)
-# fp32: the same reductions out of the Winograd adjoint transform (mmfn_wino_input_adjoint_emit_f32).  55 col_partial launches
-# less per step, but the adjoint launch with the reduction (256 VGPRs, <= 512 blocks walking their tiles serially) gives the time
-# back: 941 / 951 / 948 against 955 / 947 / 956 samples/s interleaved.  Off; a tested option.
-FUSE_BN_BWD_REDUCE32 = os.environ.get("MMFN_FUSE_BN_REDUCE32", "0") == "1"
+# fp32: a BatchNorm apply (+ residual + ReLU) whose consumer is an F(4x4) Winograd convolution runs inside that convolution's input
+# transform (PendingBN).  A/B switch; 0 = every BatchNorm apply is its own launch (the round-3 step).
+LAZY_BN_APPLY = os.environ.get("MMFN_LAZY_BN", "1") == "1"
+
+
+class PendingBN(object):
+    """The output of a ConvBN whose BatchNorm apply (+ residual) (+ ReLU) has not run: the convolution output and the batch
+    statistics are in HBM, the activation y = [relu](bn(co) [+ res]) is not.  Two ways out:
+      * consume(...) by an F(4x4) Winograd convolution - the apply runs inside its input transform (ops.conv2d_winograd(x_bn=...),
+        csrc/winograd.hip wino4_input_bn_kernel); with want_y the transform also writes y (a block output, which the next
+        block's skip connection and the backward's ReLU mask read), otherwise y never exists and the producer's backward
+        recomputes the ReLU sign from co;
+      * tensor(ctx): the plain apply launch (any other consumer: pooling, token kernels, a strided convolution)."""
+
+    def __init__(self, owner, co, res, relu):
+        self.owner, self.co, self.res, self.relu = owner, co, res, relu
+        self.shape, self.dtype = co.shape, co.dtype
+        self.y = None
+
+    def _out(self, ctx):
+        return ctx.bufs.get(self.owner.name + ".out", self.shape)
+
+    def tensor(self, ctx):
+        if self.y is None:
+            o = self.owner
+            M = self.co.numel() // o.cout
+            self.y = self._out(ctx)
+            ops.bn_apply(self.co.view(M, o.cout), self.y.view(M, o.cout), o.saved[3], o.saved[4], o.bn_w, o.bn_b, self.relu,
+                         res=None if self.res is None else self.res.view(M, o.cout))
+            o.saved[2] = self.y
+        return self.y
+
+    def consume(self, ctx, want_y):
+        """-> the x_bn tuple of ops.conv2d_winograd; afterwards self.y is the written activation (want_y) or stays None."""
+        o = self.owner
+        if want_y and self.y is None:
+            self.y = self._out(ctx)
+            o.saved[2] = self.y
+            y_out = self.y
+        else:
+            y_out = None
+        return (self.res, o.saved[3], o.saved[4], o.bn_w, o.bn_b, self.relu, y_out)
+
+
+def as_tensor(ctx, x):
+    return x.tensor(ctx) if isinstance(x, PendingBN) else x
 
 
 class ConvBN(object):
@@ -268,9 +309,26 @@ class ConvBN(object):
             emit._pre = (extra["stats"], ops16.gemm_stats_rows(ops16.G16_CONV_DGRAD, Mx, cin, g_[6] * g_[7] * g_[5], g_))
         return dx
 
-    def fwd(self, ctx, x, relu=True, res=None):
+    def fwd(self, ctx, x, relu=True, res=None, lazy=False, want_x=True):
+        """x: an NHWC tensor or the PendingBN of the producing ConvBN.  lazy: return a PendingBN instead of applying the BatchNorm
+        (the caller hands it to the next convolution, or calls .tensor()).  want_x (x pending): the producer's activation is
+        needed as a tensor as well (it is a block output)."""
         if ctx.bf16:
-            return self.fwd16(ctx, x, relu, res)
+            return self.fwd16(ctx, as_tensor(ctx, x), relu, res)
+        x_bn = None
+        if isinstance(x, PendingBN):
+            # the producer's BatchNorm apply inside this convolution's input transform: F(4x4) forward, and - when training - a
+            # backward that never reads x (transformed input kept, adjoint data gradient)
+            wshape, xs = self.w.shape, x.shape
+            ok = LAZY_BN_APPLY and not ctx.folded and ops.winograd_f4_ok(xs, wshape, self.stride, self.pad) and x.y is None
+            if ok and ctx.training:
+                ok = ops.winograd_wgrad_ok(xs, wshape, self.stride, self.pad) and ops.winograd_adjoint_ok(xs, wshape, self.stride, self.pad)
+            if ok:
+                pend = x
+                x_bn = pend.consume(ctx, want_x)
+                x = pend.co      # what the transform reads; same shape as the activation
+            else:
+                x = x.tensor(ctx)
         B = x.shape[0]
         _, oshape = ops.conv_geom(x.shape, self.w.shape, self.stride, self.pad)
         co = ctx.bufs.get(self.name + ".conv", oshape)
@@ -285,6 +343,7 @@ class ConvBN(object):
                 keep_u = ctx.wino_u(self.name, self.w)
         M = oshape[0] * oshape[1] * oshape[2]
         if not ctx.training and ctx.folded:
+            assert x_bn is None
             # eval with BatchNorm folded into the filter (Engine.fold_batchnorm): convolution + shift + skip + ReLU in ONE launch,
             # as a direct implicit GEMM (at batch 1 the Winograd form - transform, 36-batch GEMM, transform - measured slower: 4.99 vs
             # 4.59 ms per tick)
@@ -308,17 +367,20 @@ class ConvBN(object):
         elif ctx.training:
             ops.conv2d_fwd_bn_stats(x, self.w, self.stride, self.pad, co, mean, rstd, self.bn.running_mean, self.bn.running_var,
                                     self.bn.num_batches_tracked, self.bn.eps, self.bn.momentum, keep_v=keep_v, keep_u=keep_u,
-                                    u_ready=keep_u is not None and ctx.wino_in_table(self.name))
+                                    u_ready=keep_u is not None and ctx.wino_in_table(self.name), x_bn=x_bn)
         else:
-            ops.conv2d_fwd(x, self.w, self.stride, self.pad, out=co)
+            ops.conv2d_fwd(x, self.w, self.stride, self.pad, out=co, x_bn=x_bn)
             ops.bn_eval_prepare(self.bn.running_mean, self.bn.running_var, mean, rstd, self.bn.eps)
-        y = ctx.bufs.get(self.name + ".out", oshape)
-        ops.bn_apply(co2, y.view(M, self.cout), mean, rstd, self.bn_w, self.bn_b, relu,
-                     res=None if res is None else res.view(M, self.cout))
-        self.saved = (x, co, y, mean, rstd, relu)
+        # saved[0]: the input - with x_bn the producer's convolution output stands in: only its SHAPE is read by the backward
+        # (the Winograd weight gradient uses the kept transformed input); saved[2]: the activation, None until / unless written
+        self.saved = [x, co, None, mean, rstd, relu]
         self.saved_v = keep_v
         self.saved_u = keep_u
-        return y
+        self.x_is_standin = x_bn is not None
+        pend = PendingBN(self, co, res, relu)
+        if lazy and LAZY_BN_APPLY:
+            return pend
+        return pend.tensor(ctx)
 
     def bwd(self, ctx, g, need_dx=True, ge_out=None, dx_res=None, mask_y=None, emit=None):
         """g: dL/dy.  ge_out receives the ReLU-masked g (the residual branch's gradient).
@@ -330,40 +392,30 @@ class ConvBN(object):
         x, co, y, mean, rstd, relu = self.saved
         M = co.numel() // self.cout
         dco = ctx.bufs.get(self.name + ".dconv", co.shape)
-        ymask = None
+        ymask = relu_bias = None
         if relu:
-            ymask = (y if mask_y is None else mask_y).view(M, self.cout)
+            ym = y if mask_y is None else mask_y
+            if ym is not None:
+                ymask = ym.view(M, self.cout)
+            else:
+                # the forward applied this BatchNorm + ReLU inside the next convolution's input transform and never wrote its
+                # output (PendingBN): the backward kernels recompute the sign of bn(co) from co
+                relu_bias = self.bn_b
         u = getattr(self, "saved_u", None)
-        if need_dx and u is not None and FUSE_BN_BWD_APPLY:
+        if need_dx and u is not None:
             # weight and data gradient together in the Winograd domain (shared A dy A^T), and dy = the BatchNorm backward of g
             # is formed inside that transform: only the two reductions run as kernels of their own, dy never goes to HBM
             means = ctx.bufs.get(self.name + ".bnmeans", (2, self.cout))
-            pre, self._pre32 = getattr(self, "_pre32", None), None
-            if pre is not None and mask_y is None:
-                # the consumer's adjoint transform already summed (ge, ge * xhat) per block while it was storing g
-                ops.bn_bwd_reduce_partials(pre[0], pre[1], M, self.cout, self.g_bn_w, self.g_bn_b, means)
-            else:
-                ops.bn_bwd_reduce(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.g_bn_w, self.g_bn_b, means)
+            ops.bn_bwd_reduce(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.g_bn_w, self.g_bn_b, means,
+                              relu_wb=None if relu_bias is None else (self.bn_w, relu_bias))
             dx = ctx.bufs.get(self.name + ".dx", x.shape)
-            em = None
-            if emit is not None and FUSE_BN_BWD_REDUCE32 and getattr(emit, "saved_u", None) is not None and emit.saved[1].dtype == torch.float32 \
-                    and tuple(emit.saved[1].shape) == tuple(x.shape):
-                # dx IS the gradient entering `emit`'s BatchNorm (emit produced x): its two reductions come out of this launch
-                _, eco, ey, emean, erstd, erelu = emit.saved
-                rows = ops.wino_adjoint_emit_rows(x.shape)
-                if rows > 0:
-                    part = ctx.bufs.get(emit.name + ".bnpart32", (rows, 2, x.shape[-1]), torch.float64)
-                    em = (ey if erelu else None, eco, emean, erstd, part)
-                    emit._pre32 = (part, rows)
             ops.conv2d_bwd_winograd(dco, x, u, self.gw, dx, v=getattr(self, "saved_v", None), res=dx_res,
-                                    bn=(g, None if ymask is None else ymask.view(g.shape), co, mean, rstd, self.bn_w, means, ge_out), emit=em)
+                                    bn=(g, None if ymask is None else ymask.view(g.shape), co, mean, rstd, self.bn_w, relu_bias, means,
+                                        ge_out))
             return dx
+        assert not getattr(self, "x_is_standin", False), "%s: the direct backward needs the input activation" % self.name
         ops.bn_bwd(g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.bn_w, dco.view(M, self.cout),
-                   self.g_bn_w, self.g_bn_b, ge_out=None if ge_out is None else ge_out.view(M, self.cout))
-        if need_dx and u is not None:   # weight and data gradient together in the Winograd domain (shared A dy A^T)
-            dx = ctx.bufs.get(self.name + ".dx", x.shape)
-            ops.conv2d_bwd_winograd(dco, x, u, self.gw, dx, v=getattr(self, "saved_v", None), res=dx_res)
-            return dx
+                   self.g_bn_w, self.g_bn_b, ge_out=None if ge_out is None else ge_out.view(M, self.cout), relu_bias=relu_bias)
         if self.is_stem() and not need_dx:
             self.stem_wgrad(ctx, dco)
             return None
@@ -391,9 +443,14 @@ class BasicBlock(object):
                                mod.downsample[1], s, 0)
 
     def fwd(self, ctx, x):
-        y1 = self.c1.fwd(ctx, x, relu=True)
+        """x: tensor, or the PendingBN of the previous block's output.  Returns the PendingBN of this block's output (fp32 path;
+        the bf16 mode applies every BatchNorm eagerly): the first BatchNorm + ReLU is applied inside the second convolution's
+        input transform and its output is never written; the second BatchNorm + skip + ReLU inside the NEXT block's first
+        convolution, which also writes the block output (its own skip connection reads it)."""
+        y1 = self.c1.fwd(ctx, x, relu=True, lazy=True, want_x=True)
+        x = as_tensor(ctx, x)     # written by c1's input transform if it was pending, else by the apply launch
         skip = x if self.down is None else self.down.fwd(ctx, x, relu=False)
-        return self.c2.fwd(ctx, y1, relu=True, res=skip)
+        return self.c2.fwd(ctx, y1, relu=True, res=skip, lazy=True, want_x=False)
 
     def bwd(self, ctx, g, mask_y=None, emit=None):
         """emit: the ConvBN (the previous block's second convolution) whose BatchNorm this block's input gradient enters."""
@@ -443,7 +500,7 @@ class ResNetTrunk(object):
     def layer_fwd(self, ctx, li, x):
         for blk in self.layers[li]:
             x = blk.fwd(ctx, x)
-        return x
+        return as_tensor(ctx, x)
 
     def layer_bwd(self, ctx, li, g, mask_y=None):
         blocks = self.layers[li]

@@ -436,7 +436,9 @@ def winograd_v_numel(x_shape):
     return 36 * B * (H // 4) * (W // 4) * C
 
 
-WINOGRAD_BN_FUSED = os.environ.get("MMFN_WINOGRAD_BN_FUSED", "1") == "1"
+def winograd_f4_ok(x_shape, w_shape, stride, pad):
+    """The F(4x4,3x3) form of the forward (what the fused BatchNorm-apply input transform exists for)."""
+    return winograd_ok(x_shape, w_shape, stride, pad, {}) and WINOGRAD_F4 and x_shape[1] % 4 == 0 and x_shape[2] % 4 == 0
 
 
 def wino_weight_group(table, n_layers, total):
@@ -456,10 +458,13 @@ def make_wino_group_table(pairs, device):
     return t, len(pairs), start
 
 
-def conv2d_winograd(x, w, out, res=None, m=None, keep_v=None, bn=None, keep_u=None, u_ready=False):
+def conv2d_winograd(x, w, out, res=None, m=None, keep_v=None, bn=None, keep_u=None, u_ready=False, x_bn=None):
     """3x3 stride-1 'same' convolution as Winograd F(m x m, 3x3): streaming transforms around one (m+2)^2-batch GEMM.
     m = 4 when the image size allows (4x fewer MFMA FLOPs), else 2.  keep_v (F(4x4) only): a per-layer buffer that
-    receives the transformed input, so the weight gradient can reuse it instead of transforming x again."""
+    receives the transformed input, so the weight gradient can reuse it instead of transforming x again.
+    x_bn = (res or None, mean, rstd, weight, bias, relu, y_out or None) (F(4x4) only): x is the PRODUCER's convolution output and
+    the convolution's input is [relu](bn(x) [+ res]), applied inside the input transform (mmfn_wino_input_bn_f32); y_out also
+    receives that activation as a tensor."""
     B, H, W, Ci = x.shape
     Co = w.shape[0]
     if m is None:
@@ -479,7 +484,13 @@ def conv2d_winograd(x, w, out, res=None, m=None, keep_v=None, bn=None, keep_u=No
                    4.0 * (B * H * W * (Ci + Co) + 9 * Co * Ci), 2.0 * n * T * Co * Ci):
         if not (u_ready and keep_u is not None and m == 4):   # u_ready: this layer's U was written by wino_weight_group
             _call("mmfn_wino_weight_f32", ptr(w), ptr(U), Co, Ci, m, st)
-        _call("mmfn_wino_input_f32", ptr(x), ptr(V), B, H, W, Ci, m, st)
+        if x_bn is not None:
+            assert m == 4
+            xres, xmean, xrstd, xw, xb, xrelu, y_out = x_bn
+            _call("mmfn_wino_input_bn_f32", ptr(x), ptr(xres), ptr(xmean), ptr(xrstd), ptr(xw), ptr(xb), 1 if xrelu else 0, ptr(y_out),
+                  ptr(V), B, H, W, Ci, st)
+        else:
+            _call("mmfn_wino_input_f32", ptr(x), ptr(V), B, H, W, Ci, m, st)
         gemm(V, U, Mt, T, Co, Ci, Ci, Ci, Co, A_ROWMAJOR, B_NK, batch=n, strideA=T * Ci, strideB=Co * Ci, strideC=T * Co)
         if bn is not None and m == 4 and res is None and 256 % (Co // 4) == 0:
             # BatchNorm batch statistics come out of the output transform; only the tiny finalize kernel remains
@@ -495,29 +506,32 @@ def conv2d_winograd(x, w, out, res=None, m=None, keep_v=None, bn=None, keep_u=No
 
 
 def conv2d_fwd_bn_stats(x, w, stride, pad, out, mean, rstd, running_mean, running_var, nbt, eps, momentum, keep_v=None, keep_u=None,
-                        u_ready=False):
+                        u_ready=False, x_bn=None):
     """Training-mode conv followed by the BatchNorm batch statistics of its output (model_vec.py:509-593: every conv of the
-    trunks is followed by a BatchNorm2d).  On the Winograd path the statistics are a by-product of the output transform."""
-    if WINOGRAD_BN_FUSED and winograd_ok(x.shape, w.shape, stride, pad, {}):
-        _, fused = conv2d_winograd(x, w, out, keep_v=keep_v, keep_u=keep_u, u_ready=u_ready,
+    trunks is followed by a BatchNorm2d).  On the Winograd path the statistics are a by-product of the output transform.
+    x_bn: see conv2d_winograd (the caller checked winograd_f4_ok)."""
+    if winograd_ok(x.shape, w.shape, stride, pad, {}):
+        _, fused = conv2d_winograd(x, w, out, keep_v=keep_v, keep_u=keep_u, u_ready=u_ready, x_bn=x_bn,
                                    bn=(mean, rstd, running_mean, running_var, nbt, eps, momentum))
         if fused:
             return out
     else:
+        assert x_bn is None
         conv2d_fwd(x, w, stride, pad, out=out, keep_v=keep_v, keep_u=keep_u, u_ready=u_ready)
     M = out.numel() // out.shape[-1]
     bn_train_stats(out.view(M, out.shape[-1]), mean, rstd, running_mean, running_var, nbt, eps, momentum)
     return out
 
 
-def conv2d_fwd(x, w, stride, pad, out=None, keep_v=None, keep_u=None, u_ready=False, **epi):
-    """y[B,OH,OW,Cout] = conv(x[B,H,W,Cin], w[Cout,KH,KW,Cin])."""
+def conv2d_fwd(x, w, stride, pad, out=None, keep_v=None, keep_u=None, u_ready=False, x_bn=None, **epi):
+    """y[B,OH,OW,Cout] = conv(x[B,H,W,Cin], w[Cout,KH,KW,Cin]).  x_bn: see conv2d_winograd (the caller checked winograd_f4_ok)."""
     g, oshape = conv_geom(x.shape, w.shape, stride, pad)
     if out is None:
         out = torch.empty(oshape, dtype=torch.float32, device=x.device)
     if winograd_ok(x.shape, w.shape, stride, pad, epi):
         assert epi.get("ldr", oshape[3]) == oshape[3]
-        return conv2d_winograd(x, w, out, res=epi.get("res"), keep_v=keep_v, keep_u=keep_u, u_ready=u_ready)
+        return conv2d_winograd(x, w, out, res=epi.get("res"), keep_v=keep_v, keep_u=keep_u, u_ready=u_ready, x_bn=x_bn)
+    assert x_bn is None
     B, OH, OW, Cout = oshape
     K = g[6] * g[7] * g[2]
     return gemm(x, w, out, B * OH * OW, Cout, K, 0, K, Cout, A_IM2COL, B_NK, conv=g, **epi)
@@ -592,9 +606,9 @@ def _wgrad_winograd_body(dy, x, out, v, B, H, W, Ci, Co, T, dU, V, dMt, st, bn=N
     else:
         _call("mmfn_wino_input_f32", ptr(x), ptr(V), B, H, W, Ci, 4, st)
     if bn is not None:
-        g, ymask, co, mean, rstd, weight, means, ge_out = bn
-        _call("mmfn_wino_outgrad_bn_f32", ptr(g), ptr(ymask), ptr(co), ptr(mean), ptr(rstd), ptr(weight), ptr(means), ptr(ge_out),
-              ptr(dMt), B, H, W, Co, st)
+        g, ymask, co, mean, rstd, weight, relu_bias, means, ge_out = bn
+        _call("mmfn_wino_outgrad_bn_f32", ptr(g), ptr(ymask), ptr(co), ptr(mean), ptr(rstd), ptr(weight), ptr(relu_bias), ptr(means),
+              ptr(ge_out), ptr(dMt), B, H, W, Co, st)
     else:
         _call("mmfn_wino_outgrad_f32", ptr(dy), ptr(dMt), B, H, W, Co, st)
     gemm(dMt, V, dU, Co, Ci, T, Co, Ci, Ci, A_COLMAJOR, B_KN, batch=36, strideA=T * Co, strideB=T * Ci, strideC=Co * Ci)
@@ -610,22 +624,16 @@ def winograd_adjoint_ok(x_shape, w_shape, stride, pad):
     return WINOGRAD_ADJOINT_DGRAD and winograd_wgrad_ok(x_shape, w_shape, stride, pad)
 
 
-def wino_adjoint_emit_rows(x_shape):
-    B, H, W, C = x_shape
-    return lib().mmfn_wino_input_adjoint_emit_rows(B, H, W, C)
-
-
-def conv2d_bwd_winograd(dy, x, u, dw_out, dx_out, v=None, res=None, bn=None, emit=None):
+def conv2d_bwd_winograd(dy, x, u, dw_out, dx_out, v=None, res=None, bn=None):
     """Weight AND data gradient of a 3x3 stride-1 'same' convolution in the F(4x4,3x3) domain, sharing the transformed
     output gradient dM = A dy A^T:
         dw = G^T [ sum_tiles dM^T . V ] G          (V = B^T x B, kept by the forward or recomputed)
         dx = overlap-add( B (dM . U) B^T ) (+ res)  (U = G w G^T, kept by the forward: the ADJOINT of the forward pipeline,
                                                      no flipped filter, no second filter / input transform)
-    bn = (g, ymask or None, conv_out, mean, rstd, weight, means, ge_out or None), all NHWC / [C]: dy is then the BatchNorm backward
-    of g (reductions already done by bn_bwd_reduce) formed on the fly inside the transform; the `dy` argument only gives the shape.
-    emit = (ey or None, ex, emean, erstd, partials [rows, 2, Ci] float64): dx enters the BatchNorm (+ ReLU, mask ey) that produced x
-    from ex; the adjoint transform then also writes that BatchNorm backward's two reductions as per-block partial sums
-    (wino_adjoint_emit_rows(x.shape) rows; finished by bn_bwd_reduce_partials)."""
+    bn = (g, ymask or None, conv_out, mean, rstd, weight, relu_bias or None, means, ge_out or None), all NHWC / [C]: dy is then the
+    BatchNorm backward of g (reductions already done by bn_bwd_reduce) formed on the fly inside the transform; the `dy` argument
+    only gives the shape.  relu_bias (with ymask None): the ReLU mask is recomputed from conv_out (bn_bwd).
+    x: the convolution's input, or - with v given - anything carrying its .shape."""
     B, H, W, Ci = x.shape
     Co = dy.shape[3]
     T = B * (H // 4) * (W // 4)
@@ -642,13 +650,7 @@ def conv2d_bwd_winograd(dy, x, u, dw_out, dx_out, v=None, res=None, bn=None, emi
         dV = Vs  # the scratch V region is free again: with a kept V it was never used, otherwise the wgrad GEMM is done with it
         gemm(dMt, u.view(-1)[:36 * Co * Ci], dV, T, Ci, Co, Co, Ci, Ci, A_ROWMAJOR, B_KN, batch=36, strideA=T * Co, strideB=Co * Ci,
              strideC=T * Ci)
-        if emit is None:
-            _call("mmfn_wino_input_adjoint_f32", ptr(dV), ptr(res), ptr(dx_out), B, H, W, Ci, st)
-        else:
-            ey, ex, emean, erstd, part = emit
-            assert part.dtype == torch.float64 and part.numel() >= wino_adjoint_emit_rows(x.shape) * 2 * Ci and ex.shape == x.shape
-            _call("mmfn_wino_input_adjoint_emit_f32", ptr(dV), ptr(res), ptr(dx_out), B, H, W, Ci, ptr(ey), ptr(ex), ptr(emean), ptr(erstd),
-                  ptr(part), st)
+        _call("mmfn_wino_input_adjoint_f32", ptr(dV), ptr(res), ptr(dx_out), B, H, W, Ci, st)
     return dw_out, dx_out
 
 
@@ -739,7 +741,9 @@ def bn_apply(x2d, y2d, mean, rstd, weight, bias, relu, res=None):
     return y2d
 
 
-def bn_bwd(g2d, y2d, x2d, mean, rstd, weight, dx, dweight, dbias, ge_out=None):
+def bn_bwd(g2d, y2d, x2d, mean, rstd, weight, dx, dweight, dbias, ge_out=None, relu_bias=None):
+    """relu_bias (the BatchNorm's bias) with y2d None: the ReLU mask is recomputed from x2d - the forward applied this BatchNorm
+    inside its consumer's Winograd input transform and never wrote y (conv2d_winograd(x_bn=...))."""
     M, C = x2d.shape
     if g2d.dtype != BF16 and (x2d.dtype == BF16 or (y2d is not None and y2d.dtype == BF16)):
         raise TypeError("bn_bwd: fp32 output gradient with bf16 activations (every activation-side tensor of the bf16 mode is bf16)")
@@ -748,23 +752,18 @@ def bn_bwd(g2d, y2d, x2d, mean, rstd, weight, dx, dweight, dbias, ge_out=None):
         _call("mmfn_bn_bwd_bf16", ptr(g2d), ptr(y2d), ptr(x2d), 0 if x2d.dtype == BF16 else 1, M, C, ptr(mean), ptr(rstd), ptr(weight),
               ptr(dx), ptr(ge_out), ptr(dweight), ptr(dbias), ptr(norm_workspace(x2d.device)), stream())
         return dx
-    _call("mmfn_bn_bwd_f32", ptr(g2d), ptr(y2d), ptr(x2d), M, C, ptr(mean), ptr(rstd), ptr(weight), ptr(dx), ptr(ge_out),
-          ptr(dweight), ptr(dbias), ptr(norm_workspace(x2d.device)), stream())
+    _call("mmfn_bn_bwd_f32", ptr(g2d), ptr(y2d), ptr(x2d), M, C, ptr(mean), ptr(rstd), ptr(weight), ptr(relu_bias), ptr(dx),
+          ptr(ge_out), ptr(dweight), ptr(dbias), ptr(norm_workspace(x2d.device)), stream())
     return dx
 
 
-def bn_bwd_reduce(g2d, y2d, x2d, mean, rstd, dweight, dbias, means):
+def bn_bwd_reduce(g2d, y2d, x2d, mean, rstd, dweight, dbias, means, relu_wb=None):
     """The reductions of bn_bwd only (dweight, dbias, means[2][C]); conv2d_bwd_winograd(bn=...) applies them inside its
-    output-gradient transform."""
+    output-gradient transform.  relu_wb = (weight, bias) with y2d None: the recomputed ReLU mask (bn_bwd)."""
     M, C = x2d.shape
-    _call("mmfn_bn_bwd_reduce_f32", ptr(g2d), ptr(y2d), ptr(x2d), M, C, ptr(mean), ptr(rstd), ptr(dweight), ptr(dbias), ptr(means),
-          ptr(norm_workspace(x2d.device)), stream())
-    return means
-
-
-def bn_bwd_reduce_partials(partials, rows, M, C, dweight, dbias, means):
-    """bn_bwd_reduce from per-block partial sums another launch left behind (conv2d_bwd_winograd(emit=...))."""
-    _call("mmfn_bn_bwd_reduce_partials_f32", ptr(partials), rows, M, C, ptr(dweight), ptr(dbias), ptr(means), stream())
+    rw, rb = relu_wb if relu_wb is not None else (None, None)
+    _call("mmfn_bn_bwd_reduce_f32", ptr(g2d), ptr(y2d), ptr(x2d), M, C, ptr(mean), ptr(rstd), ptr(rw), ptr(rb), ptr(dweight),
+          ptr(dbias), ptr(means), ptr(norm_workspace(x2d.device)), stream())
     return means
 
 

@@ -1,0 +1,80 @@
+"""Gradient yardsticks shared by tests/test_parity_benchsize_gpu.py and tools/grad_cosine.py (TEST INFRASTRUCTURE: nothing
+under mmfn_amd/ imports this).
+
+The backward of phase2_train_net.py:104-108 (`loss.backward()` through 85 train-mode BatchNorms) amplifies fp32 rounding, so a
+HIP gradient is judged against an fp64 evaluation of the oracle's graph, with the fp32 oracle's own distance to fp64 as the
+yardstick, per backward stage (mmfn_amd.params.FlatLayout.stage_of: 0 = fusion scale 4 ... 3 = layer1 + stems + VectorNet)."""
+import copy
+
+import torch
+
+from . import harness
+
+
+def to64(a):
+    if torch.is_tensor(a):
+        return a.double() if a.is_floating_point() else a
+    if isinstance(a, (list, tuple)):
+        return type(a)(to64(x) for x in a)
+    return a
+
+
+def stage_of(name):
+    """Same rule as mmfn_amd.params.FlatLayout.stage_of (restated here so the checker does not import the product)."""
+    for s, (gpt, layer) in enumerate((("transformer4", "layer4"), ("transformer3", "layer3"), ("transformer2", "layer2"))):
+        if gpt in name or layer in name:
+            return s
+    if name.startswith(("join.", "decoder.", "output.")) or "radar_encoder" in name:
+        return 0
+    return 3
+
+
+def oracle_gradients(oracle, args, gt_wp):
+    """-> (loss32, grads32, loss64, grads64, pred32) of one train-mode step of `oracle` (weights untouched: the AdamW step of
+    harness.train_step is applied to copies)."""
+    o64 = copy.deepcopy(oracle).double()
+    _, loss64, g64 = harness.train_step(o64, to64(args), gt_wp.double())
+    del o64
+    o32 = copy.deepcopy(oracle)
+    pred32, loss32, g32 = harness.train_step(o32, args, gt_wp)
+    return loss32, g32, loss64, g64, pred32
+
+
+def stage_cosines(hip_grads, g32, g64, group=stage_of):
+    """{stage: (cos(HIP, fp64), cos(CPU fp32, fp64))} over all tensors of a stage taken together."""
+    acc = {}
+    for name, t in g64.items():
+        if t is None:
+            continue
+        st = group(name)
+        a, b, c = hip_grads[name].detach().cpu().double().flatten(), t.flatten(), g32[name].double().flatten()
+        d = acc.setdefault(st, [0.0] * 5)
+        d[0] += float(torch.dot(a, b)); d[1] += float(torch.dot(a, a)); d[2] += float(torch.dot(b, b))
+        d[3] += float(torch.dot(c, b)); d[4] += float(torch.dot(c, c))
+    return {st: (d[0] / max((d[1] * d[2]) ** 0.5, 1e-300), d[3] / max((d[4] * d[2]) ** 0.5, 1e-300)) for st, d in sorted(acc.items())}
+
+
+def tensor_rows(hip_grads, g32, g64):
+    """[(stage, name, |f64|, rel err HIP, rel err CPU fp32, cos HIP, cos CPU fp32)] for every non-zero gradient tensor."""
+    rows = []
+    for name, t in g64.items():
+        if t is None:
+            continue
+        b = t.flatten()
+        n = b.norm().item()
+        if n == 0.0:
+            continue
+        a, c = hip_grads[name].detach().cpu().double().flatten(), g32[name].double().flatten()
+        cos = lambda u: float(torch.dot(u, b) / max(u.norm().item() * n, 1e-300))
+        rows.append((stage_of(name), name, n, (a - b).norm().item() / n, (c - b).norm().item() / n, cos(a), cos(c)))
+    return rows
+
+
+def stage_bar(cos_cpu):
+    """The bar a HIP stage cosine has to clear, given the fp32 oracle's cosine on the same stage (round-3 review, item 2):
+    at most twice the oracle's angle^2 away from the fp64 direction (1 - cos ~ angle^2 / 2), and never below 0.99 where
+    the oracle itself reaches 0.995."""
+    bar = 1.0 - 2.0 * (1.0 - cos_cpu) - 1e-6
+    if cos_cpu >= 0.995:
+        bar = max(bar, 0.99)
+    return bar

@@ -207,7 +207,7 @@ def test_winograd_backward_with_fused_batchnorm_backward(relu):
     dbw_b, dbb_b = torch.empty(Cout, device=dev), torch.empty(Cout, device=dev)
     ops.bn_bwd_reduce(g.view(M, Cout), ymask, co.view(M, Cout), mean, rstd, dbw_b, dbb_b, means)
     dw_b, dx_b, ge_b = torch.empty_like(w), torch.empty_like(x), torch.empty_like(g)
-    ops.conv2d_bwd_winograd(dco, x, u, dw_b, dx_b, v=v, bn=(g, None if ymask is None else y, co, mean, rstd, bn_w, means, ge_b))
+    ops.conv2d_bwd_winograd(dco, x, u, dw_b, dx_b, v=v, bn=(g, None if ymask is None else y, co, mean, rstd, bn_w, None, means, ge_b))
     assert torch.equal(dbw_a, dbw_b) and torch.equal(dbb_a, dbb_b) and torch.equal(ge_a, ge_b)
     for a, b in ((dx_a, dx_b), (dw_a, dw_b)):
         assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item()   # fma contraction may differ between the two kernels

@@ -236,40 +236,74 @@ def test_tokens_and_upsample_with_several_frames(S, C, frames):
         _close(o.permute(0, 3, 1, 2), f.grad, 1e-6)
 
 
-@pytest.mark.parametrize("B,H,W,C,relu,with_res", [(2, 16, 16, 64, True, True), (3, 8, 8, 256, True, False), (1, 32, 32, 128, False, True),
-                                                    (2, 8, 8, 512, True, True)])
-def test_winograd_adjoint_emits_the_batchnorm_backward_reductions(B, H, W, C, relu, with_res):
-    """mmfn_wino_input_adjoint_emit_f32: the data gradient of the plain launch, bit for bit, plus per-block (sum ge, sum ge * xhat)
-    whose finished form equals mmfn_bn_bwd_reduce_f32 run on the stored gradient."""
+@pytest.mark.parametrize("B,H,W,C,relu,with_res,want_y", [(2, 16, 16, 64, True, False, False), (2, 16, 16, 64, True, True, True),
+                                                         (3, 8, 8, 512, True, True, True), (1, 64, 64, 64, True, False, False),
+                                                         (2, 32, 32, 128, False, True, True), (2, 8, 8, 256, False, False, False)])
+def test_winograd_input_transform_applies_the_producers_batchnorm(B, H, W, C, relu, with_res, want_y):
+    """mmfn_wino_input_bn_f32 (BatchNorm apply + residual + ReLU of the producing layer inside the consumer's F(4x4) input
+    transform, model_vec.py:509-593 BasicBlock chain) == mmfn_bn_apply_f32 followed by mmfn_wino_input_f32, BIT FOR BIT: the
+    transformed input, and the activation tensor when it is requested; nothing is written when it is not."""
     from mmfn_amd import ops
     from mmfn_amd.ops import _call, ptr, stream
     g = _g(B * H + C)
-    T = B * (H // 4) * (W // 4)
     M = B * H * W
-    dV = torch.randn(36, T, C, generator=g).to(DEV)
+    co = (torch.randn(B, H, W, C, generator=g) * 2 + 0.3).to(DEV)
     res = torch.randn(B, H, W, C, generator=g).to(DEV) if with_res else None
-    ey = torch.randn(B, H, W, C, generator=g).to(DEV)
-    ex = (torch.randn(B, H, W, C, generator=g) * 2 + 0.5).to(DEV)
-    mean, rstd = (torch.randn(C, generator=g) * 0.3).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
-    dx1, dx2 = torch.empty(B, H, W, C, device=DEV), torch.empty(B, H, W, C, device=DEV)
-    _call("mmfn_wino_input_adjoint_f32", ptr(dV), ptr(res), ptr(dx1), B, H, W, C, stream())
-    rows = ops.wino_adjoint_emit_rows((B, H, W, C))
-    assert 0 < rows <= 512
-    part = torch.full((rows, 2, C), float("nan"), dtype=torch.float64, device=DEV)
-    _call("mmfn_wino_input_adjoint_emit_f32", ptr(dV), ptr(res), ptr(dx2), B, H, W, C, ptr(ey if relu else None), ptr(ex), ptr(mean),
-          ptr(rstd), ptr(part), stream())
-    assert torch.equal(dx1, dx2)
-    dw1, db1, m1 = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2, C, device=DEV)
-    dw2, db2, m2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2, C, device=DEV)
-    ops.bn_bwd_reduce(dx1.view(M, C), ey.view(M, C) if relu else None, ex.view(M, C), mean, rstd, dw1, db1, m1)
-    ops.bn_bwd_reduce_partials(part, rows, M, C, dw2, db2, m2)
-    ge = dx1.double() * ((ey > 0).double() if relu else 1.0)
-    xh = (ex.double() - mean.double()) * rstd.double()
-    ref_b, ref_w = ge.sum(dim=(0, 1, 2)), (ge * xh).sum(dim=(0, 1, 2))
-    for got, ref in ((db2, ref_b), (dw2, ref_w), (m2[0], ref_b / M), (m2[1], ref_w / M)):
-        assert torch.allclose(got.double(), ref, rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
-    for a_, b_ in ((dw1, dw2), (db1, db2), (m1, m2)):
-        assert torch.allclose(a_, b_, rtol=1e-5, atol=1e-6 * float(a_.abs().max()))
+    mean, rstd = (torch.randn(C, generator=g) * 0.2).to(DEV), (torch.rand(C, generator=g) + 0.5).to(DEV)
+    w, b = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    y_ref = ops.bn_apply(co.view(M, C), torch.empty(M, C, device=DEV), mean, rstd, w, b, relu, res=None if res is None else res.view(M, C))
+    T = B * (H // 4) * (W // 4)
+    V_ref = torch.empty(36 * T * C, device=DEV)
+    _call("mmfn_wino_input_f32", ptr(y_ref), ptr(V_ref), B, H, W, C, 4, stream())
+    V = torch.full((36 * T * C,), float("nan"), device=DEV)
+    y = torch.full((M, C), float("nan"), device=DEV) if want_y else None
+    _call("mmfn_wino_input_bn_f32", ptr(co), ptr(res), ptr(mean), ptr(rstd), ptr(w), ptr(b), 1 if relu else 0, ptr(y), ptr(V), B, H, W, C,
+          stream())
+    assert torch.equal(V, V_ref)
+    if want_y:
+        assert torch.equal(y, y_ref)
+    # against torch: relu(bn(x) + res) then the same transform through the convolution it feeds
+    ref = (co - mean) * rstd * w + b
+    if res is not None:
+        ref = ref + res
+    if relu:
+        ref = torch.relu(ref)
+    _close(y_ref.view(B, H, W, C), ref.cpu(), 1e-5, "bn apply")
+
+
+@pytest.mark.parametrize("M,C,HW", [(2 * 16 * 16, 64, 16), (3 * 8 * 8, 512, 8), (2 * 32 * 32, 128, 32)])
+def test_batchnorm_backward_recomputes_the_relu_mask_of_an_unwritten_output(M, C, HW):
+    """The backward kernels of a BatchNorm + ReLU whose output never reached HBM (applied inside the next convolution's input
+    transform): the mask recomputed from the convolution output (relu_bias / relu_wb) gives bit-identical results to the mask read
+    from the written activation - reductions, the apply pass, and the Winograd output-gradient transform."""
+    from mmfn_amd import ops
+    from mmfn_amd.ops import _call, ptr, stream
+    g = _g(M + C + 1)
+    x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(DEV)
+    w, b = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    mean, rstd = x.mean(0), (x.var(0, unbiased=False) + 1e-5).rsqrt()
+    gy = torch.randn(M, C, generator=g).to(DEV)
+    y = ops.bn_apply(x, torch.empty_like(x), mean, rstd, w, b, True)
+    assert 0.2 < (y > 0).float().mean().item() < 0.8
+    outs = []
+    for ymask, rb in ((y, None), (None, b)):
+        dx, ge = torch.empty_like(x), torch.empty_like(x)
+        dw, db = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        ops.bn_bwd(gy, ymask, x, mean, rstd, w, dx, dw, db, ge_out=ge, relu_bias=rb)
+        dw2, db2, means = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2, C, device=DEV)
+        ops.bn_bwd_reduce(gy, ymask, x, mean, rstd, dw2, db2, means, relu_wb=None if rb is None else (w, rb))
+        B = M // (HW * HW)
+        dMt = torch.empty(36 * B * (HW // 4) * (HW // 4) * C, device=DEV)
+        ge2 = torch.empty_like(x)
+        _call("mmfn_wino_outgrad_bn_f32", ptr(gy), ptr(ymask), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(rb), ptr(means), ptr(ge2), ptr(dMt),
+              B, HW, HW, C, stream())
+        outs.append((dx, ge, dw, db, dw2, db2, means, dMt, ge2))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+    # and without either the mask is NOT applied (a caller that forgets relu_bias would silently train a different network)
+    dxn = torch.empty_like(x)
+    ops.bn_bwd(gy, None, x, mean, rstd, w, dxn, torch.empty(C, device=DEV), torch.empty(C, device=DEV))
+    assert not torch.equal(dxn, outs[0][0])
 
 
 def test_gap_and_transpose():
