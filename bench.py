@@ -371,6 +371,7 @@ def main():
     ap.add_argument("--no-oracle-check", action="store_true", help="skip the loss_vs_oracle block (one CPU oracle forward)")
     ap.add_argument("--single-stream", action="store_true", help="disable encoder-branch concurrency (profiling runs)")
     ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps for the roofline block")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-operation table of the roofline block's instrumented steps to stderr")
     ap.add_argument("--no-also", action="store_true",
                     help="default one-GPU run only: do not append the bf16 training mode's record (`also.bf16`, a second bench process "
                          "after the fp32 line's timed region)")
@@ -628,7 +629,7 @@ def main():
         if tfiles and default_workload:  # PMC-derived HBM bytes per launch of this kernel family (tools/profile_round.sh)
             rec = json.load(open(tfiles[-1]))
             traffic, traffic_src = round(rec["hbm_bytes_per_launch"]), os.path.basename(tfiles[-1])
-        if os.environ.get("MMFN_BENCH_BREAKDOWN"):
+        if args.breakdown:
             rows = sorted(prof.by_tag().items(), key=lambda kv: -kv[1][2])
             for tag, (n, fl, t) in rows[:60]:
                 sys.stderr.write("%-46s n=%3d  %8.3f ms  %7.2f TF/s\n" % (tag, n, t, fl / (t * 1e-3) / 1e12 if t > 0 else 0))

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
     return;
   }
   // Interior tile with the common epilogue operations (bias, ReLU, ReLU-backward mask, dropout, residual, final ReLU): the same
-  // per-lane pointers; the flags are read once per tile instead of once per element, ReLU is a max against 0 or -inf.
+  // per-lane pointers; the flags are read once per tile instead of once per element.
   if (!dgp && !to_slab && m0 + BM <= d.M && n0 + BN <= d.N && !(d.flags & (MMFN_EPI_GELU | MMFN_EPI_ACCUM))) {
     const int f = d.flags;
     const size_t lrow = (size_t)(m0 + wm * TM * 32 + 4 * h);
@@ -730,7 +730,9 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
     float* p0 = d.C + lrow * d.ldc + lcol;
     const float* r0 = (f & MMFN_EPI_RESIDUAL) ? d.res + lrow * d.ldr + lcol : nullptr;
     const float* a0 = (f & MMFN_EPI_MASK_AUX) ? d.aux + lrow * d.ldaux + lcol : nullptr;
-    const float floor1 = (f & MMFN_EPI_RELU) ? 0.0f : -INFINITY, floor2 = (f & MMFN_EPI_RELU_LAST) ? 0.0f : -INFINITY;
+    // wave-uniform branches, NOT a max against -inf when the flag is off: v_max_f32 returns the non-NaN operand, so a NaN
+    // accumulator would leave an interior tile as -inf while the edge tiles' general path (epilogue_store) keeps it NaN
+    const bool relu1 = (f & MMFN_EPI_RELU) != 0, relu2 = (f & MMFN_EPI_RELU_LAST) != 0;
     const bool drop = (f & MMFN_EPI_DROPOUT) != 0;
     const float inv_keep = drop ? 1.0f / (1.0f - d.drop_p) : 1.0f;
 #pragma unroll
@@ -741,12 +743,14 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-          float v = fmaxf(acc[i][q][r] + bias, floor1);
+          float v = acc[i][q][r] + bias;
+          if (relu1) v = fmaxf(v, 0.0f);
           if (a0) v = a0[(size_t)dr * d.ldaux + q * 32] > 0.0f ? v : 0.0f;
           if (drop)
             v *= mmfn_dropout_scale(key, (uint64_t)(lrow + dr) * (uint64_t)d.N + (uint64_t)(lcol + q * 32), d.drop_p, inv_keep);
           if (r0) v += r0[(size_t)dr * d.ldr + q * 32];
-          p0[(size_t)dr * d.ldc + q * 32] = fmaxf(v, floor2);
+          if (relu2) v = fmaxf(v, 0.0f);
+          p0[(size_t)dr * d.ldc + q * 32] = v;
         }
       }
     return;

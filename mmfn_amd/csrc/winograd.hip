@@ -213,6 +213,9 @@ __global__ __launch_bounds__(NT) void wino4_input_kernel(const float* __restrict
 // HBM.  y != NULL: the activation is needed as a tensor as well (the block output: the next block's skip connection); every
 // tile then writes the 4x4 interior of its 6x6 patch, which tiles the image exactly.  y == NULL: it is never written; the
 // backward recomputes the ReLU sign from x (col_partial_kernel / wino4_outgrad_bn_kernel, zmask).
+// Loads are unconditional (coordinates clamped into the image, the padding ring selected to 0 afterwards): a branch around each
+// pixel would serialise the 36 (72 with a residual) loads of a thread.  The 16 interior pixels of a patch are always inside.
+template <bool HAS_RES, bool WRITE_Y>
 __global__ __launch_bounds__(NT) void wino4_input_bn_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             const float* __restrict__ bw, const float* __restrict__ bb, int relu,
@@ -226,27 +229,33 @@ __global__ __launch_bounds__(NT) void wino4_input_bn_kernel(const float* __restr
     f32x4 al, be;
 #pragma unroll
     for (int e = 0; e < 4; ++e) { al[e] = mmfn_bn_alpha(bw[c4 + e], rstd[c4 + e]); be[e] = mmfn_bn_beta(bb[c4 + e], mean[c4 + e], al[e]); }
+    const size_t img = (size_t)b * H * W;
     f32x4 r[6][6];
 #pragma unroll
     for (int e = 0; e < 6; ++e) {
       const int xx = 4 * j - 1 + e;
+      const bool okx = (e >= 1 && e <= 4) || (unsigned)xx < (unsigned)W;
+      const int xc = okx ? xx : (xx < 0 ? 0 : W - 1);
       f32x4 d[6], c[6];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         const int yy = 4 * ii - 1 + a;
-        const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        if (ok) {
-          const size_t off = (((size_t)b * H + yy) * W + xx) * C + c4;
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+        const bool oky = (a >= 1 && a <= 4) || (unsigned)yy < (unsigned)H;
+        const int yc = oky ? yy : (yy < 0 ? 0 : H - 1);
+        const size_t off = (img + (size_t)yc * W + xc) * C + c4;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+        f32x4 o;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = mmfn_bn_affine(xv[q], al[q], be[q]);
-          if (res) o += *reinterpret_cast<const f32x4*>(res + off);
-          if (relu) {   // fmaxf, as bn_apply_kernel
+        for (int q = 0; q < 4; ++q) o[q] = mmfn_bn_affine(xv[q], al[q], be[q]);
+        if (HAS_RES) o += *reinterpret_cast<const f32x4*>(res + off);
+        if (relu) {   // fmaxf, as bn_apply_kernel
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = fmaxf(o[q], 0.0f);
-          }
-          if (y && a >= 1 && a <= 4 && e >= 1 && e <= 4) *reinterpret_cast<f32x4*>(y + off) = o;
+          for (int q = 0; q < 4; ++q) o[q] = fmaxf(o[q], 0.0f);
+        }
+        if (a >= 1 && a <= 4 && e >= 1 && e <= 4) {
+          if (WRITE_Y) *reinterpret_cast<f32x4*>(y + off) = o;
+        } else if (!(okx && oky)) {
+          o = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         d[a] = o;
       }
@@ -670,8 +679,13 @@ extern "C" int mmfn_wino_input_f32(const float* x, float* V, int B, int H, int W
 extern "C" int mmfn_wino_input_bn_f32(const float* x, const float* res, const float* mean, const float* rstd, const float* weight,
                                       const float* bias, int relu, float* y, float* V, int B, int H, int W, int C, void* stream) {
   if (!x || !V || !mean || !rstd || !weight || !bias || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
-  hipLaunchKernelGGL(wino4_input_bn_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0, (hipStream_t)stream, x,
-                     res, mean, rstd, weight, bias, relu, y, V, B, H, W, C);
+  const dim3 grid(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4)));
+#define MMFN_WINO_IN_BN(R, Y)                                                                                                        \
+  hipLaunchKernelGGL((wino4_input_bn_kernel<R, Y>), grid, dim3(NT), 0, (hipStream_t)stream, x, res, mean, rstd, weight, bias, relu, y, V, \
+                     B, H, W, C)
+  if (res) { if (y) MMFN_WINO_IN_BN(true, true); else MMFN_WINO_IN_BN(true, false); }
+  else     { if (y) MMFN_WINO_IN_BN(false, true); else MMFN_WINO_IN_BN(false, false); }
+#undef MMFN_WINO_IN_BN
   MMFN_LAUNCH_CHECK();
   return 0;
 }

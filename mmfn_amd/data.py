@@ -396,6 +396,11 @@ def stage_raw_batch(data, device, config, variant="vec", non_blocking=True):
     dataloader.py:233 is requested from the splat kernel."""
     dev = torch.device(device)
     to = lambda t, dt=None: torch.as_tensor(t).to(dt or torch.as_tensor(t).dtype).to(dev, non_blocking=non_blocking)
+    if variant != "img" and config.seq_len > 1:
+        # with several frames per sample the ego frame is the LAST one (waypoints, target point, sweeps moved into it); lanes and
+        # radar below are frame 0's.  The vector-map / radar models cannot run seq_len > 1 anyway (Engine.__init__, as the
+        # reference: model_vec.py:226) - refuse here too instead of pairing frame-0 lanes with last-frame labels
+        raise NotImplementedError("raw batches with seq_len > 1 exist for the image-map model only (variant 'img')")
     lane, lane_num, _ = data["vectormaps"][0]
     rgb, pts = to(data["rgb_u8"]), to(data["lidar_pts"])
     if rgb.dim() == 5:   # seq_len > 1: a sample's frames become consecutive batch entries (model_vec.py:506-508)

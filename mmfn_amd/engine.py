@@ -81,19 +81,11 @@ class Ctx(object):
         enqueued so far on the current stream.  Inline when no side stream is configured."""
         if self.side is None:
             return fn()
-        rec = self.recorder()
-        if rec is not None:
-            return rec.side(self.side, fn, lane_id=1)   # its own linear graph, exact eager dependencies (graphs.Recorder.side)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.side.wait_event(ev)
         with torch.cuda.stream(self.side), ops.lane(1):
             fn()
-
-    def recorder(self):
-        """The lane-graph recorder while a split capture is running, else None."""
-        rec = self.engine._recorder if self.engine is not None else None
-        return rec if (rec is not None and rec.split_lanes) else None
 
     def fork_point(self):
         """An event at the current point of the current stream, for offload_at()."""
@@ -118,16 +110,13 @@ class Ctx(object):
         """Current stream waits for all offloaded work (before its input buffers are reused)."""
         if self.side is None:
             return
-        rec = self.recorder()
-        if rec is not None:
-            return rec.join(self.side)
         ev = torch.cuda.Event()
         ev.record(self.side)
         torch.cuda.current_stream().wait_event(ev)
 
 
 # ----------------------------------------------------------------------------- conv + BN
-FUSE_BN_BWD_REDUCE = os.environ.get("MMFN_FUSE_BN_REDUCE", "1") == "1"   # A/B switch, see ConvBN.bwd16 (bf16 mode)
+FUSE_BN_BWD_REDUCE = True   # see ConvBN.bwd16 (bf16 mode)
 # fp32: a BatchNorm apply (+ residual + ReLU) whose consumer is an F(4x4) Winograd convolution runs inside that convolution's input
 # transform (PendingBN).  A/B switch; 0 = every BatchNorm apply is its own launch (the round-3 step).
 LAZY_BN_APPLY = os.environ.get("MMFN_LAZY_BN", "1") == "1"
@@ -519,7 +508,7 @@ class Linear(object):
         self.w16 = self.w16t = None   # bf16 shadows [out, in] / [in, out] (Engine._build_shadows, bf16 mode)
 
 
-DEFER_LN_REDUCTIONS = os.environ.get("MMFN_DEFER_LN", "1") == "1"   # A/B switch, see LayerNorm.bwd
+DEFER_LN_REDUCTIONS = True   # see LayerNorm.bwd
 
 
 class LayerNorm(object):
@@ -563,30 +552,6 @@ class LayerNorm(object):
 
 
 # ----------------------------------------------------------------------------- GPT fusion transformer
-GPT_LATE_FORK = os.environ.get("MMFN_GPT_LATE_FORK", "1") == "1"   # A/B: see Ctx.offload_at
-GPT_FORK_EACH = os.environ.get("MMFN_GPT_FORK_EACH", "0") == "1"   # A/B: fork every piece of side work where it arises (round-2a behaviour)
-
-
-class _ForkEach(list):
-    """list stand-in whose append() forks the closure to the side stream immediately."""
-
-    def __init__(self, ctx):
-        list.__init__(self)
-        self.ctx = ctx
-
-    def append(self, fn):
-        self.ctx.offload(fn)
-
-
-# AdamW per readiness group under the backward (Engine.backward_and_step).  OFF: measured slower than the single launch after the
-# backward - 1685-1690 vs 1745-1755 samples/s in the bf16 mode, 934 vs 951 in fp32 (and 1520 / 855 with the fork attached before
-# the writing stream's next kernel) - for any grid size of the per-group launches: the 17 extra branches of the replayed graph
-# cost more than the 0.5-0.6 ms of optimizer they hide.  Kept as a tested option (bit-identical results).
-OVERLAP_ADAMW = os.environ.get("MMFN_OVERLAP_ADAMW", "0") == "1"
-GPT_GROUP_MIN_C = int(os.environ.get("MMFN_GPT_GROUP_MIN_C", "0"))
-GPT_GROUP_MAX_C = int(os.environ.get("MMFN_GPT_GROUP_MAX_C", "0"))   # widest transformer whose weight gradients run as batched launches
-
-
 class GPT(object):
     """model_vec.py:136-246 (GPT), :112-133 (Block), :73-109 (SelfAttention)."""
 
@@ -617,25 +582,6 @@ class GPT(object):
             blk["bqkv"], blk["g_bqkv"] = layout.packed(bp + ".attn.key.bias", 3 * C)
             self.blocks.append(blk)
         self.ln_f = LayerNorm(name + ".ln_f", layout, prefix + ".ln_f")
-        # The eight blocks are laid out one after the other in the flat buffer, every block with the same tensors: block i's
-        # gradient of any tensor is block 0's + i * stride.  That lets ONE batched launch write the same weight gradient of
-        # all blocks (bwd, `grouped`).
-        self.block_stride = None
-        if len(self.blocks) > 1:
-            keys = [("fc1", "gw"), ("fc1", "gb"), ("fc2", "gw"), ("proj", "gw")]
-            def off(blk, k):
-                t = getattr(blk[k[0]], k[1])
-                return t.data_ptr()
-            strides = set()
-            for k in keys:
-                for i in range(1, len(self.blocks)):
-                    strides.add((off(self.blocks[i], k) - off(self.blocks[i - 1], k)) // 4)
-            for i in range(1, len(self.blocks)):
-                strides.add((self.blocks[i]["g_wqkv"].data_ptr() - self.blocks[i - 1]["g_wqkv"].data_ptr()) // 4)
-                strides.add((self.blocks[i]["g_bqkv"].data_ptr() - self.blocks[i - 1]["g_bqkv"].data_ptr()) // 4)
-            if len(strides) == 1:
-                self.block_stride = strides.pop()
-        self.grouped = self.block_stride is not None and GPT_GROUP_MIN_C <= self.C <= GPT_GROUP_MAX_C
 
     def fwd(self, ctx, feats, velocity):
         B = velocity.shape[0]
@@ -653,7 +599,7 @@ class GPT(object):
         self.acts = []
         scale = 1.0 / math.sqrt(hs)
         nb = len(self.blocks)
-        # the activations the weight gradients read again, stacked over the blocks (one batched launch per weight in bwd)
+        # the activations the weight gradients read again, one slab per block (the side stream may lag by several blocks)
         S_a, S_a2 = bufs.get(nm + ".S.a", (nb, M, C), adt), bufs.get(nm + ".S.a2", (nb, M, C), adt)
         S_o, S_h = bufs.get(nm + ".S.att", (nb, M, C), adt), bufs.get(nm + ".S.h", (nb, M, 4 * C), adt)
         self.stacks = (S_a, S_a2, S_o, S_h)
@@ -692,7 +638,6 @@ class GPT(object):
         scale = 1.0 / math.sqrt(hs)
         nblk = len(self.blocks)
         drop = p_resid > 0.0
-        grouped = self.grouped and ctx.side is not None and not ctx.bf16
         # the LayerNorm backward that produces a block's incoming gradient also writes its dropped copy (the residual
         # dropouts of the forward sit in GEMM epilogues; their masks are re-applied here without an extra pass)
         sb_of = lambda i: self.stream_base + 1 + 3 * i
@@ -708,13 +653,12 @@ class GPT(object):
         GD2 = bufs.get(nm + ".S.gdrop2", (nblk, M, C), adt) if drop else None
         GH = bufs.get(nm + ".S.gh", (nblk, M, 4 * C), adt)
         DQKV = bufs.get(nm + ".S.dqkv", (nblk, M, 3 * C), adt)
-        # ... and its column sums, which are the bias gradient of the Linear that closes the residual branch (mlp.2 / attn.proj)
-        # Side work (everything that only feeds the optimizer) is collected and forked to the side stream ONCE per block: in a
-        # replayed graph every fork moves the continuation of the chain to another hardware queue, and each such hop costs
-        # 10-16 us of idle time (profiles/r02c_graph_timeline.txt) - with a fork per weight gradient and per LayerNorm
-        # reduction (7 per block) that was 0.3 ms per transformer.  Grouped transformers (C <= 256) do not fork at all: their
-        # side work runs as a handful of batched launches after the chain, and the whole backward is one linear graph.
-        side = _ForkEach(ctx) if GPT_FORK_EACH else []
+        # Side work - everything that only feeds the optimizer: weight / bias gradients, column sums, the LayerNorm row
+        # reductions - is collected per block and forked to the side stream ONCE per block, and the fork is captured AFTER the
+        # chain's next kernel (Ctx.offload_at): in a replayed graph every fork moves the continuation of the chain to another
+        # hardware queue, and each such hop costs 10-16 us of idle time (profiles/r02c_graph_timeline.txt) - with a fork per
+        # weight gradient and per LayerNorm reduction (7 per block) that was 0.3 ms per transformer.
+        side = []
         pending = None
         g = self.ln_f.bwd(ctx, g_y.view(M, C), out=G[nblk - 1], dropped=GD[nblk - 1] if drop else None, drop_p=p_resid,
                           rng_stream=sb_of(nblk - 1) + 2, colsum=self.blocks[nblk - 1]["fc2"].gb, defer=side)
@@ -722,17 +666,12 @@ class GPT(object):
             blk = self.blocks[i]
             sb = sb_of(i)
             x, a, qkv, o, lse, x1, a2, h = self.acts[i]
-            # Weight / bias gradients only feed the optimizer, so they go to the side stream (ctx.offload) while the dX chain
-            # continues: block by block for the wide transformer (its weight-gradient GEMMs are as big as the chain's), and
-            # for C <= 256 - where a block's 14 side launches of 8-11 us each outlast its chain - as ONE batched launch per
-            # weight over all blocks after the chain (below).
             # ---- MLP branch: x2 = x1 + drop(fc2(relu(fc1(ln2(x1)))))
             gp = GD[i] if drop else g
-            if not grouped:
-                side.append(lambda gp=gp, blk=blk, h=h: ops.linear_dw(gp, h, out=blk["fc2"].gw))   # fc2.gb: from the LayerNorm backward
+            side.append(lambda gp=gp, blk=blk, h=h: ops.linear_dw(gp, h, out=blk["fc2"].gw))   # fc2.gb: from the LayerNorm backward
             gh = GH[i]
             ghpart = None
-            if ctx.bf16 and not grouped:
+            if ctx.bf16:
                 # the column sums of gh (= mlp.0's bias gradient) come out of this GEMM's epilogue as partial rows
                 from . import ops16
                 ghpart = bufs.get("%s.b%d.ghpart" % (nm, i), (ops16.max_stats_rows(M), 2, 4 * C), torch.float64)
@@ -740,13 +679,13 @@ class GPT(object):
                 ghrows = ops16.gemm_stats_rows(ops16.G16_NT, M, 4 * C, C)
             else:
                 ops.linear_dx(gp, Wb(blk["fc2"]), out=gh, aux=h, ldaux=4 * C)
-            if pending is not None:
+            if pending is not None:   # the previous block's side work, now that this block's first chain kernel is captured
                 ctx.offload_at(pending[0], lambda work=pending[1]: [f() for f in work])
                 pending = None
-            if not grouped and ghpart is not None:
+            if ghpart is not None:
                 side.append(lambda gh=gh, blk=blk, a2=a2, p=ghpart, r=ghrows: (ops16.colsum_partials(p, r, 4 * C, blk["fc1"].gb),
                                                                                ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
-            elif not grouped:
+            else:
                 side.append(lambda gh=gh, blk=blk, a2=a2: (ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
             ga2 = bufs.get(nm + ".ga", (M, C), adt)
             ops.linear_dx(gh, Wb(blk["fc1"]), out=ga2)
@@ -754,44 +693,23 @@ class GPT(object):
                                 rng_stream=sb + 1, colsum=blk["proj"].gb, defer=side)
             # ---- attention branch: x1 = x + drop(proj(att(ln1(x))))
             gp = GD2[i] if drop else g1
-            if not grouped:
-                side.append(lambda gp=gp, blk=blk, o=o: ops.linear_dw(gp, o, out=blk["proj"].gw))   # proj.gb: from ln2's backward
+            side.append(lambda gp=gp, blk=blk, o=o: ops.linear_dw(gp, o, out=blk["proj"].gw))   # proj.gb: from ln2's backward
             go = bufs.get(nm + ".go", (M, C), adt)
             ops.linear_dx(gp, Wb(blk["proj"]), out=go)
             dqkv = DQKV[i]
             delta = bufs.get(nm + ".delta", (B, nh, T))
             ops.attention_bwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, go, C, lse, delta, dqkv[:, C:], dqkv, dqkv[:, 2 * C:],
                               3 * C, B, T, nh, hs, scale, drop_p=p_attn, rng_state=ctx.rng_state, rng_stream=sb)
-            if not grouped:
-                side.append(lambda dqkv=dqkv, blk=blk, a=a: (ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
+            side.append(lambda dqkv=dqkv, blk=blk, a=a: (ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
             ga = bufs.get(nm + ".ga2", (M, C), adt)
             ops.linear_dx(dqkv, blk["wqkv16t"] if ctx.bf16 else blk["wqkv"], out=ga)
             g = blk["ln1"].bwd(ctx, ga, dres=g1, out=G[i - 1] if i > 0 else bufs.get(nm + ".g_tok", (M, C), adt),
                                dropped=GD[i - 1] if (drop and i > 0) else None, drop_p=p_resid,
                                rng_stream=sb_of(i - 1) + 2, colsum=self.blocks[i - 1]["fc2"].gb if i > 0 else None, defer=side)
-            if not grouped and not GPT_FORK_EACH:   # this block's side work: one fork, behind everything the chain has enqueued so far
-                work, side = side, []
-                if GPT_LATE_FORK and ctx.recorder() is None:
-                    pending = (ctx.fork_point(), work)   # enqueued after the next block's first kernel (Ctx.offload_at)
-                else:
-                    ctx.offload(lambda work=work: [f() for f in work])
+            work, side = side, []
+            pending = (ctx.fork_point(), work)   # enqueued after the next block's first kernel (Ctx.offload_at)
         if pending is not None:
             ctx.offload_at(pending[0], lambda work=pending[1]: [f() for f in work])
-        if grouped:
-            S_a, S_a2, S_o, S_h = self.stacks
-            b0, st = self.blocks[0], self.block_stride
-
-            def all_blocks():
-                ops.linear_dw_batched(GD if drop else G, S_h, b0["fc2"].gw, st)
-                ops.colsum_batched(GH, b0["fc1"].gb, st)
-                ops.linear_dw_batched(GH, S_a2, b0["fc1"].gw, st)
-                ops.linear_dw_batched(GD2 if drop else G1, S_o, b0["proj"].gw, st)
-                ops.colsum_batched(DQKV, b0["g_bqkv"], st)
-                ops.linear_dw_batched(DQKV, S_a, b0["g_wqkv"], st)
-
-            all_blocks()
-            for f in side:     # the LayerNorm reductions (17 small launches)
-                f()
         ctx.rejoin()
         gtok = g.view(B, T, C)
         ops.tokens_bwd(gtok, self.velocity, self.g_pos.view(T, C), self.vel.gw.view(C), self.vel.gb, p_embd, ctx.rng_state,
@@ -1130,9 +1048,6 @@ def _in_precision(fn):
     return wrapped
 
 
-LANE_TAIL_ADJOINT = os.environ.get("MMFN_LANE_TAIL_ADJOINT", "1") == "1"   # A/B switch, see Engine.backward_scale
-
-
 class Engine(object):
     """Forward / backward / optimizer step of one MMFN replica on one GPU.
 
@@ -1202,7 +1117,7 @@ class Engine(object):
         # gaps; captured into the hipGraph this becomes a fork/join DAG.
         self.side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         self.multi_stream = True
-        self._recorder = None   # mmfn_amd.graphs.Recorder while a lane-graph capture is running
+        self._recorder = None   # mmfn_amd.graphs.Recorder while a capture is running
         self.folded = {}        # ConvBN name -> (BatchNorm-folded filter, shift), see fold_batchnorm()
         # "f32" (parity path) or "bf16": bf16 MFMA operands with fp32 accumulation for the Linear / Winograd GEMMs
         self.gemm_dtype = getattr(cfg, "gemm_dtype", "f32")
@@ -1215,13 +1130,8 @@ class Engine(object):
         self.opt_hyper = torch.zeros(16, 8, dtype=torch.float32, device=dev)
         self._hyper_host = None
         self._hyper_pinned, self._hyper_slot = None, 0
-        self.opt_stream = None    # stream of the per-group AdamW launches (backward_and_step)
-        self._opt_ranges = None   # readiness group -> (begin, end) of the flat buffer, once checked to tile [0, tail)
-        self._opt_done = set()
-        self._opt_pending = []
-        self._opt_ngroups = 1
         self.n_lanes = int(os.environ.get("MMFN_BRANCH_LANES", "3"))
-        self.offload_wgrad = os.environ.get("MMFN_OFFLOAD_WGRAD", "1") == "1"
+        self.offload_wgrad = True   # transformer weight / bias gradients on the side stream (worth 3.9 ms per step)
 
     # ------------------------------------------------------------------ bf16 weight shadows
     def _build_shadows(self):
@@ -1320,12 +1230,6 @@ class Engine(object):
         """Run fns[0] on the current stream and fns[1:] on the side streams, fork/join with events."""
         if not self.multi_stream:
             return [f() for f in fns]
-        rec = self._recorder
-        if rec is not None and rec.split_lanes:
-            # lane graphs (mmfn_amd.graphs): every lane becomes its own linear hipGraph, stitched with eager events
-            if self.n_lanes == 2:
-                return rec.branches([[fns[0]], (self.side[0], list(fns[1:]))])
-            return rec.branches([[fns[0]]] + [(self.side[i], [f]) for i, f in enumerate(fns[1:])])
         main = torch.cuda.current_stream()
         fork = torch.cuda.Event()
         fork.record(main)
@@ -1496,8 +1400,6 @@ class Engine(object):
             dF3 = ops.pool_bcast_add(G[3], gin, bufs.get("dF3.3", G[3].shape), base[3], 1)
             self.rad.bwd(ctx, dF3)
             self._ready(on_ready, 0, "head")
-        # inside lane graphs (graphs.Recorder split mode) a lane is a linear graph of its own: the hooks run after the join
-        in_lane_ok = not (self._recorder is not None and self._recorder.split_lanes)
         if s > 0:
             nxt = self.gpts[s - 1]
             gtok_next = bufs.get("gtok%d" % (s - 1), (B, nxt.T, nxt.C), ctx.adt)
@@ -1505,32 +1407,25 @@ class Engine(object):
             def stage(m):
                 d = ops.pool_bcast_add(G[m], gin, bufs.get("dF%d.%d" % (s, m), G[m].shape, G[m].dtype), base[m], frames[m])
                 g = trunks[m].layer_bwd(ctx, s + 1, d)
-                if in_lane_ok:
-                    self._ready(on_ready, st, names[m])
-                if LANE_TAIL_ADJOINT:
-                    # the adjoint of the next scale's upsample-add for this branch (its own 64 token rows of gtok) at the tail of
-                    # the lane, beside the other lanes, instead of three launches on the main stream ahead of the transformer
-                    ops.upsample_adj(g, gtok_next, base[m], frames[m])
+                self._ready(on_ready, st, names[m])
+                # the adjoint of the next scale's upsample-add for this branch (its own 64 token rows of gtok) at the tail of
+                # the lane, beside the other lanes, instead of three launches on the main stream ahead of the transformer
+                ops.upsample_adj(g, gtok_next, base[m], frames[m])
                 return g
 
             self._G = self._branches([lambda m=m: stage(m) for m in range(3)])
-            self._adj_done = LANE_TAIL_ADJOINT
-            if not in_lane_ok:
-                for m in range(3):
-                    self._ready(on_ready, st, names[m])
+            self._adj_done = True
             return
 
         def img_tail():
             d = ops.pool_bcast_add(G[0], gin, bufs.get("dF0.0", G[0].shape, G[0].dtype), base[0], frames[0])
             self.img.stem_bwd(ctx, self.img.layer_bwd(ctx, 1, d))
-            if in_lane_ok:
-                self._ready(on_ready, st, "img")
+            self._ready(on_ready, st, "img")
 
         def lid_tail():
             d = ops.pool_bcast_add(G[1], gin, bufs.get("dF0.1", G[1].shape, G[1].dtype), base[1], frames[1])
             self.lid.stem_bwd(ctx, self.lid.layer_bwd(ctx, 1, d))
-            if in_lane_ok:
-                self._ready(on_ready, st, "lid")
+            self._ready(on_ready, st, "lid")
 
         def map_tail():
             d = ops.pool_bcast_add(G[2], gin, bufs.get("dF0.2", G[2].shape, G[2].dtype), base[2], frames[2])
@@ -1538,13 +1433,9 @@ class Engine(object):
                 self.map.stem_bwd(ctx, self.map.layer_bwd(ctx, 1, d))
             else:
                 self.vec.bwd(ctx, d)
-            if in_lane_ok:
-                self._ready(on_ready, st, "map" if self.variant == "img" else "vec")
+            self._ready(on_ready, st, "map" if self.variant == "img" else "vec")
 
         self._branches([img_tail, lid_tail, map_tail])
-        if not in_lane_ok:
-            for grp in ("img", "lid", "map" if self.variant == "img" else "vec"):
-                self._ready(on_ready, st, grp)
 
     # ------------------------------------------------------------------ optimizer
     def set_param_groups(self, group_of):
@@ -1598,108 +1489,17 @@ class Engine(object):
         ops.adamw_groups(L.params, L.grads, L.exp_avg, L.exp_avg_sq, self.step_count, self.opt_hyper, len(groups),
                          group_of=self.opt_group_of if len(groups) > 1 else None, n=L.tail)
 
-    # ---- the optimizer of a fused step, range by range under the backward (option, see OVERLAP_ADAMW)
-    # AdamW is elementwise, and the gradients of a readiness group (params.FlatLayout.group_ranges) are final long before the
-    # backward ends - the deepest fusion transformer's 25 M parameters first.  With the option on, the step's AdamW is issued per
-    # group, on a stream of its own, once the group is reported complete (the same hook the data-parallel buckets use) instead of
-    # as one pass over 105 M parameters after the last backward kernel.  Data parallel on the C-ABI transport: a group's AdamW
-    # follows its all-reduce on the communication stream.  Same kernel, same operands per element: bit-identical results.
-    def overlapped_step_ok(self, dp=None):
-        if not OVERLAP_ADAMW or (self._recorder is not None and self._recorder.split_lanes):
-            return False
-        if dp is not None and dp.comm is None:
-            return False   # torch.distributed transport: the reductions complete on streams we do not own
-        if self._opt_ranges is None:
-            L = self.layout
-            spans = sorted(L.group_ranges.items(), key=lambda kv: kv[1][0])
-            pos, ok = 0, True
-            for _, (b, e) in spans:
-                e = min(e, L.tail)
-                ok = ok and b == pos and b % 4 == 0 and e % 4 == 0
-                pos = max(pos, e)
-            self._opt_ranges = {k: (b, min(e, L.tail)) for k, (b, e) in spans} if ok and pos == L.tail else {}
-        return bool(self._opt_ranges)
-
-    def _step_begin(self, lr, grad_scale, adam):
-        groups = self.hyper_rows(lr=lr, grad_scale=grad_scale, **adam)
-        self.set_hyper(groups)
-        self.module.weights_changed()
-        ops.step_advance(self.step_count)
-        self._opt_done = set()
-        self._opt_pending = []
-        self._opt_ngroups = len(groups)
-        if self.opt_stream is None:
-            self.opt_stream = torch.cuda.Stream(device=self.device)
-
-    def _step_range(self, key, on=None):
-        """AdamW over readiness group `key`, ordered after everything enqueued so far on the current stream (on=None: on the
-        optimizer stream) or simply enqueued on stream `on` (the communication stream, behind the group's all-reduce)."""
-        if key in self._opt_done or key not in self._opt_ranges:
-            return
-        self._opt_done.add(key)
-        b, e = self._opt_ranges[key]
-        if e <= b:
-            return
-        if on is not None:
-            self._adamw_span(b, e, on)
-            return
-        # The fork is issued one hook LATE: a captured graph keeps the first-captured child of a node on the node's hardware
-        # queue and moves later children to other queues (graphs.py), so the stream that wrote this group must capture its
-        # next kernel before the optimizer branch is attached to the same point - the event marks the point now, the wait on
-        # it (and the launch) follow at the next hook / at the end.
-        self._step_flush()
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self._opt_pending.append((b, e, ev))
-
-    def _adamw_span(self, b, e, st):
-        L = self.layout
-        with torch.cuda.stream(st):
-            ops.adamw_groups(L.params[b:e], L.grads[b:e], L.exp_avg[b:e], L.exp_avg_sq[b:e], self.step_count, self.opt_hyper,
-                             self._opt_ngroups, group_of=self.opt_group_of[b // 4:e // 4] if self._opt_ngroups > 1 else None, n=e - b)
-
-    def _step_flush(self):
-        for b, e, ev in self._opt_pending:
-            self.opt_stream.wait_event(ev)
-            self._adamw_span(b, e, self.opt_stream)
-        self._opt_pending = []
-
-    def _step_finish(self, on=None):
-        for key in sorted(self._opt_ranges, key=lambda k: self._opt_ranges[k][0]):   # groups this variant never reports
-            self._step_range(key, on=on)
-        if on is None:
-            self._step_flush()
-            done = torch.cuda.Event()
-            done.record(self.opt_stream)
-            torch.cuda.current_stream().wait_event(done)
-
     def backward_and_step(self, dp=None, lr=1e-4, **adam):
-        """Backward of the last training forward + AdamW (+ the gradient all-reduces of `dp`)."""
-        if not self.overlapped_step_ok(dp):
-            if dp is None:
-                self.backward()
-                self.optimizer_step(lr=lr, **adam)
-            else:
-                self.backward(on_ready=dp.reduce)
-                dp.finish()
-                self.optimizer_step(lr=lr, grad_scale=1.0 / dp.world, **adam)
-            return
+        """Backward of the last training forward + AdamW (+ the gradient all-reduces of `dp`, issued from the streams that
+        complete each readiness group while the backward is still running; the 1/world average is folded into AdamW)."""
         if dp is None:
-            self._step_begin(lr, 1.0, adam)
-            self.backward(on_ready=self._step_range)
-            self._step_finish()
+            self.backward()
+            self.optimizer_step(lr=lr, **adam)
             return
-        self._step_begin(lr, 1.0 / dp.world, adam)
-
-        def hook(key):
-            dp.reduce(key)                                  # all-reduce on the communication stream ...
-            self._step_range(key, on=dp.comm_stream)        # ... and the group's AdamW right behind it
-
-        self.backward(on_ready=hook)
-        for key in dp.group_order:
-            hook(key)
-        self._step_finish(on=dp.comm_stream)
-        dp.finish()                                         # the compute stream waits for the communication stream
+        dp.begin()
+        self.backward(on_ready=dp.reduce)
+        dp.finish()
+        self.optimizer_step(lr=lr, grad_scale=1.0 / dp.world, **adam)
 
     def train_step(self, inp, gt, lr=1e-4, dp=None, **adam):
         """zero-grad (implicit: every gradient is overwritten) + forward + L1 + backward + AdamW

@@ -26,7 +26,7 @@ _gemm_dtype = "f32"
 # operands pixel-major, transposed into k-contiguous LDS rows in registers) runs at 28-138 TF/s, slower than the fp32 Winograd-
 # domain weight gradient (and than the fp32 direct one at 64 channels), and fp32 weight gradients are the more accurate anyway.
 # MMFN_BF16_WGRAD=1 selects the bf16 kernel (kept for its tests and for a transpose-read rewrite).
-BF16_WGRAD = os.environ.get("MMFN_BF16_WGRAD", "0") == "1"
+BF16_WGRAD = False
 
 
 class precision(object):
@@ -427,7 +427,7 @@ def winograd_ok(x_shape, w_shape, stride, pad, epi, for_wgrad=False):
             and min(Ci, Co) >= WINOGRAD_MIN_CHANNELS and Ci % 16 == 0 and Co % 16 == 0 and set(epi) <= {"res", "ldr"})
 
 
-WINOGRAD_F4 = os.environ.get("MMFN_WINOGRAD_F4", "1") == "1"
+WINOGRAD_F4 = True   # F(4x4,3x3) wherever the image sides are multiples of 4 (tests flip it to reach the F(2x2) kernels)
 
 
 def winograd_v_numel(x_shape):
@@ -573,7 +573,7 @@ def conv2d_dgrad(dy, w, x_shape, stride, pad, out=None, **epi):
     return gemm(dy, w, out, B * H * W, Cin, K, 0, 0, Cin, A_DGRAD, B_DGRADW, conv=g, **epi)
 
 
-WINOGRAD_WGRAD = os.environ.get("MMFN_WINOGRAD_WGRAD", "1") == "1"
+WINOGRAD_WGRAD = True
 
 
 def winograd_wgrad_ok(x_shape, w_shape, stride, pad):
@@ -616,7 +616,7 @@ def _wgrad_winograd_body(dy, x, out, v, B, H, W, Ci, Co, T, dU, V, dMt, st, bn=N
     return out
 
 
-WINOGRAD_ADJOINT_DGRAD = os.environ.get("MMFN_WINOGRAD_ADJOINT", "1") == "1"
+WINOGRAD_ADJOINT_DGRAD = True
 
 
 def winograd_adjoint_ok(x_shape, w_shape, stride, pad):
@@ -824,25 +824,6 @@ def colsum(x2d, out, M=None, C=None, ld=None):
     return out
 
 
-def colsum_batched(x3d, out0, stride_out):
-    """out0 + z*stride_out <- column sums of x3d[z] for every z (x3d: [batch, M, C] contiguous); out0: the first entry's [C] view
-    of a buffer in which the entries are stride_out floats apart (bias gradients of a transformer's blocks in the flat buffer)."""
-    nb, M, C = x3d.shape
-    need = nb * lib().mmfn_colsum_workspace_bytes(M, C)
-    _call("mmfn_colsum_batched_f32", ptr(x3d), nb, M * C, M, C, C, ptr(out0), int(stride_out), ptr(norm_workspace(x3d.device, need)),
-          stream())
-
-
-def linear_dw_batched(dy3d, x3d, out0, stride_out, **epi):
-    """dw[z] = dy3d[z]^T @ x3d[z] for every z in one (split-K) launch; dy3d [batch, M, N], x3d [batch, M, K] contiguous,
-    out0 = entry 0's [N, K] view, the entries stride_out floats apart."""
-    nb, M, N = dy3d.shape
-    K = x3d.shape[2]
-    return gemm(dy3d, x3d, out0, N, K, M, N, K, out0.stride(0), A_COLMAJOR, B_KN, batch=nb, strideA=M * N, strideB=M * K,
-                strideC=int(stride_out), **epi)
-
-
-# ---------------------------------------------------------------- pooling / tokens / upsample
 def maxpool_fwd(x, y, idx):
     B, H, W, C = x.shape
     _call("mmfn_maxpool3x3s2_fwd_bf16" if x.dtype == BF16 else "mmfn_maxpool3x3s2_fwd_f32", ptr(x), ptr(y), ptr(idx), B, H, W, C, stream())
@@ -1104,7 +1085,7 @@ def shadow_transpose(table, n, total):
 
 
 # ---------------------------------------------------------------- 7x7 stems: explicit im2col + plain GEMM
-STEM_IM2COL = os.environ.get("MMFN_STEM_IM2COL", "1") == "1"   # A/B switch (engine.ConvBN stems)
+STEM_IM2COL = True   # the 7x7 stems as explicit im2col + plain GEMM (engine.ConvBN.stem_conv)
 
 
 def im2col_small(x, col, kh, kw, stride, pad):

@@ -99,6 +99,18 @@ class DataParallel(object):
         for b, e in chunks:
             self.pending.append(self.dist.all_reduce(g[b:e], op=self.dist.ReduceOp.SUM, async_op=True))
 
+    def begin(self):
+        """Start of a step's backward (Engine.backward_and_step, GraphedStep.__call__).  A step that raised between its first
+        reduce() and finish() - out of memory, a failed capture that the caller retries eagerly - must not leak into the next
+        one: groups still marked as reduced would be skipped (training on un-reduced gradients, or ranks issuing different
+        collective sequences and hanging).  Outstanding ProcessGroup work of such a step is completed first."""
+        if self.pending and self.comm is None:
+            for w in self.pending:
+                if w is not None:
+                    w.wait()
+        self.pending = []
+        self.reduced = set()
+
     def reduce(self, key):
         """Engine hook (Engine.backward(on_ready=...)): every gradient of readiness group `key` = (stage, name) has been
         enqueued on the current stream.  Every rank calls this in the same program order, so the collectives match up."""
@@ -158,10 +170,9 @@ class GraphedStep(object):
             RNG advance + forward + loss + head backward + backward of fusion scale 4   -> buckets of stage 0
             backward of scale 3 -> stage 1;  scale 2 -> stage 2;  scale 1 + stems + VectorNet -> stage 3, wait for all
             fused AdamW
-    MMFN_LANE_GRAPHS=1 additionally cuts wherever the engine forks into its branch lanes (graphs.py).
     An eager step is ~2200 Python-issued launches, which makes the host the bottleneck."""
 
-    def __init__(self, engine, dp, inp, gt, lr=1e-4, warm=2, lane_graphs=None, single_graph=None, **adam):
+    def __init__(self, engine, dp, inp, gt, lr=1e-4, warm=2, single_graph=None, **adam):
         from .graphs import Recorder
         self.engine, self.dp = engine, dp
         eng = engine
@@ -171,14 +182,11 @@ class GraphedStep(object):
         scale = 1.0 / (dp.world if dp is not None else 1)
         self.scale = scale
         eng.set_hyper(eng.hyper_rows(lr=lr, grad_scale=scale, **adam))  # the captured AdamW reads them from device memory
-        rec = self.recorder = Recorder(eng, split_lanes=lane_graphs)   # None: MMFN_LANE_GRAPHS decides (default: forks inside the graphs)
+        rec = self.recorder = Recorder(eng)
         if dp is not None:
             rec.extra_streams.append(dp.comm_stream)
-        if eng.opt_stream is None:
-            eng.opt_stream = torch.cuda.Stream(device=eng.device)
-        rec.extra_streams.append(eng.opt_stream)
         if single_graph is None:
-            single_graph = dp is not None and dp.comm is not None and not rec.split_lanes
+            single_graph = dp is not None and dp.comm is not None
         if single_graph and (dp is None or dp.comm is None):
             raise ValueError("a single-graph data-parallel step needs the C-ABI transport (DataParallel(comm=...))")
         self.single_graph = bool(single_graph) or dp is None
@@ -189,7 +197,7 @@ class GraphedStep(object):
             eng.forward(inp, True, gt)
             if dp is None or single_graph:
                 # single GPU, or collectives captured on the communication stream (forked from the stream that wrote each
-                # bucket, joined by finish()): no cut, one replay call per step; AdamW per readiness group under the backward
+                # bucket, joined by finish()): no cut, one replay call per step
                 eng.backward_and_step(dp, lr=lr, **adam)
                 return
             else:
@@ -212,6 +220,8 @@ class GraphedStep(object):
         self.engine.set_hyper(self.engine.hyper_rows(lr=lr, grad_scale=self.scale, **adam))
 
     def __call__(self):
+        if self.dp is not None and not self.single_graph:
+            self.dp.begin()   # (single graph: the bucket bookkeeping only ran at capture time)
         self.recorder.replay()
         self.engine.module.weights_changed()   # the replayed AdamW does not pass through Engine.optimizer_step
         return self.loss

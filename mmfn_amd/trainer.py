@@ -25,15 +25,18 @@ from . import ops
 from .parallel import StaticBatchStep, StaticEvalStep
 
 
-def _release(state):
-    """Free an evicted capture (hipGraph exec + its private pool + the static input copies): nothing may still be replaying
-    it, so wait for the device first; the "seen" / "eager" placeholders hold nothing."""
+def _evict_lru(cache):
+    """Drop the least recently used entry of a capture cache (dict in LRU order) and free it - hipGraph exec, its private
+    pool, the static input copies - HERE: nothing may still be replaying it, so wait for the device first.  The entry is popped
+    inside this function and never handed in as an argument: a caller's argument slot would keep the capture alive until this
+    call returned, i.e. past gc.collect() / drain_graveyard().  The "seen" / "eager" placeholders hold nothing."""
+    state = cache.pop(next(iter(cache)))
     if isinstance(state, str) or state is None:
         return
     import gc
     from . import graphs
     torch.cuda.synchronize()
-    del state
+    del state                  # the last reference: Graph.__del__ parks the capture in the graveyard now
     gc.collect()
     graphs.drain_graveyard()   # the capture's hipGraphExecs are destroyed here, with the device idle
 
@@ -91,7 +94,7 @@ class Trainer(object):
                         loss = eng.train_step(inp, gt, lr=lr, dp=dp, **adam) if state == "eager" else state(inp, gt, lr=lr, **adam)
                     self._static_steps[sig] = state  # re-inserted last: the dict is the LRU order
                     while len(self._static_steps) > self.max_captured_shapes:
-                        _release(self._static_steps.pop(next(iter(self._static_steps))))  # least recently used
+                        _evict_lru(self._static_steps)
                 else:
                     loss = eng.train_step(inp, gt, lr=lr, dp=dp, **adam)
             else:
@@ -149,7 +152,7 @@ class Trainer(object):
                         loss = eng.forward(inp, False, gt)[1] if state == "eager" else state(inp, gt)
                     self._static_evals[sig] = state
                     while len(self._static_evals) > self.max_captured_shapes:
-                        _release(self._static_evals.pop(next(iter(self._static_evals))))
+                        _evict_lru(self._static_evals)
                 else:
                     _, loss = eng.forward(inp, False, gt)
                 total += loss
@@ -174,7 +177,7 @@ class Trainer(object):
         weights = _plain_state_dict(model)
         opt_state = optimizer.state_dict()
         # every file goes to a temporary name first and is renamed into place, so no file is ever torn; recent.log is written
-        # LAST and records size + mtime of the files it belongs to: a crash between the renames can leave model.pth one save
+        # LAST and records size + a content hash of the files it belongs to: a crash between the renames can leave model.pth one save
         # newer than recent_optim.pth, and resume() then SAYS so (the files stay plain state_dicts the reference can load, so
         # the pairing cannot be stored inside them)
         if best:
@@ -214,8 +217,9 @@ class Trainer(object):
         stale = [n for n in names if n in table.get("files", {}) and table["files"][n] != _stamp(os.path.join(logdir, n))]
         if stale:
             import warnings
-            warnings.warn("checkpoint file(s) %s were written after recent.log (interrupted save?): model, optimizer state and "
-                          "counters may come from different saves" % ", ".join(stale))
+            warnings.warn("checkpoint file(s) %s differ in size or content from what recent.log recorded (a save interrupted between "
+                          "its renames, or files replaced afterwards): model, optimizer state and counters may come from different "
+                          "saves" % ", ".join(stale))
         weights = torch.load(os.path.join(logdir, names[0]), map_location="cpu")
         model.load_state_dict({k[7:] if k.startswith("module.") else k: v for k, v in weights.items()})
         optimizer.load_state_dict(torch.load(os.path.join(logdir, names[1]), map_location="cpu"))
@@ -233,8 +237,17 @@ def _bucket_lanes(inp, bucket):
 
 
 def _stamp(path):
-    st = os.stat(path)
-    return [st.st_size, st.st_mtime_ns]
+    """[size, sha256 of the first and last MiB]: identifies a save by CONTENT, so copying or restoring a log directory without
+    its mtimes (cp, rsync without -t, an object-store download) does not look like an interrupted save."""
+    import hashlib
+    size = os.stat(path).st_size
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        h.update(f.read(1 << 20))
+        if size > (2 << 20):
+            f.seek(size - (1 << 20))
+            h.update(f.read(1 << 20))
+    return [size, h.hexdigest()]
 
 
 def _atomic_save(obj, path):

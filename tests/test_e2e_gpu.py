@@ -251,63 +251,8 @@ def test_raw_sensor_ingest_path_equals_tensor_path():
     assert torch.equal(pred, ref)
 
 
-def test_batched_transformer_weight_gradients_equal_per_block_ones(monkeypatch):
-    """engine.GPT `grouped` mode (MMFN_GPT_GROUP_MAX_C): the weight / bias gradients of all blocks of a transformer from one batched
-    split-K launch per weight (strided outputs in the flat gradient buffer, stacked per-block activations) instead of one launch
-    per block: same gradients up to the rounding of a different split, same loss."""
-    from mmfn_amd import engine
-    _, net_a, batch, args = _setup("vec", dropout=0.1)
-    net_a._engine_for()                                   # engines are built at first use: build this one un-grouped
-    monkeypatch.setattr(engine, "GPT_GROUP_MIN_C", 0)
-    monkeypatch.setattr(engine, "GPT_GROUP_MAX_C", 512)
-    _, net_b, _, _ = _setup("vec", dropout=0.1)
-    assert all(g.grouped for g in net_b._engine_for().gpts) and not any(g.grouped for g in net_a._engine_for().gpts)
-    dargs = _dev_args(args)
-    gt = batch["gt_wp"].to(DEV)
-    losses = []
-    for net in (net_a, net_b):
-        net.train()
-        eng = net._engine_for()
-        inp = net._pack(*dargs)
-        _, loss = eng.forward(inp, True, gt)
-        eng.backward()
-        losses.append(loss.item())
-    assert losses[0] == losses[1]
-    ga, gb = net_a._layout.grads, net_b._layout.grads
-    n = net_a._layout.tail
-    err = (ga[:n] - gb[:n]).abs().max().item()
-    assert err <= 2e-5 * ga[:n].abs().max().item(), err
-    names = [k for k in net_a._layout.grad_views if "transformer" in k and ("mlp.0" in k or "attn.proj" in k or "key" in k)]
-    for k in names:
-        a, b = net_a._layout.grad_views[k], net_b._layout.grad_views[k]
-        assert (a - b).abs().max().item() <= 1e-5 * max(a.abs().max().item(), 1e-6), k
-
-
-def test_lane_graph_replay_equals_eager_steps():
-    """graphs.Recorder in lane-graph mode (every branch lane and every piece of transformer side work its own linear hipGraph,
-    stitched with eager events - MMFN_LANE_GRAPHS=1) replays to exactly the parameters eager train steps produce."""
-    from mmfn_amd.parallel import GraphedStep
-    _, net_a, batch, args = _setup("vec", dropout=0.1)
-    _, net_b, _, _ = _setup("vec", dropout=0.1)
-    dargs = _dev_args(args)
-    gt = batch["gt_wp"].to(DEV)
-    net_a.train(), net_b.train()
-    inp_a, inp_b = net_a._pack(*dargs), net_b._pack(*dargs)
-    for _ in range(3):
-        loss_a = net_a.train_step(inp_a, gt)
-    step = GraphedStep(net_b._engine_for(), None, inp_b, gt, warm=1, lane_graphs=True)
-    assert step.recorder.split_lanes and step.recorder.n_graphs > 20
-    for _ in range(2):
-        loss_b = step()
-    torch.cuda.synchronize()
-    assert loss_a.item() == loss_b.item()
-    sa, sb = net_a.state_dict(), net_b.state_dict()
-    for k in sa:
-        assert torch.equal(sa[k], sb[k]), k
-
-
 def test_segmented_graph_step_equals_eager_steps():
-    """parallel.GraphedStep (linear hipGraphs per branch lane, cut at the gradient-bucket boundaries under data parallelism) replays to exactly the
+    """parallel.GraphedStep (one hipGraph on one GPU; cut at the gradient-bucket boundaries under torch.distributed data parallelism) replays to exactly the
     parameters the eager train_step produces, dropout included (counter RNG advances on the device)."""
     from mmfn_amd.parallel import GraphedStep
     _, net_a, batch, args = _setup("vec", dropout=0.1)
@@ -347,16 +292,15 @@ def test_failed_capture_leaves_the_stream_usable(monkeypatch):
             raise RuntimeError("injected capture failure")
         return real_vec(*a, **k)
 
-    for lane_graphs in (True, False):
-        monkeypatch.setattr(E.VectorNet, "bwd", boom)    # fails inside a lane (its own graph in lane-graph mode)
-        with pytest.raises(RuntimeError, match="injected"):
-            GraphedStep(net._engine_for(), None, inp, gt, warm=0, lane_graphs=lane_graphs)
-        monkeypatch.setattr(E.VectorNet, "bwd", real_vec)
-        assert not torch.cuda.is_current_stream_capturing()
-        torch.cuda.synchronize()                         # illegal while any stream of this thread is still capturing
-        loss = net.train_step(inp, gt)                   # the eager fallback the trainer / bench.py take
-        torch.cuda.synchronize()
-        assert torch.isfinite(loss).all()
+    monkeypatch.setattr(E.VectorNet, "bwd", boom)    # fails inside a branch lane: a side stream forked into the capture
+    with pytest.raises(RuntimeError, match="injected"):
+        GraphedStep(net._engine_for(), None, inp, gt, warm=0)
+    monkeypatch.setattr(E.VectorNet, "bwd", real_vec)
+    assert not torch.cuda.is_current_stream_capturing()
+    torch.cuda.synchronize()                         # illegal while any stream of this thread is still capturing
+    loss = net.train_step(inp, gt)                   # the eager fallback the trainer / bench.py take
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss).all()
 
     def boom_opt(self, *a, **k):
         if torch.cuda.is_current_stream_capturing():
@@ -367,14 +311,6 @@ def test_failed_capture_leaves_the_stream_usable(monkeypatch):
     with pytest.raises(RuntimeError, match="injected"):
         GraphedStep(net._engine_for(), None, inp, gt, warm=0)
     monkeypatch.setattr(E.Engine, "optimizer_step", real_opt)
-    # the per-group optimizer option: the failure strikes with the optimizer stream forked into the capture and not yet joined
-    real_fin = E.Engine._step_finish
-    monkeypatch.setattr(E, "OVERLAP_ADAMW", True)
-    monkeypatch.setattr(E.Engine, "_step_finish", boom_opt)
-    with pytest.raises(RuntimeError, match="injected"):
-        GraphedStep(net._engine_for(), None, inp, gt, warm=0)
-    monkeypatch.setattr(E.Engine, "_step_finish", real_fin)
-    monkeypatch.setattr(E, "OVERLAP_ADAMW", False)
     torch.cuda.synchronize()
     step = GraphedStep(net._engine_for(), None, inp, gt, warm=0)   # and a later capture works
     step()
@@ -492,42 +428,6 @@ def test_folded_batchnorm_session_matches_unfolded_and_follows_weight_changes():
     folded.refresh()
     a2, _ = both()
     assert (a2 - b1).abs().max().item() <= 2e-5
-
-
-@pytest.mark.parametrize("variant", ["vec", "img"])
-def test_adamw_under_the_backward_equals_adamw_after_it(variant, monkeypatch):
-    """Engine.backward_and_step issues AdamW per readiness group while the backward still runs (its own stream, forked from
-    the stream that wrote the group): same kernel, same operands - parameters and moments must be bit-identical to the
-    one-launch optimizer step after the backward, eagerly and as a replayed hipGraph, dropout on."""
-    from mmfn_amd import engine as E
-    from mmfn_amd.parallel import GraphedStep
-    _, net_a, batch, args = _setup(variant, dropout=0.1)
-    _, net_b, _, _ = _setup(variant, dropout=0.1)
-    _, net_c, _, _ = _setup(variant, dropout=0.1)
-    dargs = _dev_args(args)
-    gt = batch["gt_wp"].to(DEV)
-    for n in (net_a, net_b, net_c):
-        n.train()
-    inp_a, inp_b, inp_c = net_a._pack(*dargs), net_b._pack(*dargs), net_c._pack(*dargs)
-    monkeypatch.setattr(E, "OVERLAP_ADAMW", False)
-    for _ in range(3):
-        loss_a = net_a.train_step(inp_a, gt)
-    monkeypatch.setattr(E, "OVERLAP_ADAMW", True)
-    assert net_b._engine_for().overlapped_step_ok()
-    for _ in range(3):
-        loss_b = net_b.train_step(inp_b, gt)
-    step = GraphedStep(net_c._engine_for(), None, inp_c, gt, warm=1)
-    for _ in range(2):
-        loss_c = step()
-    torch.cuda.synchronize()
-    assert loss_a.item() == loss_b.item() == loss_c.item()
-    La, Lb, Lc = net_a._layout, net_b._layout, net_c._layout
-    for name in ("params", "exp_avg", "exp_avg_sq"):
-        assert torch.equal(getattr(La, name), getattr(Lb, name)), name
-        assert torch.equal(getattr(La, name), getattr(Lc, name)), name
-    eng = net_b._engine_for()
-    spans = sorted(eng._opt_ranges.values())
-    assert spans[0][0] == 0 and spans[-1][1] == Lb.tail and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
 
 
 @pytest.mark.parametrize("variant", ["vec", "img"])

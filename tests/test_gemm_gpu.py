@@ -67,6 +67,30 @@ def test_epilogue_flags():
     assert not torch.equal(y1 != 0, y3 != 0)
 
 
+@pytest.mark.parametrize("relu", [False, True])
+def test_nan_propagates_alike_through_interior_and_edge_tiles(relu):
+    """A NaN accumulator must leave the GEMM the same way from an interior tile (flag-hoisted epilogue) and from an edge tile
+    (general per-element epilogue): NaN without ReLU - never -inf, which would mask a diverged run in one part of the matrix
+    only - and fmaxf's 0 with it, as torch.relu(nan) is NOT what the reference gives but both tile kinds agree."""
+    from mmfn_amd import ops
+    dev = _dev()
+    M, N, K = 192 + 40, 128 + 24, 64          # 64x64 tiles: interior tiles and a ragged right / bottom edge
+    g = torch.Generator().manual_seed(17)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    x[5, 3] = float("nan")      # row of an interior tile
+    x[M - 2, 7] = float("nan")  # row of an edge tile
+    for tile in (0, 1, 4):
+        y = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), relu=relu, tile=tile).cpu()
+        for row in (5, M - 2):
+            if relu:
+                assert bool((y[row] == 0).all()), (tile, row)
+            else:
+                assert bool(torch.isnan(y[row]).all()), (tile, row, y[row][:4])
+        ok = torch.ones(M, dtype=torch.bool); ok[5] = ok[M - 2] = False
+        ref = x[ok] @ w.t() + b
+        _close(y[ok], torch.relu(ref) if relu else ref)
+
+
 CONVS = [  # B, H, W, Cin, Cout, k, stride, pad
     (2, 16, 16, 64, 64, 3, 1, 1), (2, 16, 16, 64, 128, 3, 2, 1), (2, 16, 16, 64, 128, 1, 2, 0),
     (1, 8, 8, 256, 512, 3, 2, 1), (3, 9, 11, 16, 32, 3, 1, 1), (2, 32, 32, 3, 64, 7, 2, 3),
