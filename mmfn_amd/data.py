@@ -107,6 +107,223 @@ class FrameStore(torch.utils.data.Dataset):
 PRE_Data = FrameStore  # reference name
 
 
+# ------------------------------------------------------------------------------------------ packed frames (row f1 at full rate)
+# FrameStore unpickles ~0.9 MB per sample on the host; at the step rate of one MI355X (1000 samples/s) that, plus the
+# worker -> main-process hand-over of every batch, is the bottleneck of the training loop.  pack_frames
+# converts a directory of phase-1 pickles ONCE into flat per-field arrays; PackedFrames memory-maps them and PackedLoader gathers
+# a batch's rows straight into pinned staging tensors in a background thread: one memcpy per field, no pickling, no worker
+# processes.  The batches are bit-identical to collate([FrameStore[i] for i in indices]) (tests/test_data_cpu.py).
+PACK_FORMAT = "mmfn-packed-frames-1"
+
+
+def _leaf_kind(v):
+    if isinstance(v, (torch.Tensor, np.ndarray)):
+        return "array"
+    if isinstance(v, (float, np.floating)):
+        return "float"
+    if isinstance(v, (bool, np.bool_)):
+        return "bool"
+    if isinstance(v, (int, np.integer)):
+        return "int"
+    if isinstance(v, (str, bytes)):
+        return "str"
+    if isinstance(v, (tuple, list)):
+        return "list"
+    raise TypeError("pack_frames: unsupported field type %s" % type(v))
+
+
+def pack_frames(store, out_dir):
+    """FrameStore (or any dataset of phase-1 sample dicts) -> out_dir/{schema.json, <field>.bin ...}.  One streaming pass.
+    Every field must have the same structure in all samples (what `collate` requires too); lane sets may be ragged."""
+    import json
+    os.makedirs(out_dir, exist_ok=True)
+    files, scalars, schema = {}, {}, None
+
+    def emit(name, arr):
+        arr = np.ascontiguousarray(arr.numpy() if isinstance(arr, torch.Tensor) else np.asarray(arr))
+        ent = files.get(name)
+        if ent is None:
+            ent = files[name] = {"fd": open(os.path.join(out_dir, name + ".bin"), "wb"), "dtype": arr.dtype.str, "shape": list(arr.shape)}
+        if arr.dtype.str != ent["dtype"] or list(arr.shape) != ent["shape"]:
+            raise ValueError("pack_frames: field %s changes dtype / shape between samples (%s %s vs %s %s)"
+                             % (name, arr.dtype.str, list(arr.shape), ent["dtype"], ent["shape"]))
+        ent["fd"].write(arr.tobytes())
+
+    def walk(v, name):
+        kind = _leaf_kind(v)
+        if kind == "array":
+            emit(name, v)
+            return {"kind": "array", "name": name}
+        if kind == "list":
+            return {"kind": "list", "items": [walk(x, "%s.%d" % (name, j)) for j, x in enumerate(v)]}
+        scalars.setdefault(name, []).append(v.decode() if isinstance(v, bytes) else (v.item() if isinstance(v, np.generic) else v))
+        return {"kind": kind, "name": name}
+
+    def lanes(v, name):   # per frame of the sequence: ragged [L, n, F] -> concatenated rows + a count
+        items = []
+        for j, x in enumerate(v):
+            x = np.ascontiguousarray(x.numpy() if isinstance(x, torch.Tensor) else np.asarray(x))
+            nm = "%s.%d" % (name, j)
+            ent = files.get(nm)
+            if ent is None:
+                ent = files[nm] = {"fd": open(os.path.join(out_dir, nm + ".bin"), "wb"), "dtype": x.dtype.str, "shape": list(x.shape[1:]), "ragged": True}
+            if x.dtype.str != ent["dtype"] or list(x.shape[1:]) != ent["shape"]:
+                raise ValueError("pack_frames: lane field %s changes dtype / row shape between samples" % nm)
+            ent["fd"].write(x.tobytes())
+            scalars.setdefault(nm + ".count", []).append(int(x.shape[0]))
+            items.append({"kind": "lanes", "name": nm})
+        return {"kind": "list", "items": items}
+
+    n = len(store)
+    for i in range(n):
+        sample = store[i]
+        node = {k: (lanes(v, k) if k == "vectormaps" else walk(v, k)) for k, v in sample.items()}
+        if schema is None:
+            schema = node
+        elif node != schema:
+            raise ValueError("pack_frames: sample %d has a different structure than sample 0" % i)
+    for ent in files.values():
+        ent.pop("fd").close()
+    with open(os.path.join(out_dir, "schema.json"), "w") as f:
+        json.dump({"format": PACK_FORMAT, "n": n, "fields": schema, "files": files, "scalars": scalars}, f)
+    return out_dir
+
+
+class PackedFrames(object):
+    """Memory-mapped view of a pack_frames directory.  batch(indices) == collate([store[i] for i in indices]), bit for bit
+    (values, dtypes, shapes, container types), with the tensors optionally in pinned memory."""
+
+    def __init__(self, root):
+        import json
+        with open(os.path.join(root, "schema.json")) as f:
+            meta = json.load(f)
+        if meta.get("format") != PACK_FORMAT:
+            raise ValueError("%s is not a %s directory" % (root, PACK_FORMAT))
+        self.n, self.fields, self.scalars = meta["n"], meta["fields"], meta["scalars"]
+        self.arrays, self.offsets = {}, {}
+        for name, ent in meta["files"].items():
+            dt, shape = np.dtype(ent["dtype"]), tuple(ent["shape"])
+            path = os.path.join(root, name + ".bin")
+            if ent.get("ragged"):
+                counts = np.asarray(self.scalars[name + ".count"], dtype=np.int64)
+                self.offsets[name] = np.concatenate([[0], np.cumsum(counts)])
+                rows = int(self.offsets[name][-1])
+            else:
+                rows = self.n
+            self.arrays[name] = np.memmap(path, dtype=dt, mode="r", shape=(rows,) + shape) if rows else np.zeros((0,) + shape, dt)
+
+    def __len__(self):
+        return self.n
+
+    def _gather(self, node, idx, pin):
+        kind = node["kind"]
+        if kind == "list":
+            return [self._gather(c, idx, pin) for c in node["items"]]
+        name = node["name"]
+        if kind == "array":
+            src = self.arrays[name]
+            out = torch.empty((len(idx),) + src.shape[1:], dtype=_TORCH_DTYPE[src.dtype.str], pin_memory=pin)
+            np.take(src, idx, axis=0, out=out.numpy(), mode="clip")   # (indices are in range; "clip" writes into `out` directly)
+            return out
+        if kind == "lanes":   # as _pad_lanes: [padded [B, Lmax, ...], counts i64 [B], int Lmax]
+            src, off = self.arrays[name], self.offsets[name]
+            nums = torch.tensor([int(off[i + 1] - off[i]) for i in idx])
+            lmax = int(nums.max().item())
+            out = torch.zeros((len(idx), lmax) + src.shape[1:], dtype=_TORCH_DTYPE[src.dtype.str], pin_memory=pin)
+            o = out.numpy()
+            for b, i in enumerate(idx):
+                o[b, :off[i + 1] - off[i]] = src[off[i]:off[i + 1]]
+            return [out, nums, lmax]
+        vals = self.scalars[name]
+        if kind == "float":
+            return torch.tensor([float(vals[i]) for i in idx], dtype=torch.float64)
+        if kind in ("int", "bool"):
+            return torch.tensor([vals[i] for i in idx])
+        if kind == "str":
+            return [vals[i] for i in idx]
+        raise ValueError(kind)
+
+    def batch(self, indices, pin=False):
+        idx = np.asarray(list(indices), dtype=np.int64)
+        if idx.size and (idx.min() < 0 or idx.max() >= self.n):
+            raise IndexError("sample index out of range")
+        return {k: self._gather(node, idx, pin) for k, node in self.fields.items()}
+
+    def __getitem__(self, i):
+        """One sample as a batch of one (debugging aid; training goes through PackedLoader)."""
+        return self.batch([i])
+
+
+_TORCH_DTYPE = {np.dtype(k).str: v for k, v in (("uint8", torch.uint8), ("int8", torch.int8), ("int16", torch.int16), ("int32", torch.int32),
+                                                  ("int64", torch.int64), ("float16", torch.float16), ("float32", torch.float32),
+                                                  ("float64", torch.float64), ("bool", torch.bool))}
+
+
+class PackedLoader(object):
+    """Iterates collated batches of a PackedFrames store; a background thread assembles them `prefetch` batches ahead into
+    pinned memory (the caching host allocator keeps a block until the asynchronous copy that reads it has completed).
+    Same role as make_loader(FrameStore, ...) for Trainer.train / DevicePrefetcher; `sampler` takes a DistributedSampler."""
+
+    def __init__(self, packed, batch_size, shuffle=False, sampler=None, seed=0, drop_last=False, prefetch=3, pin_memory=True):
+        self.packed, self.batch_size, self.shuffle, self.sampler = packed, int(batch_size), shuffle, sampler
+        self.seed, self.drop_last, self.prefetch = seed, drop_last, max(1, int(prefetch))
+        self.pin = bool(pin_memory) and torch.cuda.is_available()
+        self.epoch = 0
+
+    def _order(self):
+        if self.sampler is not None:
+            return [int(i) for i in self.sampler]
+        n = len(self.packed)
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            return torch.randperm(n, generator=g).tolist()
+        return list(range(n))
+
+    def __len__(self):
+        n = len(self.sampler) if self.sampler is not None else len(self.packed)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        import queue
+        import threading
+        order = self._order()
+        self.epoch += 1
+        B = self.batch_size
+        chunks = [order[i:i + B] for i in range(0, len(order), B)]
+        if self.drop_last and chunks and len(chunks[-1]) < B:
+            chunks.pop()
+        q, stop = queue.Queue(maxsize=self.prefetch), threading.Event()
+
+        def work():
+            try:
+                for c in chunks:
+                    if stop.is_set():
+                        return
+                    q.put(self.packed.batch(c, pin=self.pin))
+                q.put(None)
+            except BaseException as exc:   # hand the failure to the consumer instead of dying silently
+                q.put(exc)
+
+        t = threading.Thread(target=work, name="mmfn-packed-loader", daemon=True)
+        t.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                yield item
+        finally:
+            stop.set()
+            while t.is_alive():    # unblock a producer waiting on a full queue
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    t.join(timeout=0.05)
+
+
 # ------------------------------------------------------------------------------------------ collation
 def _stack(items):
     first = items[0]

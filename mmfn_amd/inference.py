@@ -1,9 +1,15 @@
 """Closed-loop (batch-1) inference entry: raw sensor frames in, waypoints and a control command out.
 
-Restates the per-tick work of the driving agent around `self.net(...)` (team_code/e2e_agent/mmfn_vectornet.py:
-199-311) for seq_len = 1: camera frame -> centre crop (`scale_and_crop_image`), LiDAR sweep (this tick + the
-previous one, :249) -> y flip (:272) -> ego-frame transform (identity for a single frame: source and target
-pose coincide, :268-275) -> 2 x 256 x 256 histogram, lanes [L,10,5] -> VectorNet, then `control_pid`.
+Restates the per-tick work of the three driving agents around `self.net(...)` for seq_len = 1 -
+team_code/e2e_agent/mmfn_vectornet.py:199-311 (vec), mmfn_imgnet.py:199-296 (img), mmfn_radar.py:206-320 (rad):
+camera frame -> centre crop (`scale_and_crop_image`), LiDAR sweep (this tick + the previous one, mmfn_vectornet.py:249)
+-> y flip (:272) -> ego-frame transform (identity for a single frame: source and target pose coincide, :268-275) ->
+2 x 256 x 256 histogram; then per variant
+    vec   lanes [L,10,5] -> VectorNet                                   (mmfn_vectornet.py:287-297)
+    img   the bird's-eye OpenDRIVE raster [256,256,3] u8, as it is      (mmfn_imgnet.py:244-246: transpose, float, no normalisation)
+    rad   lanes + the radar returns of both sensors [n,5] -> `radar_to_size` (81 rows) and the 81 x 81 difference matrix
+          of their second column                                        (mmfn_radar.py:298-308)
+and `control_pid`.
 
 All of it runs on the GPU: the uint8 frame and the XYZI points are copied as they are and cropped / normalised /
 splatted by the ingest kernels (csrc/ingest.hip); the eval-mode network is captured once into a hipGraph over
@@ -19,9 +25,12 @@ FAR = 1.0e6  # x coordinate of padding points: outside every histogram bin, igno
 
 class DrivingSession(object):
     def __init__(self, net, image_hw=(300, 400), max_points=1 << 17, max_lanes=128, use_graph=True, fold_batchnorm=True):
-        if net.variant != "vec":
-            raise NotImplementedError("closed-loop session is built for the vec model (mmfn_vectornet agent)")
+        if net.variant not in ("vec", "img", "rad"):
+            raise NotImplementedError("unknown model variant %r" % (net.variant,))
+        if (int(net.config.seq_len), int(net.config.n_views)) != (1, 1):
+            raise NotImplementedError("the closed-loop session feeds one frame per tick (seq_len = n_views = 1, as the agents run)")
         self.net = net.eval()
+        self.variant = net.variant
         self.eng = net._engine_for()
         dev = net._layout.device
         H, W = image_hw
@@ -30,11 +39,17 @@ class DrivingSession(object):
             "rgb_u8": torch.zeros(1, H, W, 3, dtype=torch.uint8, device=dev),
             "lidar_pts": torch.full((1, max_points, 4), FAR, dtype=torch.float32, device=dev),
             "lidar_flip_y": True,
-            "lane": torch.zeros(1, max_lanes, 10, 5, dtype=torch.float32, device=dev),
-            "lane_num": torch.ones(1, dtype=torch.int32, device=dev),
             "target_point": torch.zeros(1, 2, dtype=torch.float32, device=dev),
             "velocity": torch.zeros(1, dtype=torch.float32, device=dev),
         }
+        if self.variant == "img":
+            self.inp["map"] = torch.zeros(1, 3, 256, 256, dtype=torch.float32, device=dev)
+        else:
+            self.inp["lane"] = torch.zeros(1, max_lanes, 10, 5, dtype=torch.float32, device=dev)
+            self.inp["lane_num"] = torch.ones(1, dtype=torch.int32, device=dev)
+        if self.variant == "rad":
+            self.inp["radar"] = torch.zeros(1, 81, 5, dtype=torch.float32, device=dev)
+            self.inp["radar_adj"] = torch.zeros(1, 81, 81, dtype=torch.float32, device=dev)
         # pinned staging so the copies are asynchronous and the graph launch follows them in stream order
         self.host = {k: torch.empty(v.shape, dtype=v.dtype).pin_memory() for k, v in self.inp.items() if isinstance(v, torch.Tensor)}
         self.host["lidar_pts"].fill_(FAR)
@@ -70,7 +85,7 @@ class DrivingSession(object):
             self._folded_version = getattr(self.net, "_weights_version", 0)
 
     # ------------------------------------------------------------------ one tick
-    def _load(self, rgb, sweep, lanes, target_point, speed):
+    def _load(self, rgb, sweep, lanes, target_point, speed, map_image=None, radar=None):
         # plain numpy writes into the pinned buffers: torch CPU copies fan out over every OpenMP thread, and
         # their spin-waiting is enough to get a quota-limited container throttled for most of a scheduler period
         h = self.host_np
@@ -87,13 +102,26 @@ class DrivingSession(object):
         if n < self._n_points:  # only the rows the previous sweep filled need to go back to padding
             hp[n:self._n_points, 0] = FAR
         self._n_points = n
-        lanes = np.asarray(lanes, dtype=np.float32)
-        L = lanes.shape[0]
-        if not 1 <= L <= self.max_lanes:
-            raise ValueError("lane count %d outside [1, %d]" % (L, self.max_lanes))
-        h["lane"][0, :L] = lanes
-        h["lane"][0, L:] = 0.0
-        h["lane_num"][0] = L
+        if self.variant == "img":
+            m = np.asarray(map_image)
+            if m.shape == (256, 256, 3):      # the raster as the agent holds it (HWC): np.transpose(..., (2, 0, 1)), mmfn_imgnet.py:245
+                m = m.transpose(2, 0, 1)
+            if m.shape != (3, 256, 256):
+                raise ValueError("map_image must be [256,256,3] or [3,256,256], got %s" % (m.shape,))
+            h["map"][0] = m
+        else:
+            lanes = np.asarray(lanes, dtype=np.float32)
+            L = lanes.shape[0]
+            if not 1 <= L <= self.max_lanes:
+                raise ValueError("lane count %d outside [1, %d]" % (L, self.max_lanes))
+            h["lane"][0, :L] = lanes
+            h["lane"][0, L:] = 0.0
+            h["lane_num"][0] = L
+        if self.variant == "rad":
+            from . import data as D
+            r = D.radar_to_size(np.asarray(radar, dtype=np.float64))    # float64 like the agent's numpy arrays; rounded once below
+            h["radar"][0] = r
+            h["radar_adj"][0] = D.radar_adjacency(r)
         h["target_point"][0, 0], h["target_point"][0, 1] = float(target_point[0]), float(target_point[1])
         h["velocity"][0] = float(speed)
         h = self.host
@@ -107,9 +135,14 @@ class DrivingSession(object):
                 self.inp[k].copy_(t, non_blocking=True)
 
     @torch.no_grad()
-    def predict(self, rgb, lidar, lanes, target_point, speed, merge_previous_sweep=True):
-        """rgb u8 [H,W,3]; lidar [n,>=3] XYZ(I) of this tick (sensor frame, y not yet flipped); lanes [L,10,5];
-        target_point (x, y) in the ego frame; speed in m/s.  Returns pred_wp as a CPU tensor [1, pred_len, 2]."""
+    def predict(self, rgb, lidar, lanes, target_point, speed, merge_previous_sweep=True, map_image=None, radar=None):
+        """rgb u8 [H,W,3]; lidar [n,>=3] XYZ(I) of this tick (sensor frame, y not yet flipped); lanes [L,10,5] (vec / rad; None
+        for img); target_point (x, y) in the ego frame; speed in m/s; map_image (img): the bird's-eye raster u8 [256,256,3];
+        radar (rad): the radar returns [n,5] of both sensors.  Returns pred_wp as a CPU tensor [1, pred_len, 2]."""
+        if self.variant == "img" and map_image is None:
+            raise ValueError("the image-map model needs map_image")
+        if self.variant == "rad" and radar is None:
+            raise ValueError("the radar model needs the radar returns")
         lidar = np.asarray(lidar)
         sweep = lidar
         if merge_previous_sweep and self.prev_sweep is not None:  # half-rate LiDAR: two ticks make one revolution (:249)
@@ -120,7 +153,7 @@ class DrivingSession(object):
             # weights beside fresh transformers.  Re-fold in place (one launch per convolution; the captured graph stays valid).
             # Weights modified behind the module's back (raw writes into p.data) still need an explicit refresh().
             self.refresh()
-        self._load(rgb, sweep, lanes, target_point, speed)
+        self._load(rgb, sweep, lanes, target_point, speed, map_image, radar)
         if self.graph is not None:
             self.graph.replay()
         else:
@@ -129,9 +162,9 @@ class DrivingSession(object):
         torch.cuda.current_stream().synchronize()
         return torch.from_numpy(self.out_host.numpy().copy())
 
-    def run_step(self, rgb, lidar, lanes, target_point, speed):
+    def run_step(self, rgb, lidar, lanes, target_point, speed, map_image=None, radar=None):
         """predict + PID, with the agent's post-processing of the command (mmfn_vectornet.py:299-310)."""
-        wp = self.predict(rgb, lidar, lanes, target_point, speed)
+        wp = self.predict(rgb, lidar, lanes, target_point, speed, map_image=map_image, radar=radar)
         steer, throttle, brake, meta = self.net.control_pid(wp, torch.tensor([float(speed)]))
         brake = float(brake)
         if brake < 0.05:

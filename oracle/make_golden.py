@@ -109,6 +109,10 @@ def run_variant(variant, ref_models, ref_dl, ref_cfg, out_dir):
             a1 = ([fronts[:1]], [bev[:1]], None, one, [batch["radar"][:1]], [batch["radar_adj"][:1]],
                   batch["target_point"][:1], batch["velocity"][:1])
             res["eval_pred_wp_b1_agent"] = model(*a1).numpy()
+    else:   # the image-map agent's call (e2e_agent/mmfn_imgnet.py:273-276): batch 1, the raster in the maps list, no vector map / radar
+        with torch.no_grad():
+            res["eval_pred_wp_b1_agent"] = model([fronts[:1]], [bev[:1]], [maps[:1]], None, None, None,
+                                                 batch["target_point"][:1], batch["velocity"][:1]).numpy()
     for m in bns:
         m.momentum = 0.1
     fixtures.fill_module(model)  # restore closed-form running stats for the train-step vectors

@@ -94,6 +94,71 @@ def test_frame_store_and_staging(tmp_path, io):
     assert torch.equal(gt2, gt) and torch.equal(args2[0][0], fronts[0])
 
 
+def _same(a, b, path=""):
+    """Recursive equality of two collated batches: container types, dtypes, shapes, values."""
+    assert type(a) is type(b), (path, type(a), type(b))
+    if isinstance(a, dict):
+        assert list(a) == list(b), path
+        for k in a:
+            _same(a[k], b[k], path + "/" + k)
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), path
+        for j, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, "%s[%d]" % (path, j))
+    elif isinstance(a, torch.Tensor):
+        assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), (path, a.dtype, b.dtype, a.shape, b.shape)
+    else:
+        assert a == b, (path, a, b)
+
+
+def test_packed_frames_give_the_batches_of_the_pickle_store(tmp_path):
+    """pack_frames / PackedFrames / PackedLoader (the loader that feeds the step at its resident rate): every batch equals
+    collate() over the same FrameStore samples bit for bit - ragged lanes, float64 labels, bool / int / tuple fields - in any
+    index order; the loader covers every sample once per epoch, reshuffles per epoch, honours a sampler and drop_last."""
+    cfg = GlobalConfig()
+    src = tmp_path / "pkl"
+    src.mkdir()
+    samples = fixtures.synthetic_samples(lane_counts=(5, 9, 3, 7, 1), seed=5, radar_counts=(50, 100, 81, 3, 90))
+    for i, s in enumerate(samples):
+        with open(src / ("%d.pkl" % i), "wb") as fd:
+            pickle.dump(s, fd)
+    store = D.FrameStore(str(src), cfg, "train")
+    packed = D.PackedFrames(D.pack_frames(store, str(tmp_path / "packed")))
+    assert len(packed) == len(store) == 5
+    for idx in ([0, 1, 2, 3, 4], [4, 2], [3], [1, 1, 0]):
+        _same(packed.batch(idx), D.collate([store[i] for i in idx]))
+    with pytest.raises(IndexError):
+        packed.batch([5])
+    # the loader
+    seen = []
+    loader = D.PackedLoader(packed, batch_size=2, shuffle=True, seed=3, pin_memory=False)
+    assert len(loader) == 3
+    e1 = [b["velocity"].tolist() for b in loader]
+    e2 = [b["velocity"].tolist() for b in loader]
+    flat = lambda e: sorted(v for b in e for v in b)
+    assert flat(e1) == flat(e2) == sorted(float(s["velocity"]) for s in (store[i] for i in range(5)))
+    assert e1 != e2                                            # a new permutation every epoch
+    assert [len(b) for b in e1] == [2, 2, 1]
+    assert len(D.PackedLoader(packed, 2, drop_last=True)) == 2 and len(list(D.PackedLoader(packed, 2, drop_last=True, pin_memory=False))) == 2
+    sampler = D.shard_sampler(store, rank=1, world=2, shuffle=False)
+    got = [b["velocity"].tolist() for b in D.PackedLoader(packed, 2, sampler=sampler, pin_memory=False)]
+    want = [float(store[i]["velocity"]) for i in sampler]
+    assert [v for b in got for v in b] == want
+    # staging and the prefetcher take its batches like the DataLoader's
+    b0 = next(iter(D.PackedLoader(packed, 3, pin_memory=False)))
+    ref = D.collate([store[i] for i in range(3)])
+    (a1, g1), (a2, g2) = D.stage_batch(b0, "cpu", cfg, non_blocking=False), D.stage_batch(ref, "cpu", cfg, non_blocking=False)
+    _same(list(a1), list(a2))
+    assert torch.equal(g1, g2)
+    it = iter(D.PackedLoader(packed, 1, pin_memory=False))     # an abandoned iteration must not leave the producer thread blocked
+    next(it)
+    it.close()
+    # a store whose samples disagree in structure is refused
+    bad = dict(samples[0]); bad.pop("steer")
+    with pytest.raises(ValueError):
+        D.pack_frames([samples[0], bad], str(tmp_path / "bad"))
+
+
 def test_raw_route_reader_with_two_frames_per_sample(tmp_path, golden_dir):
     """RawFrameStore at seq_len = 2 against the reference's CARLA_Data on the same synthetic route (raw_route.npz, s2_*): camera /
     map / lane / radar frames, labels, waypoints, and the LiDAR sweeps moved into the ego frame of the last one.  The reference

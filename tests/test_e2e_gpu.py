@@ -318,6 +318,46 @@ def test_failed_capture_leaves_the_stream_usable(monkeypatch):
     assert torch.isfinite(step.loss).all()
 
 
+@pytest.mark.parametrize("variant", ["vec", "img", "rad"])
+def test_driving_session_reproduces_the_agents_batch1_vectors(variant, golden_dir):
+    """DrivingSession for the three agents (e2e_agent/mmfn_vectornet.py, mmfn_imgnet.py, mmfn_radar.py): raw u8 frame, raw sweep
+    (the session flips y as the agents do), lanes / bird's-eye raster / raw radar returns in, against the waypoints the
+    REFERENCE produced for the same sample in its agent-style batch-1 call (tests/golden `eval_pred_wp_b1_agent`) - with the
+    BatchNorms folded into the filters and the tick replayed as one hipGraph, and unfolded / eager."""
+    from mmfn_amd.inference import DrivingSession
+    from oracle import harness
+    g = np.load(os.path.join(golden_dir, "mmfn_%s_b2.npz" % variant))
+    oracle, net, batch, args = _setup(variant, B=2)
+    harness.calibrate_bn(oracle, args)       # as oracle/make_golden.py: running statistics := statistics of the batch-2 call
+    net.load_state_dict(oracle.state_dict(), strict=True)
+    rgb = batch["rgb_u8"][0].numpy()
+    pts = batch["lidar_pts"][0].numpy().copy()
+    pts[:, 1] *= -1                          # the fixture's sweep is in the ego frame already; the agent's y flip undoes this
+    kw = {}
+    lanes = None
+    if variant == "img":
+        kw["map_image"] = batch["map_u8"][0].numpy().transpose(1, 2, 0)     # HWC, as the agent holds it
+    else:
+        lanes = batch["lane"][0, :int(batch["lane_num"][0])].numpy()
+    if variant == "rad":
+        kw["radar"] = batch["radar"][0].numpy()                              # 81 returns: radar_to_size keeps them as they are
+    tp, speed = batch["target_point"][0].tolist(), float(batch["velocity"][0])
+    ref = g["eval_pred_wp_b1_agent"]
+    outs = []
+    for fold, graph in ((True, True), (False, False)):
+        sess = DrivingSession(net, max_points=1 << 15, max_lanes=32, use_graph=graph, fold_batchnorm=fold)
+        got = sess.predict(rgb, pts, lanes, tp, speed, merge_previous_sweep=False, **kw).numpy()
+        assert np.abs(got - ref).max() <= 1e-4, (variant, fold, np.abs(got - ref).max())
+        outs.append(got)
+        got2 = sess.predict(rgb, pts, lanes, tp, speed, merge_previous_sweep=False, **kw).numpy()   # a second tick over the same buffers
+        assert np.array_equal(got, got2)
+    out = sess.run_step(rgb, pts, lanes, tp, speed, **kw)
+    assert -1.0 <= out["steer"] <= 1.0 and 0.0 <= out["throttle"] <= 0.75
+    if variant != "vec":
+        with pytest.raises(ValueError):
+            sess.predict(rgb, pts, lanes, tp, speed)      # the raster / the radar returns are missing
+
+
 def test_driving_session_equals_reference_pipeline(golden_dir):
     """Batch-1 closed-loop entry (raw u8 frame + XYZI sweep + ragged lanes, hipGraph) == the agent's sequence:
     oracle crop / y-flip / histogram on the CPU, then the oracle network, then control_pid."""

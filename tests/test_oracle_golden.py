@@ -73,6 +73,11 @@ def test_model_against_reference(golden_dir, variant):
               batch["target_point"][:1], batch["velocity"][:1])
         with torch.no_grad():
             np.testing.assert_allclose(model(*a1).numpy(), g["eval_pred_wp_b1_agent"], rtol=0, atol=1e-6)
+    else:   # the image-map agent's batch-1 call (e2e_agent/mmfn_imgnet.py:273-276)
+        with torch.no_grad():
+            wp1 = model([args[0][0][:1]], [args[1][0][:1]], [args[2][0][:1]], None, None, None, batch["target_point"][:1],
+                        batch["velocity"][:1]).numpy()
+        np.testing.assert_allclose(wp1, g["eval_pred_wp_b1_agent"], rtol=0, atol=1e-6)
 
     fixtures.fill_module(model)
     pred, loss, grads = harness.train_step(model, args, batch["gt_wp"])

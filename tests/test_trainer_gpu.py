@@ -150,6 +150,33 @@ def test_graph_replay_epoch_equals_eager_epoch(store):
     assert nets[0][0] == nets[1][0] and worst[0] == 0.0, (nets[0][0], nets[1][0], worst)
 
 
+def test_epoch_from_packed_frames_equals_epoch_from_pickles(store, tmp_path):
+    """data.PackedLoader (memory-mapped flat arrays gathered into pinned staging by a thread) feeds Trainer.train exactly what
+    the DataLoader over the phase-1 pickles feeds it: two epochs, dropout on, graph replay - losses and every weight bit-equal."""
+    from mmfn_amd import data as D
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd import model as M
+    from mmfn_amd.optim import FusedAdamW
+    from mmfn_amd.trainer import Trainer
+    from oracle import harness
+    oracle = harness.build_oracle("vec", dropout=0.1)
+    cfg = GlobalConfig()
+    packed = D.PackedFrames(D.pack_frames(store, str(tmp_path / "packed")))
+    loaders = (D.make_loader(store, batch_size=2, num_workers=0), D.PackedLoader(packed, batch_size=2))
+    out = []
+    for loader in loaders:
+        net = M.MMFN(cfg, DEV)
+        net.load_state_dict(oracle.state_dict(), strict=True)
+        tr = Trainer(DEV, None)
+        opt = FusedAdamW(net, lr=1e-4)
+        tr.train(net, loader, cfg, opt)
+        tr.train(net, loader, cfg, opt)
+        out.append((tr.train_loss, net.state_dict()))
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+
+
 def test_graph_replayed_validation_equals_eager_validation(store):
     """Trainer.validate(graph=True): the eval forward captured per input shape and replayed over changing batches gives the same
     validation loss as eager launches, before and after the weights change (the capture reads the weights at replay time)."""

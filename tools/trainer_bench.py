@@ -1,5 +1,6 @@
-"""End-to-end rate of the real training loop (pickled PRE_Data frames -> DataLoader workers -> pinned staging -> H2D ->
-fused step), eager launches vs static-input hipGraph replay.  Complements bench.py, whose inputs are resident in HBM."""
+"""End-to-end rate of the real training loop (phase-1 frames -> loader -> pinned staging -> H2D -> fused step): pickled PRE_Data
+frames through DataLoader workers with eager launches / static-input hipGraph replay, and the packed store (data.pack_frames +
+PackedLoader) with graph replay.  Complements bench.py, whose inputs are resident in HBM."""
 import json
 import os
 import pickle
@@ -41,16 +42,26 @@ def run(mode, B=32, n=768, epochs=2):
         net = MMFN(cfg, "cuda:0")
         opt = FusedAdamW(net, lr=1e-4)
         tr = Trainer("cuda:0", None)
-        loader = torch.utils.data.DataLoader(store, batch_size=B, shuffle=False, num_workers=8, collate_fn=D.collate,
-                                             persistent_workers=True, prefetch_factor=4)
-        tr.train(net, loader, cfg, opt, graph=(mode == "graph"))  # warm epoch (buffers, capture, worker start-up)
+        if mode == "packed":   # the flat memory-mapped store (data.pack_frames, one-time conversion) + its threaded loader
+            t_pack = time.time()
+            packed = D.PackedFrames(D.pack_frames(store, os.path.join(tmp, "packed")))
+            t_pack = time.time() - t_pack
+            loader = D.PackedLoader(packed, batch_size=B)
+        else:
+            loader = torch.utils.data.DataLoader(store, batch_size=B, shuffle=False, num_workers=8, collate_fn=D.collate,
+                                                 persistent_workers=True, prefetch_factor=4)
+        graph = mode != "eager"
+        tr.train(net, loader, cfg, opt, graph=graph)  # warm epoch (buffers, capture, worker start-up)
         torch.cuda.synchronize()
         t0 = time.time()
         for _ in range(epochs):
-            tr.train(net, loader, cfg, opt, graph=(mode == "graph"))
+            tr.train(net, loader, cfg, opt, graph=graph)
         torch.cuda.synchronize()
         dt = time.time() - t0
-        return {"samples_per_s": round(epochs * n / dt, 1), "ms_per_step": round(dt / (epochs * n / B) * 1e3, 2)}
+        res = {"samples_per_s": round(epochs * n / dt, 1), "ms_per_step": round(dt / (epochs * n / B) * 1e3, 2)}
+        if mode == "packed":
+            res["pack_seconds_per_1000_frames"] = round(t_pack / n * 1000, 2)
+        return res
 
 
 def main():
@@ -59,10 +70,12 @@ def main():
         return
     import subprocess
     out = {}
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "packed"):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), mode], capture_output=True, text=True)
         out[mode] = json.loads(r.stdout.strip().splitlines()[-1])
-    print(json.dumps({"workload": "Trainer.train, batch 32, 768 pickled frames/epoch, 8 persistent loader workers, one MI355X", **out}))
+    print(json.dumps({"workload": "Trainer.train, batch 32, 768 phase-1 frames/epoch, one MI355X; eager / graph: pickles through 8 persistent "
+                                  "DataLoader workers; packed: data.PackedLoader over the memory-mapped conversion of the same frames, "
+                                  "graph replay", **out}))
 
 
 if __name__ == "__main__":
