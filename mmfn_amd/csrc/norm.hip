@@ -22,7 +22,9 @@ constexpr int NT = 256;
 //         else g;  xhat = (x - mean) * rstd
 // TX: element type of x (the convolution output), TA: of the activation-side tensors g, y (fp32 path: both float; bf16 mode:
 // both bf16, except the fp32 stems whose convolution output stays fp32)
-template <int MODE, typename TX, typename TA>
+// MASK (MODE 1): 0 none, 1 from y, 2 recomputed from x - a template parameter so that the loads of an iteration are issued together
+// (a run-time test of the y pointer puts the third load behind a branch: two memory round trips per row instead of one)
+template <int MODE, int MASK, typename TX, typename TA>
 __global__ __launch_bounds__(NT) void col_partial_kernel(const TX* __restrict__ x, const TA* __restrict__ g,
                                                          const TA* __restrict__ y, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, const float* __restrict__ zw,
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(NT) void col_partial_kernel(const TX* __restrict__ 
   const int64_t r1 = (r0 + rows_per_block < M) ? r0 + rows_per_block : M;
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   f32x4 mu = {0, 0, 0, 0}, rs = {0, 0, 0, 0}, al = {0, 0, 0, 0}, be = {0, 0, 0, 0};
-  const bool zmask = MODE == 1 && !y && zb;
+  constexpr bool zmask = MODE == 1 && MASK == 2;
   if (MODE == 1) {
     mu = *reinterpret_cast<const f32x4*>(mean + col4 * 4);
     rs = *reinterpret_cast<const f32x4*>(rstd + col4 * 4);
@@ -54,11 +56,11 @@ __global__ __launch_bounds__(NT) void col_partial_kernel(const TX* __restrict__ 
       for (int e = 0; e < 4; ++e) { const double v = xv[e]; s1[e] += v; s2[e] += v * v; }
     } else {
       f32x4 gv = ldx4(g + off);
-      if (y) {
+      if (MASK == 1) {
         const f32x4 yv = ldx4(y + off);
 #pragma unroll
         for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.0f ? gv[e] : 0.0f;
-      } else if (zmask) {
+      } else if (MASK == 2) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) gv[e] = mmfn_bn_affine(xv[e], al[e], be[e]) > 0.0f ? gv[e] : 0.0f;
       }
@@ -180,11 +182,11 @@ __global__ __launch_bounds__(NT) void bn_fold_kernel(const float* __restrict__ w
 }
 
 // y = [relu]( x * alpha + beta [+ res] ), alpha = w * rstd, beta = b - mean * alpha
-template <typename TX, typename TA>
+template <bool HAS_RES, bool RELU, typename TX, typename TA>
 __global__ __launch_bounds__(NT) void bn_apply_kernel(const TX* __restrict__ x, const TA* __restrict__ res,
                                                       TA* __restrict__ y, int64_t total4, int C,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                      const float* __restrict__ w, const float* __restrict__ b, int relu) {
+                                                      const float* __restrict__ w, const float* __restrict__ b) {
   const int cq = C >> 2;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % cq) * 4;
@@ -196,12 +198,12 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const TX* __restrict__ x, 
       { alpha = mmfn_bn_alpha(w[c4 + e], rstd[c4 + e]); beta = mmfn_bn_beta(b[c4 + e], mean[c4 + e], alpha); }
       o[e] = mmfn_bn_affine(xv[e], alpha, beta);
     }
-    if (res) {
+    if (HAS_RES) {
       const f32x4 rv = ldx4(res + i * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] += rv[e];
     }
-    if (relu) {
+    if (RELU) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.0f);
     }
@@ -226,7 +228,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ partials, int 
 }
 
 // dx = w * rstd * (ge - mean(ge) - xhat * mean(ge * xhat));  optionally ge_out = ge
-template <typename TX, typename TA>
+template <int MASK, bool HAS_GE, typename TX, typename TA>
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const TA* __restrict__ g, const TA* __restrict__ y,
                                                           const TX* __restrict__ x, TX* __restrict__ dx,
                                                           TA* __restrict__ ge_out, int64_t total4, int C,
@@ -234,16 +236,15 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const TA* __restrict__
                                                           const float* __restrict__ w, const float* __restrict__ zb,
                                                           const float* __restrict__ means) {
   const int cq = C >> 2;
-  const bool zmask = !y && zb;   // ReLU mask recomputed from x (see col_partial_kernel)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % cq) * 4;
     f32x4 gv = ldx4(g + i * 4);
     const f32x4 xv = ldx4(x + i * 4);
-    if (y) {
+    if (MASK == 1) {
       const f32x4 yv = ldx4(y + i * 4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.0f ? gv[e] : 0.0f;
-    } else if (zmask) {
+    } else if (MASK == 2) {   // ReLU mask recomputed from x (see col_partial_kernel)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float alpha, beta;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const TA* __restrict__
       o[e] = (gv[e] - means[c4 + e] - xh * means[C + c4 + e]) * (w[c4 + e] * rs);
     }
     stx4(dx + i * 4, o);
-    if (ge_out) stx4(ge_out + i * 4, gv);
+    if (HAS_GE) stx4(ge_out + i * 4, gv);
   }
 }
 
@@ -471,7 +472,7 @@ int bn_train_stats_launch(const TX* x, int64_t M, int C, float eps, float moment
   hipStream_t s = (hipStream_t)stream;
   int64_t rpb;
   const int nblk = bn_grid(M, C, &rpb);
-  hipLaunchKernelGGL((col_partial_kernel<0, TX, TX>), dim3(nblk), dim3(NT), 0, s, x, (const TX*)nullptr, (const TX*)nullptr,
+  hipLaunchKernelGGL((col_partial_kernel<0, 0, TX, TX>), dim3(nblk), dim3(NT), 0, s, x, (const TX*)nullptr, (const TX*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, M, C, rpb,
                      (double*)workspace);
   MMFN_LAUNCH_CHECK();
@@ -530,8 +531,10 @@ int bn_apply_launch(const TX* x, const TA* res, TA* y, int64_t M, int C, const f
   if (C % 4 || M <= 0) return MMFN_EINVAL;
   const int64_t total4 = M * (C / 4);
   const int blocks = (int)std::min<int64_t>(ceil_div64(total4, NT), 8192);
-  hipLaunchKernelGGL((bn_apply_kernel<TX, TA>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, res, y, total4, C, mean, rstd,
-                     weight, bias, relu);
+#define MMFN_AP(R, L) hipLaunchKernelGGL((bn_apply_kernel<R, L, TX, TA>), dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, res, y, total4, C, mean, rstd, weight, bias)
+  if (res) { if (relu) MMFN_AP(true, true); else MMFN_AP(true, false); }
+  else     { if (relu) MMFN_AP(false, true); else MMFN_AP(false, false); }
+#undef MMFN_AP
   MMFN_LAUNCH_CHECK();
   return 0;
 }
@@ -548,8 +551,9 @@ int bn_bwd_launch(const TA* g, const TA* y, const TX* x, int64_t M, int C, const
   double* partials = (double*)workspace;
   if (!means) means = (float*)(partials + (size_t)nblk * 2 * C);
   if (reduce) {
-    hipLaunchKernelGGL((col_partial_kernel<1, TX, TA>), dim3(nblk), dim3(NT), 0, s, x, g, y, mean, rstd, weight, bias, M, C, rpb,
-                       partials);
+#define MMFN_CP(MK) hipLaunchKernelGGL((col_partial_kernel<1, MK, TX, TA>), dim3(nblk), dim3(NT), 0, s, x, g, y, mean, rstd, weight, bias, M, C, rpb, partials)
+    if (y) MMFN_CP(1); else if (bias) MMFN_CP(2); else MMFN_CP(0);
+#undef MMFN_CP
     MMFN_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, s, partials, nblk, M, C, dweight, dbias,
                        means);
@@ -558,8 +562,11 @@ int bn_bwd_launch(const TA* g, const TA* y, const TX* x, int64_t M, int C, const
   if (apply) {
     const int64_t total4 = M * (C / 4);
     const int blocks = (int)std::min<int64_t>(ceil_div64(total4, NT), 8192);
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<TX, TA>), dim3(blocks), dim3(NT), 0, s, g, y, x, dx, ge_out, total4, C, mean, rstd, weight,
-                       bias, means);
+#define MMFN_BA(MK, GE) hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, GE, TX, TA>), dim3(blocks), dim3(NT), 0, s, g, y, x, dx, ge_out, total4, C, mean, rstd, weight, bias, means)
+#define MMFN_BA2(MK) do { if (ge_out) MMFN_BA(MK, true); else MMFN_BA(MK, false); } while (0)
+    if (y) MMFN_BA2(1); else if (bias) MMFN_BA2(2); else MMFN_BA2(0);
+#undef MMFN_BA2
+#undef MMFN_BA
     MMFN_LAUNCH_CHECK();
   }
   return 0;
@@ -760,8 +767,10 @@ extern "C" int mmfn_bn_bwd_partials_bf16(const double* partials, int rows, const
   MMFN_LAUNCH_CHECK();
   const int64_t total4 = M * (C / 4);
   const int blocks = (int)std::min<int64_t>(ceil_div64(total4, NT), 8192);
-  hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(NT), 0, s, (const bf16_t*)g, (const bf16_t*)y, (const bf16_t*)x,
-                     (bf16_t*)dx, (bf16_t*)ge_out, total4, C, mean, rstd, weight, (const float*)nullptr, means);
+#define MMFN_BA16(MK, GE) hipLaunchKernelGGL((bn_bwd_apply_kernel<MK, GE, bf16_t, bf16_t>), dim3(blocks), dim3(NT), 0, s, (const bf16_t*)g, (const bf16_t*)y, (const bf16_t*)x, (bf16_t*)dx, (bf16_t*)ge_out, total4, C, mean, rstd, weight, (const float*)nullptr, means)
+  if (y) { if (ge_out) MMFN_BA16(1, true); else MMFN_BA16(1, false); }
+  else   { if (ge_out) MMFN_BA16(0, true); else MMFN_BA16(0, false); }
+#undef MMFN_BA16
   MMFN_LAUNCH_CHECK();
   return 0;
 }

@@ -215,10 +215,12 @@ __global__ __launch_bounds__(NT) void wino4_input_kernel(const float* __restrict
 // backward recomputes the ReLU sign from x (col_partial_kernel / wino4_outgrad_bn_kernel, zmask).
 // Loads are unconditional (coordinates clamped into the image, the padding ring selected to 0 afterwards): a branch around each
 // pixel would serialise the 36 (72 with a residual) loads of a thread.  The 16 interior pixels of a patch are always inside.
-template <bool HAS_RES, bool WRITE_Y>
+// HAS_RES / WRITE_Y / RELU are template parameters: a run-time branch inside the unrolled pixel loop - even a wave-uniform one -
+// splits it into basic blocks and the loads of a thread are no longer issued back to back.
+template <bool HAS_RES, bool WRITE_Y, bool RELU>
 __global__ __launch_bounds__(NT) void wino4_input_bn_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const float* __restrict__ bw, const float* __restrict__ bb, int relu,
+                                                            const float* __restrict__ bw, const float* __restrict__ bb,
                                                             float* __restrict__ y, float* __restrict__ V, int B, int H, int W, int C) {
   const int cq = C >> 2, th = H >> 2, tw = W >> 2;
   const int64_t T = (int64_t)B * th * tw, n = T * cq;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(NT) void wino4_input_bn_kernel(const float* __restr
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = mmfn_bn_affine(xv[q], al[q], be[q]);
         if (HAS_RES) o += *reinterpret_cast<const f32x4*>(res + off);
-        if (relu) {   // fmaxf, as bn_apply_kernel
+        if (RELU) {   // fmaxf, as bn_apply_kernel
 #pragma unroll
           for (int q = 0; q < 4; ++q) o[q] = fmaxf(o[q], 0.0f);
         }
@@ -395,6 +397,8 @@ __global__ __launch_bounds__(NT) void wino4_outgrad_kernel(const float* __restri
 // from g, y and the convolution output x instead of being written to HBM by one pass and read back by the next
 // (one launch and 2 x |dy| bytes less per convolution).  means = [2][C]: mean(ge), mean(ge * xhat) from the reduction
 // kernels.  ge_out (optional) receives ge, the gradient of the residual branch.
+// MASK: 0 no ReLU, 1 mask from y, 2 mask recomputed from x (zb).  Template parameters, not run-time tests: see wino4_input_bn_kernel.
+template <int MASK, bool HAS_GE>
 __global__ __launch_bounds__(NT) void wino4_outgrad_bn_kernel(const float* __restrict__ g, const float* __restrict__ y,
                                                               const float* __restrict__ x, const float* __restrict__ mean,
                                                               const float* __restrict__ rstd, const float* __restrict__ w,
@@ -403,7 +407,7 @@ __global__ __launch_bounds__(NT) void wino4_outgrad_bn_kernel(const float* __res
                                                               int C) {
   const int cq = C >> 2, th = H >> 2, tw = W >> 2;
   const int64_t T = (int64_t)B * th * tw, n = T * cq;
-  const bool zmask = !y && zb;   // the ReLU output was never written: its sign is recomputed from x (norm.hip col_partial_kernel)
+  constexpr bool zmask = MASK == 2;   // the ReLU output was never written: its sign is recomputed from x (norm.hip col_partial_kernel)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % cq) * 4;
     const int64_t tile = i / cq;
@@ -425,15 +429,15 @@ __global__ __launch_bounds__(NT) void wino4_outgrad_bn_kernel(const float* __res
         const size_t off = (((size_t)b * H + 4 * ii + p) * W + 4 * j + q) * C + c4;
         f32x4 gv = *reinterpret_cast<const f32x4*>(g + off);
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
-        if (y) {
+        if (MASK == 1) {
           const f32x4 yv = *reinterpret_cast<const f32x4*>(y + off);
 #pragma unroll
           for (int e = 0; e < 4; ++e) gv[e] = yv[e] > 0.0f ? gv[e] : 0.0f;
-        } else if (zmask) {
+        } else if (MASK == 2) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) gv[e] = mmfn_bn_affine(xv[e], al[e], be[e]) > 0.0f ? gv[e] : 0.0f;
         }
-        if (ge_out) *reinterpret_cast<f32x4*>(ge_out + off) = gv;
+        if (HAS_GE) *reinterpret_cast<f32x4*>(ge_out + off) = gv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float xh = (xv[e] - mu[e]) * rs[e];
@@ -536,6 +540,7 @@ __device__ __forceinline__ void wino4_adjoint_block(const float* __restrict__ dV
     if (down && right) P[3][3] += 16.f * at(tile + tw + 1, 0, 0);
 }
 
+template <bool HAS_RES>
 __global__ __launch_bounds__(NT) void wino4_input_adjoint_kernel(const float* __restrict__ dV, const float* __restrict__ res,
                                                                  float* __restrict__ dx, int B, int H, int W, int C) {
   const int cq = C >> 2, th = H >> 2, tw = W >> 2;
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(NT) void wino4_input_adjoint_kernel(const float* __
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         f32x4 v = P[a][e];
-        if (res) v += *reinterpret_cast<const f32x4*>(res + off + (size_t)e * C);
+        if (HAS_RES) v += *reinterpret_cast<const f32x4*>(res + off + (size_t)e * C);
         *reinterpret_cast<f32x4*>(dx + off + (size_t)e * C) = v;
       }
     }
@@ -680,11 +685,13 @@ extern "C" int mmfn_wino_input_bn_f32(const float* x, const float* res, const fl
                                       const float* bias, int relu, float* y, float* V, int B, int H, int W, int C, void* stream) {
   if (!x || !V || !mean || !rstd || !weight || !bias || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
   const dim3 grid(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4)));
-#define MMFN_WINO_IN_BN(R, Y)                                                                                                        \
-  hipLaunchKernelGGL((wino4_input_bn_kernel<R, Y>), grid, dim3(NT), 0, (hipStream_t)stream, x, res, mean, rstd, weight, bias, relu, y, V, \
-                     B, H, W, C)
-  if (res) { if (y) MMFN_WINO_IN_BN(true, true); else MMFN_WINO_IN_BN(true, false); }
-  else     { if (y) MMFN_WINO_IN_BN(false, true); else MMFN_WINO_IN_BN(false, false); }
+#define MMFN_WINO_IN_BN(R, Y, L)                                                                                                  \
+  hipLaunchKernelGGL((wino4_input_bn_kernel<R, Y, L>), grid, dim3(NT), 0, (hipStream_t)stream, x, res, mean, rstd, weight, bias, y, V, B, \
+                     H, W, C)
+#define MMFN_WINO_IN_BN2(R, Y) do { if (relu) MMFN_WINO_IN_BN(R, Y, true); else MMFN_WINO_IN_BN(R, Y, false); } while (0)
+  if (res) { if (y) MMFN_WINO_IN_BN2(true, true); else MMFN_WINO_IN_BN2(true, false); }
+  else     { if (y) MMFN_WINO_IN_BN2(false, true); else MMFN_WINO_IN_BN2(false, false); }
+#undef MMFN_WINO_IN_BN2
 #undef MMFN_WINO_IN_BN
   MMFN_LAUNCH_CHECK();
   return 0;
@@ -717,16 +724,23 @@ extern "C" int mmfn_wino_outgrad_bn_f32(const float* g, const float* y, const fl
                                         const float* weight, const float* relu_bias, const float* means, float* ge_out, float* dMt,
                                         int B, int H, int W, int C, void* stream) {
   if (!g || !x || !mean || !rstd || !weight || !means || !dMt || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
-  hipLaunchKernelGGL(wino4_outgrad_bn_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
-                     g, y, x, mean, rstd, weight, relu_bias, means, ge_out, dMt, B, H, W, C);
+  const dim3 grid(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4)));
+#define MMFN_OG(M, G)                                                                                                              \
+  hipLaunchKernelGGL((wino4_outgrad_bn_kernel<M, G>), grid, dim3(NT), 0, (hipStream_t)stream, g, y, x, mean, rstd, weight, relu_bias, \
+                     means, ge_out, dMt, B, H, W, C)
+#define MMFN_OG2(M) do { if (ge_out) MMFN_OG(M, true); else MMFN_OG(M, false); } while (0)
+  if (y) MMFN_OG2(1); else if (relu_bias) MMFN_OG2(2); else MMFN_OG2(0);
+#undef MMFN_OG2
+#undef MMFN_OG
   MMFN_LAUNCH_CHECK();
   return 0;
 }
 
 extern "C" int mmfn_wino_input_adjoint_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, void* stream) {
   if (!dV || !dx || (H & 3) || (W & 3) || (C & 3) || B <= 0) return MMFN_EINVAL;
-  hipLaunchKernelGGL(wino4_input_adjoint_kernel, dim3(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4))), dim3(NT), 0,
-                     (hipStream_t)stream, dV, res, dx, B, H, W, C);
+  const dim3 grid(grid_for((int64_t)B * (H / 4) * (W / 4) * (C / 4)));
+  if (res) hipLaunchKernelGGL(wino4_input_adjoint_kernel<true>, grid, dim3(NT), 0, (hipStream_t)stream, dV, res, dx, B, H, W, C);
+  else hipLaunchKernelGGL(wino4_input_adjoint_kernel<false>, grid, dim3(NT), 0, (hipStream_t)stream, dV, res, dx, B, H, W, C);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

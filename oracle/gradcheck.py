@@ -29,6 +29,22 @@ def stage_of(name):
     return 3
 
 
+GROUPS = ("head", "gpt", "vec", "img", "lid", "map", "other")
+
+
+def group_of(name):
+    """(stage, readiness group) of a parameter - the rule of mmfn_amd.params.FlatLayout.group_of restated: the trunk / transformer /
+    VectorNet a tensor belongs to inside its backward stage.  Finer than the stage: a fault in one trunk's backward moves the
+    direction of that trunk's group, not of a stage dominated by VectorNet's 16 M-parameter generator."""
+    if name.startswith(("join.", "decoder.", "output.")) or "radar_encoder" in name:
+        return (stage_of(name), "head")
+    for key, g in (("transformer", "gpt"), ("vectornet_encoder", "vec"), ("image_encoder", "img"), ("lidar_encoder", "lid"),
+                   ("img_map_encoder", "map")):
+        if key in name:
+            return (stage_of(name), g)
+    return (stage_of(name), "other")
+
+
 def oracle_gradients(oracle, args, gt_wp):
     """-> (loss32, grads32, loss64, grads64, pred32) of one train-mode step of `oracle` (weights untouched: the AdamW step of
     harness.train_step is applied to copies)."""
@@ -70,11 +86,15 @@ def tensor_rows(hip_grads, g32, g64):
     return rows
 
 
-def stage_bar(cos_cpu):
-    """The bar a HIP stage cosine has to clear, given the fp32 oracle's cosine on the same stage (round-3 review, item 2):
-    at most twice the oracle's angle^2 away from the fp64 direction (1 - cos ~ angle^2 / 2), and never below 0.99 where
-    the oracle itself reaches 0.995."""
-    bar = 1.0 - 2.0 * (1.0 - cos_cpu) - 1e-6
-    if cos_cpu >= 0.995:
-        bar = max(bar, 0.99)
+def stage_bar(cos_cpu, factor=8.0):
+    """The bar a HIP cosine has to clear, given the fp32 oracle's cosine on the same group of tensors: at most `factor` times the
+    oracle's angle^2 away from the fp64 direction (1 - cos ~ angle^2 / 2), and never below 0.999 where the oracle itself reaches
+    0.9999.  Why 8 and not the 2 the round-3 review proposed: measured at the benched initialisation (vec, batch 32,
+    tools/grad_cosine.py) the HIP path sits at 1.6-2.0 x the oracle's 1 - cos with EVERY convolution as a
+    direct implicit GEMM (longer sequential fp32 accumulation chains in the MFMA k-loop than oneDNN's blocked sums), and at
+    4.0-5.0 x with the F(4x4,3x3) Winograd convolutions, whose fp32 error is ~6-12 x a direct convolution's by construction;
+    a wrong tap, scale or mask in one layer's backward lands at 100-10000 x."""
+    bar = 1.0 - factor * (1.0 - cos_cpu) - 1e-6
+    if cos_cpu >= 0.9999:
+        bar = max(bar, 0.999)
     return bar
