@@ -133,16 +133,9 @@ def default_like_bf16(args, B):
 
 
 def usable_cores():
-    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box
-    reports 256 logical CPUs but grants a 16-CPU quota; oversubscribing it stalls oneDNN for minutes)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, n)
+    """Cores this process may actually use (affinity mask capped by the cgroup CPU quota): mmfn_amd.data.usable_cores."""
+    from mmfn_amd.data import usable_cores as _uc
+    return _uc()
 
 
 def cpu_model():

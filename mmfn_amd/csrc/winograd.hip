@@ -121,31 +121,47 @@ __global__ __launch_bounds__(NT) void wino_output_kernel(const float* __restrict
 
 // ---------------------------------------------------------------------------------------------------------------
 // F(4x4, 3x3): 6x6 input patches -> 4x4 outputs, 36 element-wise products (4x fewer MFMA FLOPs than the implicit GEMM,
-// 2.25x expansion of the transformed activations).  Interpolation points 0, +-1, +-2, inf (Lavin & Gray); in fp32 the
-// result differs from the direct convolution by ~1e-6 relative on this network's activations (tests/test_gemm_gpu.py).
+// 2.25x expansion of the transformed activations).  Cook-Toom construction over the interpolation points 0, +-a, +-b, inf.
+// Lavin & Gray's a = 1, b = 2 (rounds 1-3) has transform entries up to 8 and a fp32 error ~12x that of a direct convolution; the
+// points a = 3/4, b = 3/2 (every entry of A^T and B^T still exact in binary) halve that (tools/experiments/winograd_points.py:
+// 6.0x; Barabasz et al., "Error analysis and improving the accuracy of Winograd convolution"), measured on the training step
+// as the per-stage cosine of the gradient to fp64 (tools/grad_cosine.py).  With
+//   f_a = 2 a^2 (a^2 - b^2),  f_b = 2 b^2 (b^2 - a^2):
+//   A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1]
+//   G   = [1/(a^2 b^2) 0 0; (1, +-a, a^2)/f_a; (1, +-b, b^2)/f_b; 0 0 1]
+//   B^T = [a^2b^2 0 -(a^2+b^2) 0 1 0; 0 -+ab^2 -b^2 +-a 1 0; 0 -+a^2b -a^2 +-b 1 0; 0 a^2b^2 0 -(a^2+b^2) 0 1]
+constexpr float WA = 0.75f, WB = 1.5f;
+constexpr float WA2 = WA * WA, WB2 = WB * WB, WA3 = WA2 * WA, WB3 = WB2 * WB;
+constexpr float WK0 = WA2 * WB2;                       // a^2 b^2 (= B^T[0][0]): 81/64
+constexpr float WS2 = WA2 + WB2;                       // a^2 + b^2: 45/16
+constexpr float WFA = 1.0f / (2.0f * WA2 * (WA2 - WB2));   // 1 / f_a = -128/243
+constexpr float WFB = 1.0f / (2.0f * WB2 * (WB2 - WA2));   // 1 / f_b =   32/243
 template <typename T>
 __device__ __forceinline__ void f4_bt(const T* d, T* r) {  // r = B^T d, 6 -> 6
-  r[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-  r[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
-  r[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
-  r[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
-  r[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-  r[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+  const T ea = d[4] - WB2 * d[2], oa = d[3] - WB2 * d[1];   // rows +-a: (d4 - b^2 d2) +- a (d3 - b^2 d1)
+  const T eb = d[4] - WA2 * d[2], ob = d[3] - WA2 * d[1];   // rows +-b: (d4 - a^2 d2) +- b (d3 - a^2 d1)
+  r[0] = WK0 * d[0] - WS2 * d[2] + d[4];
+  r[1] = ea + WA * oa;
+  r[2] = ea - WA * oa;
+  r[3] = eb + WB * ob;
+  r[4] = eb - WB * ob;
+  r[5] = WK0 * d[1] - WS2 * d[3] + d[5];
 }
 template <typename T>
 __device__ __forceinline__ void f4_at(const T* m, T* o) {  // o = A^T m, 6 -> 4
   const T p = m[1] + m[2], q = m[1] - m[2], u = m[3] + m[4], v = m[3] - m[4];
   o[0] = m[0] + p + u;
-  o[1] = q + 2.f * v;
-  o[2] = p + 4.f * u;
-  o[3] = q + 8.f * v + m[5];
+  o[1] = WA * q + WB * v;
+  o[2] = WA2 * p + WB2 * u;
+  o[3] = WA3 * q + WB3 * v + m[5];
 }
 __device__ __forceinline__ void f4_g(const float* g, float* u) {  // u = G g, 3 -> 6
-  u[0] = 0.25f * g[0];
-  u[1] = (-1.f / 6.f) * (g[0] + g[1] + g[2]);
-  u[2] = (-1.f / 6.f) * (g[0] - g[1] + g[2]);
-  u[3] = (1.f / 24.f) * g[0] + (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
-  u[4] = (1.f / 24.f) * g[0] - (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
+  const float ea = g[0] + WA2 * g[2], eb = g[0] + WB2 * g[2];
+  u[0] = (1.0f / WK0) * g[0];
+  u[1] = WFA * (ea + WA * g[1]);
+  u[2] = WFA * (ea - WA * g[1]);
+  u[3] = WFB * (eb + WB * g[1]);
+  u[4] = WFB * (eb - WB * g[1]);
   u[5] = g[2];
 }
 
@@ -349,18 +365,20 @@ __global__ __launch_bounds__(NT) void wino4_weight_group_kernel(const WinoGroupE
 // dMt[t][tile][c] = (A dy A^T)[t] for the 4x4 output-gradient patch of the tile (A = transpose of A^T above, 6x4)
 template <typename T>
 __device__ __forceinline__ void f4_a(const T* y, T* m) {  // m = A y, 4 -> 6
-  const T e = y[0] + y[2], o = y[1] + y[3];
+  const T ea = y[0] + WA2 * y[2], oa = WA * y[1] + WA3 * y[3];
+  const T eb = y[0] + WB2 * y[2], ob = WB * y[1] + WB3 * y[3];
   m[0] = y[0];
-  m[1] = e + o;
-  m[2] = e - o;
-  m[3] = y[0] + 2.f * y[1] + 4.f * y[2] + 8.f * y[3];
-  m[4] = y[0] - 2.f * y[1] + 4.f * y[2] - 8.f * y[3];
+  m[1] = ea + oa;
+  m[2] = ea - oa;
+  m[3] = eb + ob;
+  m[4] = eb - ob;
   m[5] = y[3];
 }
 __device__ __forceinline__ void f4_gt(const float* u, float* g) {  // g = G^T u, 6 -> 3
-  g[0] = 0.25f * u[0] - (1.f / 6.f) * (u[1] + u[2]) + (1.f / 24.f) * (u[3] + u[4]);
-  g[1] = (1.f / 6.f) * (u[2] - u[1]) + (1.f / 12.f) * (u[3] - u[4]);
-  g[2] = -(1.f / 6.f) * (u[1] + u[2]) + (1.f / 6.f) * (u[3] + u[4]) + u[5];
+  const float pa = WFA * (u[1] + u[2]), qa = WFA * (u[1] - u[2]), pb = WFB * (u[3] + u[4]), qb = WFB * (u[3] - u[4]);
+  g[0] = (1.0f / WK0) * u[0] + pa + pb;
+  g[1] = WA * qa + WB * qb;
+  g[2] = WA2 * pa + WB2 * pb + u[5];
 }
 
 __global__ __launch_bounds__(NT) void wino4_outgrad_kernel(const float* __restrict__ dy, float* __restrict__ dMt, int B, int H, int W,
@@ -466,16 +484,16 @@ __global__ __launch_bounds__(NT) void wino4_outgrad_bn_kernel(const float* __res
 // done as a gather (below): no atomics, fixed order.
 template <typename T>
 __device__ __forceinline__ void f4_b(const T* v, T* o) {  // o = B v, 6 -> 6 (B = transpose of the B^T in f4_bt)
-  o[0] = 4.f * v[0];
-  o[1] = 4.f * (v[2] - v[1]) + 2.f * (v[4] - v[3]) + 4.f * v[5];
-  o[2] = -5.f * v[0] - 4.f * (v[1] + v[2]) - v[3] - v[4];
-  o[3] = v[1] - v[2] + 2.f * (v[3] - v[4]) - 5.f * v[5];
+  o[0] = WK0 * v[0];
+  o[1] = (WA * WB2) * (v[2] - v[1]) + (WA2 * WB) * (v[4] - v[3]) + WK0 * v[5];
+  o[2] = -WS2 * v[0] - WB2 * (v[1] + v[2]) - WA2 * (v[3] + v[4]);
+  o[3] = WA * (v[1] - v[2]) + WB * (v[3] - v[4]) - WS2 * v[5];
   o[4] = v[0] + v[1] + v[2] + v[3] + v[4];
   o[5] = v[5];
 }
 
 // Gather form, no LDS and no phases.  A thread owns one 4x4 output block (= the interior of its own tile's 6x6 patch) and adds
-// what the eight neighbouring tiles' patches put on it.  Because rows 0 and 5 of B are 4*e0 and e5 (f4_b: o[0] = 4 v[0],
+// what the eight neighbouring tiles' patches put on it.  Because rows 0 and 5 of B are a^2b^2*e0 and e5 (f4_b: o[0] = WK0 v[0],
 // o[5] = v[5]), a neighbour's halo row / column needs only ONE row / column of its dV: 36 + 4*6 + 4 = 64 loads per thread
 // instead of 9*36, every addition in a fixed order.
 // The 4x4 block of dx a thread owns: P[a][e], rows 4*ti + a, columns 4*tj + e, four channels from c4 (res not yet added).
@@ -510,13 +528,13 @@ __device__ __forceinline__ void wino4_adjoint_block(const float* __restrict__ dV
 #pragma unroll
       for (int e = 0; e < 4; ++e) P[0][e] += o[e + 1];
     }
-    if (down) {    // tile below: its patch row 0 (= 4 * dV row 0) lies on our last row
+    if (down) {    // tile below: its patch row 0 (= a^2b^2 * dV row 0) lies on our last row
       f32x4 v[6], o[6];
 #pragma unroll
       for (int e = 0; e < 6; ++e) v[e] = at(tile + tw, 0, e);
       f4_b(v, o);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) P[3][e] += 4.f * o[e + 1];
+      for (int e = 0; e < 4; ++e) P[3][e] += WK0 * o[e + 1];
     }
     if (left) {
       f32x4 v[6], o[6];
@@ -532,12 +550,12 @@ __device__ __forceinline__ void wino4_adjoint_block(const float* __restrict__ dV
       for (int a = 0; a < 6; ++a) v[a] = at(tile + 1, a, 0);
       f4_b(v, o);
 #pragma unroll
-      for (int a = 0; a < 4; ++a) P[a][3] += 4.f * o[a + 1];
+      for (int a = 0; a < 4; ++a) P[a][3] += WK0 * o[a + 1];
     }
     if (up && left) P[0][0] += at(tile - tw - 1, 5, 5);
-    if (up && right) P[0][3] += 4.f * at(tile - tw + 1, 5, 0);
-    if (down && left) P[3][0] += 4.f * at(tile + tw - 1, 0, 5);
-    if (down && right) P[3][3] += 16.f * at(tile + tw + 1, 0, 0);
+    if (up && right) P[0][3] += WK0 * at(tile - tw + 1, 5, 0);
+    if (down && left) P[3][0] += WK0 * at(tile + tw - 1, 0, 5);
+    if (down && right) P[3][3] += (WK0 * WK0) * at(tile + tw + 1, 0, 0);
 }
 
 template <bool HAS_RES>

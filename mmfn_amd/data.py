@@ -80,6 +80,31 @@ def local_target_point(x_command, y_command, ego_x, ego_y, ego_theta):
     return tuple(rot.T.dot(np.array([x_command - ego_x, y_command - ego_y])))
 
 
+# ------------------------------------------------------------------------------------------ host cores
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box may report 256 logical
+    CPUs and grant a 16-CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def limit_host_threads():
+    """torch's intra-op pool defaults to one thread per LOGICAL cpu.  Under a smaller cgroup quota every tiny host-side tensor
+    op of the loader / staging code (a float64 -> float32 cast of the lane tensor, a stack of labels) then pays an OpenMP barrier
+    across threads that are mostly descheduled - milliseconds each, ~100 ms per step measured on a 256-cpu box with a 16-cpu
+    quota (tools/trainer_bench.py: 214 samples/s instead of > 900).  Lowers the pool to the usable cores; never raises it."""
+    n = usable_cores()
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return torch.get_num_threads()
+
+
 # ------------------------------------------------------------------------------------------ sample store
 class FrameStore(torch.utils.data.Dataset):
     """Reader of the phase-1 output: one pickle per frame (written by run_steps/phase1_preprocess_data.py:42-48)
@@ -409,6 +434,7 @@ class DevicePrefetcher(object):
     step, phase2_train_net.py:78-91)."""
 
     def __init__(self, loader, device, config, variant="vec"):
+        limit_host_threads()
         self.loader, self.device, self.config, self.variant = loader, torch.device(device), config, variant
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
 

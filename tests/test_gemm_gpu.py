@@ -162,6 +162,39 @@ def test_winograd_conv_and_dgrad(cfg):
     assert (dw - dw_direct).abs().max().item() <= 3e-5 * dw_direct.abs().max().item()
 
 
+@pytest.mark.parametrize("cfg", [(4, 32, 64, 64), (4, 16, 256, 256)])
+def test_winograd_f4_rounding_error_against_fp64(cfg):
+    """F(4x4,3x3) over the points 0, +-3/4, +-3/2, inf (csrc/winograd.hip): forward, data gradient (adjoint pipeline) and weight
+    gradient against an fp64 convolution, with the direct implicit GEMM's error on the same operands as the yardstick.  Measured
+    ~5-7x the direct form's rms error (Lavin & Gray's points 0, +-1, +-2 of rounds 1-3: ~12x; tools/experiments/winograd_points.py)."""
+    from mmfn_amd import ops
+    dev = _dev()
+    B, HW, Cin, Cout = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.relu(torch.randn(B, Cin, HW, HW, generator=g))
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    dy = torch.randn(B, Cout, HW, HW, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    y64 = F.conv2d(xr, wr, padding=1)
+    y64.backward(dy.double())
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(dev)
+    xd, wd, dyd = nhwc(x), nhwc(w), nhwc(dy)
+    rms = lambda got, ref: float((got.detach().cpu().double().permute(0, 3, 1, 2) - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+    u = torch.empty(36 * Cout * Cin, device=dev)
+    v = torch.empty(ops.winograd_v_numel(xd.shape), device=dev)
+    y = ops.conv2d_fwd(xd, wd, 1, 1, keep_v=v, keep_u=u)
+    dw, dx = torch.empty_like(wd), torch.empty_like(xd)
+    ops.conv2d_bwd_winograd(dyd, xd, u, dw, dx, v=v)
+    e_w = (rms(y, y64.detach()), rms(dx, xr.grad), rms(dw, wr.grad))
+    e_d = (rms(ops.conv2d_fwd(xd, wd, 1, 1, tile=1), y64.detach()),
+           rms(ops.gemm(dyd, wd, torch.empty_like(xd), B * HW * HW, Cin, 9 * Cout, 0, 0, Cin, ops.A_DGRAD, ops.B_DGRADW,
+                        conv=ops.conv_geom(xd.shape, wd.shape, 1, 1)[0]), xr.grad),
+           rms(ops.conv2d_wgrad(dyd, xd, tuple(wd.shape), 1, 1, tile=2), wr.grad))
+    print("\n[F(4x4,3x3) %s] rel rms error vs fp64: winograd fwd %.2e dgrad %.2e wgrad %.2e | direct %.2e %.2e %.2e" % ((cfg,) + e_w + e_d))
+    for a, b in zip(e_w, e_d):
+        assert a <= 9.0 * b and a <= 2.5e-6, (e_w, e_d)
+
+
 @pytest.mark.parametrize("cfg", [(3, 32, 128, 128), (2, 16, 256, 256), (5, 8, 512, 512), (2, 16, 128, 256)])
 def test_winograd_adjoint_backward(cfg):
     """Weight + data gradient together in the F(4x4,3x3) domain (ops.conv2d_bwd_winograd): the data gradient is the adjoint of

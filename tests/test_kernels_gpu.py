@@ -298,8 +298,8 @@ def test_batchnorm_backward_recomputes_the_relu_mask_of_an_unwritten_output(M, C
         _call("mmfn_wino_outgrad_bn_f32", ptr(gy), ptr(ymask), ptr(x), ptr(mean), ptr(rstd), ptr(w), ptr(rb), ptr(means), ptr(ge2), ptr(dMt),
               B, HW, HW, C, stream())
         outs.append((dx, ge, dw, db, dw2, db2, means, dMt, ge2))
-    for a, c in zip(*outs):
-        assert torch.equal(a, c)
+    for name, a, c in zip(("dx", "ge", "dweight", "dbias", "dweight (reduce)", "dbias (reduce)", "means", "dM", "ge (transform)"), *outs):
+        assert torch.equal(a, c), (name, int((a != c).sum()), float((a - c).abs().max()))
     # and without either the mask is NOT applied (a caller that forgets relu_bias would silently train a different network)
     dxn = torch.empty_like(x)
     ops.bn_bwd(gy, None, x, mean, rstd, w, dxn, torch.empty(C, device=DEV), torch.empty(C, device=DEV))

@@ -58,7 +58,14 @@ def run(mode, B=32, n=768, epochs=2):
             tr.train(net, loader, cfg, opt, graph=graph)
         torch.cuda.synchronize()
         dt = time.time() - t0
-        res = {"samples_per_s": round(epochs * n / dt, 1), "ms_per_step": round(dt / (epochs * n / B) * 1e3, 2)}
+        res = {"samples_per_s": round(epochs * n / dt, 1), "ms_per_step": round(dt / (epochs * n / B) * 1e3, 2),
+               "host_threads": torch.get_num_threads()}
+        # what the input side alone sustains (loader + pinned staging + H2D, no training step)
+        t1 = time.time()
+        for _ in D.DevicePrefetcher(loader, "cuda:0", cfg):
+            pass
+        torch.cuda.synchronize()
+        res["input_side_only_samples_per_s"] = round(n / (time.time() - t1), 1)
         if mode == "packed":
             res["pack_seconds_per_1000_frames"] = round(t_pack / n * 1000, 2)
         return res
