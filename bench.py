@@ -294,49 +294,8 @@ def pin_rank(local_rank, world, gpu_index):
 
 
 def all_ranks_agree(dist, dev, ok):
-    """Logical AND of `ok` over the ranks (through the launcher's process group)."""
-    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return bool(int(t.item()))
-
-
-def open_capi_transport(rank, world, dist, dev, required=False, timeout_s=120.0):
-    """RCCL communicator through the C ABI + a self-test (sum of rank ids over a 1 MiB bucket on a side stream); every rank
-    must pass, else all of them use torch.distributed.  The init runs in a helper thread so that a communicator that never
-    comes up costs `timeout_s`, not the run.  Returns (RcclComm or None, note)."""
-    import threading
-    box = {}
-
-    def attempt():
-        try:
-            from mmfn_amd.comm import RcclComm
-            torch.cuda.set_device(dev)
-            c = RcclComm(rank, world, dist=dist)
-            x = torch.full((1 << 18,), float(rank + 1), dtype=torch.float32, device=dev)
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream())
-            c.all_reduce_sum_(x, stream=side)
-            side.synchronize()
-            expect = world * (world + 1) / 2.0
-            if float(x.min().item()) != expect or float(x.max().item()) != expect or c.ranks() != (world, rank):
-                raise RuntimeError("self-test all-reduce returned %r..%r, expected %r" % (float(x.min()), float(x.max()), expect))
-            box["comm"] = c
-        except BaseException as exc:   # a missing library, an RCCL error code, a wrong sum: all mean "use torch.distributed"
-            box["error"] = "%s: %s" % (type(exc).__name__, exc)
-
-    th = threading.Thread(target=attempt, daemon=True)
-    th.start()
-    th.join(timeout_s)
-    if th.is_alive():
-        box.setdefault("error", "communicator did not come up within %.0f s" % timeout_s)
-    ok = "comm" in box
-    if not all_ranks_agree(dist, dev, ok):
-        if required:
-            raise SystemExit("MMFN_DP_TRANSPORT=capi: C-ABI transport unavailable on rank %d: %s" % (rank, box.get("error", "another rank failed")))
-        if rank == 0:
-            sys.stderr.write("C-ABI RCCL transport not used (%s); falling back to torch.distributed\n" % box.get("error", "another rank failed"))
-        return None, "fallback: " + box.get("error", "another rank failed")
-    return box["comm"], None
+    from mmfn_amd.comm import all_ranks_agree as _f
+    return _f(dist, dev, ok)
 
 
 def main():
@@ -422,18 +381,14 @@ def main():
     several_frames = (args.seq_len, args.n_views) != (1, 1)
     if several_frames:   # the oracle check and the CPU baseline below are wired for the one-frame workloads
         args.no_oracle_check = args.no_cpu_baseline = True
-    comm_capi, transport_note = None, None
-    want = os.environ.get("MMFN_DP_TRANSPORT", "auto")   # auto | capi | torch
-    if world > 1 and want != "torch":
+    comm_capi, transport_note, dp = None, None, None
+    if world > 1:
         # gradient buckets through the C ABI (libmmfn_comm.so -> RCCL on our own stream: capturable, so the whole data-parallel
         # step is ONE hipGraph) whenever the library loads and its communicator passes a self-test on every rank; otherwise
-        # torch's ProcessGroup with the step cut at the bucket boundaries
-        if want == "auto" and os.environ.get("MMFN_BENCH_SINGLE_DEVICE"):
-            transport_note = "single-device CI run: RCCL refuses two ranks on one GPU, torch.distributed (gloo) instead"
-        else:
-            comm_capi, transport_note = open_capi_transport(rank, world, dist, dev, required=(want == "capi"))
-    dp = DataParallel(net, dist, comm=comm_capi) if world > 1 else None
-    if dp is not None:
+        # torch's ProcessGroup with the step cut at the bucket boundaries (mmfn_amd.parallel.connect; MMFN_DP_TRANSPORT)
+        from mmfn_amd.parallel import connect
+        dp, transport_note = connect(net, dist)
+        comm_capi = dp.comm
         dp.broadcast_parameters()
     eng = net._engine_for()
     if args.single_stream:

@@ -93,3 +93,51 @@ class RcclComm(object):
         if self._comm:
             lib().mmfn_comm_destroy(self._comm)
             self._comm = ctypes.c_void_p()
+
+
+def all_ranks_agree(dist, dev, ok):
+    """Logical AND of `ok` over the ranks (through the launcher's process group)."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def open_transport(rank, world, dist, dev, required=False, timeout_s=120.0):
+    """RCCL communicator through the C ABI + a self-test (sum of rank ids over a 1 MiB bucket on a side stream); every rank
+    must pass, else all of them use torch.distributed.  The init runs in a helper thread so that a communicator that never
+    comes up costs `timeout_s`, not the run.  Returns (RcclComm or None, note); required=True raises MMFNCommError instead of
+    falling back."""
+    import sys
+    import threading
+    box = {}
+
+    def attempt():
+        try:
+            torch.cuda.set_device(dev)
+            c = RcclComm(rank, world, dist=dist)
+            x = torch.full((1 << 18,), float(rank + 1), dtype=torch.float32, device=dev)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            c.all_reduce_sum_(x, stream=side)
+            side.synchronize()
+            expect = world * (world + 1) / 2.0
+            if float(x.min().item()) != expect or float(x.max().item()) != expect or c.ranks() != (world, rank):
+                raise RuntimeError("self-test all-reduce returned %r..%r, expected %r" % (float(x.min()), float(x.max()), expect))
+            box["comm"] = c
+        except BaseException as exc:   # a missing library, an RCCL error code, a wrong sum: all mean "use torch.distributed"
+            box["error"] = "%s: %s" % (type(exc).__name__, exc)
+
+    th = threading.Thread(target=attempt, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        box.setdefault("error", "communicator did not come up within %.0f s" % timeout_s)
+    ok = "comm" in box
+    if not all_ranks_agree(dist, dev, ok):
+        why = box.get("error", "another rank failed")
+        if required:
+            raise MMFNCommError("C-ABI transport required but unavailable on rank %d: %s" % (rank, why))
+        if rank == 0:
+            sys.stderr.write("C-ABI RCCL transport not used (%s); falling back to torch.distributed\n" % why)
+        return None, "fallback: " + why
+    return box["comm"], None

@@ -130,7 +130,11 @@ __global__ __launch_bounds__(NT) void wino_output_kernel(const float* __restrict
 //   A^T = [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1]
 //   G   = [1/(a^2 b^2) 0 0; (1, +-a, a^2)/f_a; (1, +-b, b^2)/f_b; 0 0 1]
 //   B^T = [a^2b^2 0 -(a^2+b^2) 0 1 0; 0 -+ab^2 -b^2 +-a 1 0; 0 -+a^2b -a^2 +-b 1 0; 0 a^2b^2 0 -(a^2+b^2) 0 1]
-constexpr float WA = 0.75f, WB = 1.5f;
+#ifndef MMFN_WINO_A   // (ablation builds: -DMMFN_WINO_A=1.0f -DMMFN_WINO_B=2.0f is Lavin & Gray's set, tools/experiments/r4_points_ab.sh)
+#define MMFN_WINO_A 0.75f
+#define MMFN_WINO_B 1.5f
+#endif
+constexpr float WA = MMFN_WINO_A, WB = MMFN_WINO_B;
 constexpr float WA2 = WA * WA, WB2 = WB * WB, WA3 = WA2 * WA, WB3 = WB2 * WB;
 constexpr float WK0 = WA2 * WB2;                       // a^2 b^2 (= B^T[0][0]): 81/64
 constexpr float WS2 = WA2 + WB2;                       // a^2 + b^2: 45/16
@@ -456,10 +460,16 @@ __global__ __launch_bounds__(NT) void wino4_outgrad_bn_kernel(const float* __res
           for (int e = 0; e < 4; ++e) gv[e] = mmfn_bn_affine(xv[e], al[e], be[e]) > 0.0f ? gv[e] : 0.0f;
         }
         if (HAS_GE) *reinterpret_cast<f32x4*>(ge_out + off) = gv;
+        {
+          // no floating-point contraction in here: the product below feeds the sums of f4_a, and whether the compiler fuses
+          // it into them has differed between the MASK / HAS_GE instantiations (1 ulp in 0.2 % of dM) - the mask recomputed
+          // from x must give the bits of the mask read from y
+#pragma clang fp contract(off)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xh = (xv[e] - mu[e]) * rs[e];
-          d[p][e] = (gv[e] - m1[e] - xh * m2[e]) * (wv[e] * rs[e]);   // same expression as bn_bwd_apply_kernel
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (xv[e] - mu[e]) * rs[e];
+            d[p][e] = (gv[e] - m1[e] - xh * m2[e]) * (wv[e] * rs[e]);
+          }
         }
       }
       f4_a(d, m);

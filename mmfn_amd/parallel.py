@@ -158,6 +158,28 @@ class DataParallel(object):
         return sum(ms) / len(ms)
 
 
+def connect(module, dist, transport=None, max_bucket_bytes=64 << 20):
+    """DataParallel on the best transport that comes up on EVERY rank - what trainer.fit / bench.py --gpus N use.
+
+    transport: "auto" (default; or the MMFN_DP_TRANSPORT environment variable): the C-ABI RCCL communicator (mmfn_amd.comm) when
+    the library loads, the communicator initialises and a self-test all-reduce returns the right sum on every rank - the step
+    is then ONE hipGraph with the collectives captured inside (GraphedStep) - otherwise torch.distributed (the step cut at the
+    bucket boundaries); "capi": the C ABI or an error; "torch": torch.distributed.  Returns (DataParallel, note or None)."""
+    import os
+    from . import comm as C
+    want = transport or os.environ.get("MMFN_DP_TRANSPORT", "auto")
+    if want not in ("auto", "capi", "torch"):
+        raise ValueError("transport must be auto / capi / torch, got %r" % (want,))
+    dev = module._layout.device
+    handle, note = None, None
+    if want != "torch" and dist.get_world_size() >= 1 and dev.type == "cuda":
+        if want == "auto" and os.environ.get("MMFN_BENCH_SINGLE_DEVICE"):
+            note = "single-device CI run: RCCL refuses two ranks on one GPU, torch.distributed (gloo) instead"
+        else:
+            handle, note = C.open_transport(dist.get_rank(), dist.get_world_size(), dist, dev, required=(want == "capi"))
+    return DataParallel(module, dist, max_bucket_bytes=max_bucket_bytes, comm=handle), note
+
+
 class GraphedStep(object):
     """One training step as a replayable hipGraph (or a short sequence of them; mmfn_amd.graphs.Recorder).
 

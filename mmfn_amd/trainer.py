@@ -289,9 +289,16 @@ def _plain_state_dict(model):
 
 
 def fit(model, optimizer, train_loader, val_loader, config, logdir, epochs, val_every=1, save_every=1, dp=None, rank=0,
-        on_log=None):
+        on_log=None, dist=None):
     """The epoch loop of phase2_train_net.py:307-322: train every epoch; rank 0 validates every `val_every`
-    epochs and saves every `save_every`."""
+    epochs and saves every `save_every`.  Data parallel: pass `dp` (a parallel.DataParallel), or just the initialised
+    torch.distributed module as `dist` - the transport is then chosen by parallel.connect: the C-ABI RCCL communicator when it
+    passes its self-test on every rank (the whole step, gradient all-reduces included, replays as ONE hipGraph per batch shape),
+    else torch.distributed (four graphs per step, buckets in between); a capture that fails continues eagerly."""
+    if dp is None and dist is not None and dist.get_world_size() > 1:
+        from .parallel import connect
+        dp, _ = connect(model, dist)
+        rank = dist.get_rank()
     trainer = Trainer(model._layout.device, logdir)
     if rank == 0:
         trainer.resume(model, optimizer)

@@ -197,7 +197,7 @@ def test_vec_batch32_gradient_direction_at_the_benched_initialisation(monkeypatc
     backward is so ill-conditioned that the fp32 oracle itself is at cosine 0.57 to fp64 in the shallow stage: no bar there tells
     a wrong kernel from noise.  At the initialisation bench.py trains from - torch.manual_seed(42) + the model class's own init
     (run_steps/utils.py:77-84, model_vec.py:164-177) - the same graph is well conditioned (oracle 0.99998): here the HIP gradient
-    must stay within 8x the oracle's own angle^2 to the fp64 gradient (phase2_train_net.py:104-108) per backward stage AND per
+    must stay within 4x the oracle's own angle^2 to the fp64 gradient (phase2_train_net.py:104-108) per backward stage AND per
     (stage, trunk / transformer / VectorNet) group, and a deliberately broken data gradient of ONE layer1 convolution (two
     frequency slices of its transformed filter swapped between forward and backward) must turn the test red."""
     from mmfn_amd.config import GlobalConfig

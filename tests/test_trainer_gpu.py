@@ -177,6 +177,66 @@ def test_epoch_from_packed_frames_equals_epoch_from_pickles(store, tmp_path):
         assert torch.equal(out[0][1][k], out[1][1][k]), k
 
 
+class _OneRank(object):
+    """torch.distributed stand-in for a 1-rank world (the C-ABI transport carries the collectives)."""
+
+    class ReduceOp(object):
+        SUM = 0
+
+    @staticmethod
+    def get_world_size():
+        return 1
+
+    @staticmethod
+    def get_rank():
+        return 0
+
+    @staticmethod
+    def broadcast(t, src):
+        return None
+
+
+def test_data_parallel_epoch_on_the_single_graph_transport_equals_plain_epoch(store, monkeypatch):
+    """Trainer.train(dp=parallel.connect(...)): with the C-ABI RCCL transport the training loop's step - forward, backward, every
+    gradient-bucket all-reduce, AdamW - is ONE captured hipGraph per batch shape.  One GPU: a 1-rank communicator (the sum over
+    one rank is the identity), so two epochs must leave exactly the weights of the plain single-GPU epochs; the transport
+    must really be the C ABI and the replayed step really a single graph."""
+    from mmfn_amd import data as D
+    from mmfn_amd import parallel as P
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd import model as M
+    from mmfn_amd.optim import FusedAdamW
+    from mmfn_amd.trainer import Trainer
+    from oracle import harness
+    oracle = harness.build_oracle("vec", dropout=0.1)
+    cfg = GlobalConfig()
+    loader = D.make_loader(store, batch_size=1, num_workers=0)
+    monkeypatch.delenv("MMFN_BENCH_SINGLE_DEVICE", raising=False)
+    monkeypatch.setattr(P.DataParallel, "broadcast_parameters", lambda self, src=0: None)   # (nothing to broadcast to)
+    out = []
+    for use_dp in (False, True):
+        net = M.MMFN(cfg, DEV)
+        net.load_state_dict(oracle.state_dict(), strict=True)
+        dp = None
+        if use_dp:
+            import mmfn_amd.comm as C
+            monkeypatch.setattr(C, "all_ranks_agree", lambda dist, dev, ok: ok)
+            dp, note = P.connect(net, _OneRank, transport="capi")
+            assert dp.comm is not None and note is None and dp.n_buckets() >= 17
+        tr = Trainer(DEV, None)
+        opt = FusedAdamW(net, lr=1e-4)
+        tr.train(net, loader, cfg, opt, dp=dp)
+        tr.train(net, loader, cfg, opt, dp=dp)
+        if use_dp:
+            step = next(iter(tr._static_steps.values()))
+            assert not isinstance(step, str) and step.seg.single_graph and step.seg.recorder.n_graphs == 1
+            dp.comm.destroy()
+        out.append((tr.train_loss, net.state_dict()))
+    assert out[0][0] == out[1][0]
+    for k in out[0][1]:
+        assert torch.equal(out[0][1][k], out[1][1][k]), k
+
+
 def test_graph_replayed_validation_equals_eager_validation(store):
     """Trainer.validate(graph=True): the eval forward captured per input shape and replayed over changing batches gives the same
     validation loss as eager launches, before and after the weights change (the capture reads the weights at replay time)."""
