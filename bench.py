@@ -518,15 +518,16 @@ def main():
             # time the compute stream waits for the gradient all-reduces at the end of the backward (what the overlap does not
             # hide), over a few extra steps outside the timed region
             dp.measure_exposed = True
-            for _ in range(3):
+            for _ in range(max(1, min(3, args.steps))):
                 runner()
             ex_val, ex_how = dp.exposed_ms() or 0.0, "HIP events around the wait for the reductions before AdamW"
             dp.measure_exposed = False
         ex = torch.tensor([ex_val], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(ex, op=dist.ReduceOp.MAX)   # max over ranks
-        nbytes = 4 * sum(e - b for chunks in dp.buckets for b, e in chunks)
+        nbytes = dp.bytes_per_step()
         comm = {"backend": dist.get_backend(), "library": "RCCL over xGMI" if dist.get_backend() == "nccl" else dist.get_backend(),
-                "transport": "mmfn_allreduce_sum_f32 (C ABI, libmmfn_comm.so)" if comm_capi is not None else "torch.distributed",
+                "transport": ("mmfn_allreduce_sum_%s (C ABI, libmmfn_comm.so)" % dp.grad_dtype) if comm_capi is not None else "torch.distributed",
+                "gradient_dtype_on_the_wire": dp.grad_dtype,
                 "ranks": dist.get_world_size(), "allreduce_bytes_per_step": nbytes, "buckets": dp.n_buckets(),
                 "graphs_per_step": (1 if single_graph else graph.recorder.n_graphs) if graph is not None else 0,
                 "exposed_ms_per_step": round(float(ex.item()), 3), "exposed_method": ex_how,

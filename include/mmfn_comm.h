@@ -28,6 +28,11 @@ int mmfn_comm_ranks(void* comm, int* nranks, int* rank);
 /* In-place sum all-reduce of n floats (a gradient bucket: a contiguous range of the flat gradient buffer); the 1/ranks
  * average is folded into the AdamW launch (mmfn_adamw_groups_f32 grad_scale), not applied here. */
 int mmfn_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);
+/* The same over n bf16 elements: the bf16 training mode (BASELINE configs[2]) sends its gradient buckets as bf16 - 210 MB instead of
+ * 419 MB per step over xGMI, whose ring all-reduce is bound by one ~150 GB/s link - after a cast of the
+ * fp32 bucket (mmfn_cast_f32_to_bf16) and casts the sum back into the fp32 gradient buffer (mmfn_cast_bf16_to_f32); master
+ * weights, moments and the AdamW arithmetic stay fp32. */
+int mmfn_allreduce_sum_bf16(void* comm, void* buf, int64_t n, void* stream);
 /* In-place broadcast of nbytes from `root` (initial parameters, BatchNorm buffers, optimizer state after a resume). */
 int mmfn_broadcast_bytes(void* comm, void* buf, int64_t nbytes, int root, void* stream);
 

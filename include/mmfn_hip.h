@@ -163,6 +163,8 @@ enum {
   MMFN_G16_CONV_WGRAD = 4 /* A = dY [pixels][Cout], B = implicit im2col of x with k = output pixel, n = (kh,kw,ci): dw [Cout][KH][KW][Cin] fp32 */
 };
 #define MMFN_EPI16_OUT_F32 1024 /* C (and the MMFN_EPI_ACCUM read of it) is fp32 instead of bf16; res / aux stay bf16 */
+#define MMFN_EPI16_RES_F32 2048 /* the residual operand is fp32 (the transformers' residual stream stays fp32 in the bf16 mode, as under
+                                 * torch.autocast: x + Linear(.) with x fp32) */
 
 typedef struct mmfn_gemm16_desc {
   const void* A;   /* bf16 */
@@ -189,7 +191,7 @@ typedef struct mmfn_gemm16_desc {
   int32_t lda, ldb, ldc, ldr, ldaux; /* in elements */
   int32_t form;
   int32_t H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
-  int32_t flags;       /* MMFN_EPI_* (BIAS RELU GELU MASK_AUX DROPOUT RESIDUAL ACCUM RELU_LAST) | MMFN_EPI16_OUT_F32 */
+  int32_t flags;       /* MMFN_EPI_* (BIAS RELU GELU MASK_AUX DROPOUT RESIDUAL ACCUM RELU_LAST) | MMFN_EPI16_OUT_F32 | MMFN_EPI16_RES_F32 */
   int32_t splitk;      /* TN forms: 0 auto, >= 1 forced number of contraction slices */
   int32_t tile;        /* 0 auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128 */
   uint32_t rng_stream;
@@ -397,6 +399,9 @@ int mmfn_log_softmax_bwd_f32(const float* g, const float* y, float* dx, int R, i
  * torch.autocast(bfloat16) would run it - except that the activations never exist in fp32.  Arithmetic is fp32 in registers. */
 /* weight shadows, once per step: the flat fp32 parameter buffer rounded to bf16 at the same offsets ... */
 int mmfn_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+/* ... and back (exact): the gradient buckets of the bf16 mode cross xGMI as bf16 (mmfn_allreduce_sum_bf16, include/mmfn_comm.h) and
+ * return to the fp32 gradient buffer AdamW reads; n % 4 == 0 */
+int mmfn_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
 /* ... and transposed copies for the data gradients.  table: DEVICE array of n_entries records
  * { const float* src; bf16* dst; int32 R, T, C; int32 tiles_c; int64 tile0 } (40 bytes): dst[c][t][r] = src[r][t][c]
  * (Linear [out,in] -> [in,out] with T = 1; filters [Cout][taps][Cin] -> [Cin][taps][Cout]); tile0 = running sum of
@@ -411,12 +416,17 @@ int mmfn_bn_apply_bf16(const void* x, int x_is_f32, const void* res, void* y, in
 int mmfn_bn_bwd_bf16(const void* g, const void* y, const void* x, int x_is_f32, int64_t M, int C, const float* mean,
                      const float* rstd, const float* weight, void* dx, void* ge_out, float* dweight, float* dbias,
                      void* workspace, void* stream);
-int mmfn_layernorm_fwd_bf16(const void* x, const float* weight, const float* bias, void* y, float* mean, float* rstd, int M,
-                            int C, float eps, int act, void* stream);
-int mmfn_layernorm_bwd_partial_bf16(const void* g, const void* x, const float* weight, const float* bias, const float* mean,
-                                    const float* rstd, const void* dres, void* dx, int M, int C, int act, void* dx_dropped,
-                                    float drop_p, const uint64_t* rng_state, uint32_t rng_stream, int want_colsum,
-                                    float* partials, void* stream);
+/* The fusion transformers keep their residual stream (token matrix x and its gradient) in fp32 also in the bf16 mode - what
+ * torch.autocast does to model_vec.py:124-132 (x + attn(ln1(x)): LayerNorm output and Linear operands bf16, the sum fp32); rounding
+ * that stream to bf16 alone costs 0.03-0.04 of gradient cosine per backward stage (tools/experiments/bf16_where.py).  Hence:
+ *   x_is_f32 / stream_is_f32: x (and dres, dx) are fp32; y, g and dx_dropped (the GEMM operands) stay bf16;
+ *   dx_dropped with drop_p == 0 is the plain bf16 copy of dx (rng_state may be NULL then). */
+int mmfn_layernorm_fwd_bf16(const void* x, int x_is_f32, const float* weight, const float* bias, void* y, float* mean, float* rstd,
+                            int M, int C, float eps, int act, void* stream);
+int mmfn_layernorm_bwd_partial_bf16(const void* g, const void* x, int stream_is_f32, const float* weight, const float* bias,
+                                    const float* mean, const float* rstd, const void* dres, void* dx, int M, int C, int act,
+                                    void* dx_dropped, float drop_p, const uint64_t* rng_state, uint32_t rng_stream,
+                                    int want_colsum, float* partials, void* stream);
 int mmfn_colsum_bf16(const void* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream);
 /* out[c] = sum over rows of partials[row][0][c] (mmfn_gemm_bf16 stats_mode 1: the bias gradient from the producing GEMM's epilogue) */
 int mmfn_colsum_partials_f64(const double* partials, int rows, int C, float* out, void* stream);
@@ -427,14 +437,17 @@ int mmfn_bn_bwd_partials_bf16(const double* partials, int rows, const void* g, c
                               float* dbias, void* workspace, void* stream);
 int mmfn_maxpool3x3s2_fwd_bf16(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
 int mmfn_maxpool3x3s2_bwd_bf16(const void* gy, const uint8_t* idx, void* gx, int B, int H, int W, int C, void* stream);
+/* tok_is_f32 / gtok_is_f32: the token matrix / the token gradient is the fp32 residual stream (features stay bf16); the fp32
+ * token gradient goes through mmfn_tokens_bwd_f32 */
 int mmfn_tokens_fwd_bf16(const void* const* feats, int n_modal, const int32_t* frames, int B, int S, int C, const float* pos, const float* vel_w,
-                         const float* vel_b, const float* velocity, void* tok, float drop_p, const uint64_t* rng_state,
-                         uint32_t rng_stream, void* stream);
+                         const float* vel_b, const float* velocity, void* tok, int tok_is_f32, float drop_p,
+                         const uint64_t* rng_state, uint32_t rng_stream, void* stream);
 int mmfn_tokens_bwd_bf16(void* gtok, int B, int T, int C, const float* velocity, float* dpos, float* dvel_w, float* dvel_b,
                          float drop_p, const uint64_t* rng_state, uint32_t rng_stream, void* workspace, void* stream);
 int mmfn_upsample_add_fwd_bf16(const void* feat, const void* tok, void* out, int B, int S, int C, int T, int m, int frames, void* stream);
 int mmfn_upsample_adj_bf16(const void* G, void* gtok, int B, int S, int C, int T, int m, int frames, void* stream);
-int mmfn_pool_bcast_add_bf16(const void* G, const void* gtok, void* dF, int B, int S, int C, int T, int m, int frames, void* stream);
+int mmfn_pool_bcast_add_bf16(const void* G, const void* gtok, int gtok_is_f32, void* dF, int B, int S, int C, int T, int m, int frames,
+                             void* stream);
 int mmfn_gap_sum_fwd_bf16(const void* const* feats, int n, const int32_t* frames, int B, int P, int C, float* out, void* stream);
 int mmfn_gap_sum_bwd_bf16(const float* g, void* const* outs, int n, const int32_t* frames, int B, int P, int C, void* stream);
 /* [B, R, Cc] -> [B, Cc, R] across the precision boundary: VectorNet (fp32 inside) -> the bf16 map feature, and its gradient back */

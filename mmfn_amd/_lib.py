@@ -54,6 +54,7 @@ class Gemm16Desc(ctypes.Structure):
 
 G16_NT, G16_CONV_FWD, G16_CONV_DGRAD, G16_TN, G16_CONV_WGRAD = 0, 1, 2, 3, 4
 EPI16_OUT_F32 = 1024
+EPI16_RES_F32 = 2048
 
 
 class MMFNLibraryError(RuntimeError):

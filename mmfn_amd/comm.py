@@ -37,9 +37,10 @@ def lib():
         h.mmfn_comm_destroy.argtypes = [vp]
         h.mmfn_comm_ranks.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
         h.mmfn_allreduce_sum_f32.argtypes = [vp, vp, i64, vp]
+        h.mmfn_allreduce_sum_bf16.argtypes = [vp, vp, i64, vp]
         h.mmfn_broadcast_bytes.argtypes = [vp, vp, i64, i32, vp]
         for name in ("mmfn_comm_unique_id", "mmfn_comm_init", "mmfn_comm_destroy", "mmfn_comm_ranks", "mmfn_allreduce_sum_f32",
-                     "mmfn_broadcast_bytes"):
+                     "mmfn_allreduce_sum_bf16", "mmfn_broadcast_bytes"):
             getattr(h, name).restype = i32
         _lib = h
     return _lib
@@ -74,10 +75,13 @@ class RcclComm(object):
         _check(L.mmfn_comm_init(ctypes.byref(self._comm), ctypes.cast(idbuf, ctypes.c_void_p), world, rank), "mmfn_comm_init")
 
     def all_reduce_sum_(self, t, stream=None):
-        """In-place sum over ranks of a contiguous fp32 device tensor, enqueued on `stream` (default: the current one)."""
-        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        """In-place sum over ranks of a contiguous fp32 or bf16 device tensor, enqueued on `stream` (default: the current one)."""
+        assert t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous() and t.is_cuda
         st = (stream or torch.cuda.current_stream()).cuda_stream
-        _check(lib().mmfn_allreduce_sum_f32(self._comm, t.data_ptr(), t.numel(), st), "mmfn_allreduce_sum_f32")
+        if t.dtype == torch.bfloat16:
+            _check(lib().mmfn_allreduce_sum_bf16(self._comm, t.data_ptr(), t.numel(), st), "mmfn_allreduce_sum_bf16")
+        else:
+            _check(lib().mmfn_allreduce_sum_f32(self._comm, t.data_ptr(), t.numel(), st), "mmfn_allreduce_sum_f32")
 
     def broadcast_(self, t, root=0, stream=None):
         assert t.is_contiguous() and t.is_cuda

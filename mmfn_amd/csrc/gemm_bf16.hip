@@ -432,9 +432,16 @@ __global__ __launch_bounds__(NT) void gemm16_nt_kernel(const mmfn_gemm16_desc d,
       for (int e = 0; e < 8; ++e) v[e] *= mmfn_dropout_scale(key, (uint64_t)row * (uint64_t)d.N + (uint64_t)(col + e), d.drop_p, inv_keep);
     }
     if (f & MMFN_EPI_RESIDUAL) {
-      const Row8 a = load8_bf16(reinterpret_cast<const bf16_t*>(d.res) + (size_t)row * d.ldr + col);
+      if (f & MMFN_EPI16_RES_F32) {   // the transformers' fp32 residual stream (with MMFN_EPI16_OUT_F32)
+        const float* rp = reinterpret_cast<const float*>(d.res) + (size_t)row * d.ldr + col;
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += a.v[e];
+        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+      } else {
+        const Row8 a = load8_bf16(reinterpret_cast<const bf16_t*>(d.res) + (size_t)row * d.ldr + col);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += a.v[e];
+      }
     }
     if (d.stats && d.stats_mode != 0 && !(f & (MMFN_EPI_ACCUM | MMFN_EPI_RELU_LAST))) {
       if (d.stats_mode == 1) {          // column sums of the final value: the bias gradient of the Linear whose dX this is

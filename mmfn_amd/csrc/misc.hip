@@ -116,7 +116,8 @@ extern "C" int mmfn_relu_mask_f32(const float* g, const float* y, float* out, in
 // [Cout][taps][Cin] -> [Cin][taps][Cout], taps in place).  Replaces the per-call casts torch.autocast inserts in front of
 // every aten::linear / convolution (and their backward) of the reference's training step.
 namespace {
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n4) {
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, int64_t n4) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
     stx4(out + i * 4, ldx4(in + i * 4));
 }
@@ -164,7 +165,16 @@ extern "C" int mmfn_cast_f32_to_bf16(const float* in, void* out, int64_t n, void
   if (n <= 0) return 0;
   if (n % 4 || !in || !out) return MMFN_EINVAL;
   const int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256, 4096);
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, n / 4);
+  hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, (bf16_t*)out, n / 4);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream) {
+  if (n <= 0) return 0;
+  if (n % 4 || !in || !out) return MMFN_EINVAL;
+  const int blocks = (int)std::min<int64_t>((n / 4 + 255) / 256, 4096);
+  hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, out, n / 4);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

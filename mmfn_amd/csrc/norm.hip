@@ -273,9 +273,10 @@ int bn_grid(int64_t M, int C, int64_t* rows_per_block) {
 
 // ------------------------------------------------------------------ LayerNorm
 // One wave per row, lane owns columns lane, lane+64, ... (C <= 512 -> <= 8 per lane).
-template <int MAXPL, typename TA>
+// TA: input element type, TO: output (bf16 mode: the transformers' residual stream stays fp32, the normalised GEMM operand is bf16)
+template <int MAXPL, typename TA, typename TO = TA>
 __global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const TA* __restrict__ x, const float* __restrict__ w,
-                                                           const float* __restrict__ b, TA* __restrict__ y,
+                                                           const float* __restrict__ b, TO* __restrict__ y,
                                                            float* __restrict__ mean, float* __restrict__ rstd, int M, int C,
                                                            float eps, int act) {
   const int lane = threadIdx.x & 63;
@@ -308,23 +309,27 @@ __global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const TA* __restrict_
 // One row per wave iteration; lane l owns VW consecutive columns per 64*VW-column chunk (4/8/16-byte accesses),
 // NCH chunks per row (C = 64 * VW * NCH).  Blocks are small (8 rows at M = 6144 -> 768 blocks) so the whole chip
 // streams rows; the per-block dweight / dbias partial rows are combined by colsum_finalize_kernel in fp64.
-template <int VW, int NCH, typename TA>
-__global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const TA* __restrict__ g, const TA* __restrict__ x,
+// TA: element type of the incoming gradient g and of the dropped copy dxd (GEMM operands); TX: of x, dres and dx (the residual
+// stream and its gradient).  fp32 path: both float; bf16 mode: TA = bf16, TX = float in the transformers, bf16 elsewhere.
+template <int VW, int NCH, typename TA, typename TX = TA>
+__global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const TA* __restrict__ g, const TX* __restrict__ x,
                                                            const float* __restrict__ w, const float* __restrict__ b,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const TA* __restrict__ dres, TA* __restrict__ dx,
+                                                           const TX* __restrict__ dres, TX* __restrict__ dx,
                                                            float* __restrict__ partials /* [grid][2][C] */, int M,
                                                            int act, int rows_per_block, TA* __restrict__ dxd, float drop_p,
                                                            const uint64_t* __restrict__ rng_state, uint32_t rng_stream,
                                                            int want_sum) {
   typedef float vec __attribute__((ext_vector_type(VW)));
   typedef VecIO<VW, TA> IO;
+  typedef VecIO<VW, TX> IOX;
   constexpr int C = 64 * VW * NCH;
   // optional second output dxd = dx * dropout keep-scale(row * C + col): the gradient entering the residual branch whose
   // forward applied that dropout in a GEMM epilogue (same counter RNG index) - saves a separate elementwise pass
   uint64_t dkey = 0;
   float inv_keep = 1.f;
-  if (dxd) { dkey = mmfn_rng_key(rng_state, rng_stream); inv_keep = 1.0f / (1.0f - drop_p); }
+  const bool dropping = dxd && drop_p > 0.f;   // (drop_p == 0: dxd is the plain copy of dx in the operand type)
+  if (dropping) { dkey = mmfn_rng_key(rng_state, rng_stream); inv_keep = 1.0f / (1.0f - drop_p); }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // want_sum: third partial row = column sums of what leaves in dxd (or in dx when there is no dropped copy): the bias
   // gradient of the Linear whose output gradient this is - saves the separate two-launch column sum
@@ -346,7 +351,7 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const TA* __restrict_
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const size_t off = (size_t)row * C + (i * 64 + lane) * VW;
-      const vec xv = IO::ld(x + off);
+      const vec xv = IOX::ld(x + off);
       vec gg = IO::ld(g + off);
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
@@ -374,12 +379,14 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const TA* __restrict_
       vec o;
 #pragma unroll
       for (int j = 0; j < VW; ++j) o[j] = rs * (a[i][j] - c1 - xh[i][j] * c2);
-      if (dres) o += IO::ld(dres + off);
-      IO::st(dx + off, o);
+      if (dres) o += IOX::ld(dres + off);
+      IOX::st(dx + off, o);
       if (dxd) {
-        vec od;
+        vec od = o;
+        if (dropping) {
 #pragma unroll
-        for (int j = 0; j < VW; ++j) od[j] = o[j] * mmfn_dropout_scale(dkey, (uint64_t)off + j, drop_p, inv_keep);
+          for (int j = 0; j < VW; ++j) od[j] = o[j] * mmfn_dropout_scale(dkey, (uint64_t)off + j, drop_p, inv_keep);
+        }
         IO::st(dxd + off, od);
         o = od;
       }
@@ -612,11 +619,11 @@ extern "C" int mmfn_bn_bwd_reduce_f32(const float* g, const float* y, const floa
 }
 
 namespace {
-template <typename TA>
-int layernorm_fwd_launch(const TA* x, const float* weight, const float* bias, TA* y, float* mean, float* rstd, int M, int C, float eps,
+template <typename TA, typename TO>
+int layernorm_fwd_launch(const TA* x, const float* weight, const float* bias, TO* y, float* mean, float* rstd, int M, int C, float eps,
                          int act, void* stream) {
   if (C % 64 || C > 512 || M <= 0) return MMFN_EINVAL;
-  hipLaunchKernelGGL((layernorm_fwd_kernel<8, TA>), dim3(ceil_div(M, NT / 64)), dim3(NT), 0, (hipStream_t)stream, x, weight, bias, y,
+  hipLaunchKernelGGL((layernorm_fwd_kernel<8, TA, TO>), dim3(ceil_div(M, NT / 64)), dim3(NT), 0, (hipStream_t)stream, x, weight, bias, y,
                      mean, rstd, M, C, eps, act);
   MMFN_LAUNCH_CHECK();
   return 0;
@@ -627,8 +634,9 @@ extern "C" int mmfn_layernorm_fwd_f32(const float* x, const float* weight, const
                                       float* rstd, int M, int C, float eps, int act, void* stream) {
   return layernorm_fwd_launch(x, weight, bias, y, mean, rstd, M, C, eps, act, stream);
 }
-extern "C" int mmfn_layernorm_fwd_bf16(const void* x, const float* weight, const float* bias, void* y, float* mean,
+extern "C" int mmfn_layernorm_fwd_bf16(const void* x, int x_is_f32, const float* weight, const float* bias, void* y, float* mean,
                                        float* rstd, int M, int C, float eps, int act, void* stream) {
+  if (x_is_f32) return layernorm_fwd_launch((const float*)x, weight, bias, (bf16_t*)y, mean, rstd, M, C, eps, act, stream);
   return layernorm_fwd_launch((const bf16_t*)x, weight, bias, (bf16_t*)y, mean, rstd, M, C, eps, act, stream);
 }
 
@@ -646,17 +654,17 @@ static int ln_bwd_rows_per_block(int M) { return std::max(8, ceil_div(M, 384)); 
 extern "C" int mmfn_layernorm_bwd_rows(int M) { return M > 0 ? ceil_div(M, ln_bwd_rows_per_block(M)) : 0; }
 
 namespace {
-template <typename TA>
-int layernorm_bwd_partial_launch(const TA* g, const TA* x, const float* weight, const float* bias, const float* mean, const float* rstd,
-                                 const TA* dres, TA* dx, int M, int C, int act, TA* dx_dropped, float drop_p,
+template <typename TA, typename TX>
+int layernorm_bwd_partial_launch(const TA* g, const TX* x, const float* weight, const float* bias, const float* mean, const float* rstd,
+                                 const TX* dres, TX* dx, int M, int C, int act, TA* dx_dropped, float drop_p,
                                  const uint64_t* rng_state, uint32_t rng_stream, int want_colsum, float* partials, void* stream) {
   if (M <= 0 || !partials) return MMFN_EINVAL;
-  if (dx_dropped && (!rng_state || drop_p <= 0.f || drop_p >= 1.f)) return MMFN_EINVAL;
+  if (dx_dropped && (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !rng_state))) return MMFN_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int rpb = ln_bwd_rows_per_block(M);
   const int nblk = ceil_div(M, rpb);
 #define MMFN_LN_BWD(VW, NCH) \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<VW, NCH, TA>), dim3(nblk), dim3(NT), 0, s, g, x, weight, bias, mean, rstd, dres, dx, \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<VW, NCH, TA, TX>), dim3(nblk), dim3(NT), 0, s, g, x, weight, bias, mean, rstd, dres, dx, \
                      partials, M, act, rpb, dx_dropped, drop_p, rng_state, rng_stream, want_colsum ? 1 : 0)
   switch (C) {
     case 64: MMFN_LN_BWD(1, 1); break;
@@ -678,10 +686,13 @@ extern "C" int mmfn_layernorm_bwd_partial_f32(const float* g, const float* x, co
   return layernorm_bwd_partial_launch(g, x, weight, bias, mean, rstd, dres, dx, M, C, act, dx_dropped, drop_p, rng_state, rng_stream,
                                       want_colsum, partials, stream);
 }
-extern "C" int mmfn_layernorm_bwd_partial_bf16(const void* g, const void* x, const float* weight, const float* bias,
+extern "C" int mmfn_layernorm_bwd_partial_bf16(const void* g, const void* x, int stream_is_f32, const float* weight, const float* bias,
                                                const float* mean, const float* rstd, const void* dres, void* dx, int M, int C,
                                                int act, void* dx_dropped, float drop_p, const uint64_t* rng_state,
                                                uint32_t rng_stream, int want_colsum, float* partials, void* stream) {
+  if (stream_is_f32)
+    return layernorm_bwd_partial_launch((const bf16_t*)g, (const float*)x, weight, bias, mean, rstd, (const float*)dres, (float*)dx, M, C,
+                                        act, (bf16_t*)dx_dropped, drop_p, rng_state, rng_stream, want_colsum, partials, stream);
   return layernorm_bwd_partial_launch((const bf16_t*)g, (const bf16_t*)x, weight, bias, mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, M,
                                       C, act, (bf16_t*)dx_dropped, drop_p, rng_state, rng_stream, want_colsum, partials, stream);
 }

@@ -104,11 +104,12 @@ typedef FeatPtrsT<float> FeatPtrs;
 typedef GradPtrsT<float> GradPtrs;
 
 // tok[b, m*64 + ay*8+ax, c] = drop( pos[t,c] + mean_{kxk}(F_m[b, ay*k.., ax*k.., c]) + vel_w[c]*v[b] + vel_b[c] )
-template <typename TT>
+// TO: element type of the token matrix (the transformer's residual stream: fp32 also in the bf16 mode, TT = bf16 features)
+template <typename TT, typename TO = TT>
 __global__ __launch_bounds__(NT) void tokens_fwd_kernel(FeatPtrsT<TT> feats, GroupMap gm, int n_modal, int B, int S, int C,
                                                         const float* __restrict__ pos, const float* __restrict__ vel_w,
                                                         const float* __restrict__ vel_b, const float* __restrict__ velocity,
-                                                        TT* __restrict__ tok, float drop_p,
+                                                        TO* __restrict__ tok, float drop_p,
                                                         const uint64_t* __restrict__ rng_state, uint32_t rng_stream) {
   const int cq = C >> 2;
   const int k = S >> 3;
@@ -302,8 +303,9 @@ __global__ __launch_bounds__(NT) void upsample_adj_kernel(const TT* __restrict__
 }
 
 // dF[b,y,x,c] = G[b,y,x,c] + gtok[b, m*64 + (y/k)*8 + x/k, c] / k^2      (avgpool adjoint + identity)
-template <typename TT>
-__global__ __launch_bounds__(NT) void pool_bcast_add_kernel(const TT* __restrict__ G, const TT* __restrict__ gtok,
+// TG: element type of the token gradient (fp32 residual stream of the bf16 mode: TT = bf16, TG = float)
+template <typename TT, typename TG = TT>
+__global__ __launch_bounds__(NT) void pool_bcast_add_kernel(const TT* __restrict__ G, const TG* __restrict__ gtok,
                                                             TT* __restrict__ dF, int B, int S, int C, int T, int m, int frames) {
   const int cq = C >> 2;
   const int k = S >> 3;
@@ -397,16 +399,16 @@ int maxpool_bwd_launch(const T* gy, const uint8_t* idx, T* gx, int B, int H, int
   MMFN_LAUNCH_CHECK();
   return 0;
 }
-template <typename T>
+template <typename T, typename TO>
 int tokens_fwd_launch(const T* const* feats, int n_modal, const int32_t* frames, int B, int S, int C, const float* pos, const float* vel_w,
-                      const float* vel_b, const float* velocity, T* tok, float drop_p, const uint64_t* rng_state,
+                      const float* vel_b, const float* velocity, TO* tok, float drop_p, const uint64_t* rng_state,
                       uint32_t rng_stream, void* stream) {
   if (C % 4 || S % 8 || n_modal < 1 || n_modal > 4) return MMFN_EINVAL;
   FeatPtrsT<T> fp;
   for (int i = 0; i < 4; ++i) fp.p[i] = i < n_modal ? feats[i] : nullptr;
   const GroupMap gm = make_groups(n_modal, frames);
   const int groups = gm.base[n_modal - 1] + gm.cnt[n_modal - 1];
-  hipLaunchKernelGGL(tokens_fwd_kernel<T>, dim3(grid_for((int64_t)B * groups * 64 * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL((tokens_fwd_kernel<T, TO>), dim3(grid_for((int64_t)B * groups * 64 * (C / 4))), dim3(NT), 0, (hipStream_t)stream,
                      fp, gm, n_modal, B, S, C, pos, vel_w, vel_b, velocity, tok, drop_p, rng_state, rng_stream);
   MMFN_LAUNCH_CHECK();
   return 0;
@@ -445,10 +447,10 @@ int upsample_adj_launch(const T* G, T* gtok, int B, int S, int C, int Tn, int m,
   MMFN_LAUNCH_CHECK();
   return 0;
 }
-template <typename T>
-int pool_bcast_add_launch(const T* G, const T* gtok, T* dF, int B, int S, int C, int Tn, int m, int frames, void* stream) {
+template <typename T, typename TG>
+int pool_bcast_add_launch(const T* G, const TG* gtok, T* dF, int B, int S, int C, int Tn, int m, int frames, void* stream) {
   if (C % 4 || S % 8 || frames < 1 || B % frames) return MMFN_EINVAL;
-  hipLaunchKernelGGL(pool_bcast_add_kernel<T>, dim3(grid_for((int64_t)B * S * S * (C / 4))), dim3(NT), 0, (hipStream_t)stream, G,
+  hipLaunchKernelGGL((pool_bcast_add_kernel<T, TG>), dim3(grid_for((int64_t)B * S * S * (C / 4))), dim3(NT), 0, (hipStream_t)stream, G,
                      gtok, dF, B, S, C, Tn, m, frames);
   MMFN_LAUNCH_CHECK();
   return 0;
@@ -506,8 +508,11 @@ extern "C" int mmfn_tokens_fwd_f32(const float* const* feats, int n_modal, const
   return tokens_fwd_launch(feats, n_modal, frames, B, S, C, pos, vel_w, vel_b, velocity, tok, drop_p, rng_state, rng_stream, stream);
 }
 extern "C" int mmfn_tokens_fwd_bf16(const void* const* feats, int n_modal, const int32_t* frames, int B, int S, int C, const float* pos,
-                                    const float* vel_w, const float* vel_b, const float* velocity, void* tok, float drop_p,
-                                    const uint64_t* rng_state, uint32_t rng_stream, void* stream) {
+                                    const float* vel_w, const float* vel_b, const float* velocity, void* tok, int tok_is_f32,
+                                    float drop_p, const uint64_t* rng_state, uint32_t rng_stream, void* stream) {
+  if (tok_is_f32)
+    return tokens_fwd_launch((const bf16_t* const*)feats, n_modal, frames, B, S, C, pos, vel_w, vel_b, velocity, (float*)tok, drop_p,
+                             rng_state, rng_stream, stream);
   return tokens_fwd_launch((const bf16_t* const*)feats, n_modal, frames, B, S, C, pos, vel_w, vel_b, velocity, (mbf)tok, drop_p, rng_state,
                            rng_stream, stream);
 }
@@ -545,8 +550,9 @@ extern "C" int mmfn_pool_bcast_add_f32(const float* G, const float* gtok, float*
                                        void* stream) {
   return pool_bcast_add_launch(G, gtok, dF, B, S, C, T, m, frames, stream);
 }
-extern "C" int mmfn_pool_bcast_add_bf16(const void* G, const void* gtok, void* dF, int B, int S, int C, int T, int m, int frames,
-                                        void* stream) {
+extern "C" int mmfn_pool_bcast_add_bf16(const void* G, const void* gtok, int gtok_is_f32, void* dF, int B, int S, int C, int T, int m,
+                                        int frames, void* stream) {
+  if (gtok_is_f32) return pool_bcast_add_launch((cbf)G, (const float*)gtok, (mbf)dF, B, S, C, T, m, frames, stream);
   return pool_bcast_add_launch((cbf)G, (cbf)gtok, (mbf)dF, B, S, C, T, m, frames, stream);
 }
 

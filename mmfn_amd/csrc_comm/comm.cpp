@@ -55,6 +55,12 @@ extern "C" int mmfn_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* s
   return (int)ncclAllReduce(buf, buf, (size_t)n, ncclFloat, ncclSum, (ncclComm_t)comm, (hipStream_t)stream);
 }
 
+extern "C" int mmfn_allreduce_sum_bf16(void* comm, void* buf, int64_t n, void* stream) {
+  if (!comm || (!buf && n > 0) || n < 0) return -1;
+  if (n == 0) return 0;
+  return (int)ncclAllReduce(buf, buf, (size_t)n, ncclBfloat16, ncclSum, (ncclComm_t)comm, (hipStream_t)stream);
+}
+
 extern "C" int mmfn_broadcast_bytes(void* comm, void* buf, int64_t nbytes, int root, void* stream) {
   if (!comm || (!buf && nbytes > 0) || nbytes < 0) return -1;
   if (nbytes == 0) return 0;

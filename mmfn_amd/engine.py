@@ -590,8 +590,13 @@ class GPT(object):
         bufs, nm = ctx.bufs, self.name
         p_embd, p_attn, p_resid = ctx.drop
         adt = ctx.adt
+        # The residual stream x (and, in bwd, its gradient) is fp32 in BOTH modes: in the bf16 mode the LayerNorm outputs, q / k / v,
+        # the attention output and the MLP hidden - every GEMM operand - are bf16, the sums x + proj(.) and x + mlp(.) are not
+        # (what torch.autocast does to model_vec.py:124-132; rounding the stream alone costs 0.03-0.04 of gradient cosine per
+        # backward stage, tools/experiments/bf16_where.py)
+        sdt = torch.float32
         Wf = (lambda lin: lin.w16) if ctx.bf16 else (lambda lin: lin.w)      # forward operand of a Linear
-        x = bufs.get(nm + ".x0", (B, T, C), adt)
+        x = bufs.get(nm + ".x0", (B, T, C), sdt)
         ops.tokens_fwd(feats, self.pos.view(T, C), self.vel.w.view(C), self.vel.b, velocity, x, p_embd, ctx.rng_state,
                        self.stream_base, frames=self.frames)
         self.velocity = velocity
@@ -613,18 +618,18 @@ class GPT(object):
             # packed columns: [key | query | value]  (reference registration order, model_vec.py:82-84)
             ops.attention_fwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, C, lse, B, T, nh, hs, scale, drop_p=p_attn,
                               rng_state=ctx.rng_state, rng_stream=sb)
-            x1 = bufs.get("%s.b%d.x1" % (nm, i), (M, C), adt)
+            x1 = bufs.get("%s.b%d.x1" % (nm, i), (M, C), sdt)
             ops.linear_fwd(o, Wf(blk["proj"]), blk["proj"].b, out=x1, res=x, ldr=C, drop_p=p_resid, rng_state=ctx.rng_state,
                            rng_stream=sb + 1)
             a2 = blk["ln2"].fwd(ctx, x1, out=S_a2[i])
             h = S_h[i]
             ops.linear_fwd(a2, Wf(blk["fc1"]), blk["fc1"].b, out=h, relu=True)
-            x2 = bufs.get("%s.b%d.x2" % (nm, i), (M, C), adt)
+            x2 = bufs.get("%s.b%d.x2" % (nm, i), (M, C), sdt)
             ops.linear_fwd(h, Wf(blk["fc2"]), blk["fc2"].b, out=x2, res=x1, ldr=C, drop_p=p_resid, rng_state=ctx.rng_state,
                            rng_stream=sb + 2)
             self.acts.append((x, a, qkv, o, lse, x1, a2, h))
             x = x2
-        y = self.ln_f.fwd(ctx, x)
+        y = self.ln_f.fwd(ctx, x, out=bufs.get(nm + ".ln_f.out", (M, C), adt))
         return y.view(B, T, C)
 
     def bwd(self, ctx, g_y):
@@ -645,11 +650,13 @@ class GPT(object):
         # (what enters the MLP branch), G1 / GD2 the same for the attention branch, GH / DQKV the gradients of the hidden / qkv
         # activations.  The side stream reads them for the weight gradients, so they are per block and it may lag by any number
         # of blocks: one rejoin at the end of the transformer.
-        adt = ctx.adt
+        adt, sdt = ctx.adt, torch.float32   # sdt: the residual stream's gradient is fp32 in both modes (see fwd)
+        # bf16 mode: the "dropped copy" is also where the stream gradient becomes a bf16 GEMM operand, so it exists without dropout too
+        drop = drop or ctx.bf16
         Wb = (lambda lin: lin.w16t) if ctx.bf16 else (lambda lin: lin.w)     # data-gradient operand of a Linear (bf16: the transposed shadow)
-        G = bufs.get(nm + ".S.g", (nblk, M, C), adt)
+        G = bufs.get(nm + ".S.g", (nblk, M, C), sdt)
         GD = bufs.get(nm + ".S.gdrop", (nblk, M, C), adt) if drop else None
-        G1 = bufs.get(nm + ".S.g1", (nblk, M, C), adt)
+        G1 = bufs.get(nm + ".S.g1", (nblk, M, C), sdt)
         GD2 = bufs.get(nm + ".S.gdrop2", (nblk, M, C), adt) if drop else None
         GH = bufs.get(nm + ".S.gh", (nblk, M, 4 * C), adt)
         DQKV = bufs.get(nm + ".S.dqkv", (nblk, M, 3 * C), adt)
@@ -703,7 +710,7 @@ class GPT(object):
             side.append(lambda dqkv=dqkv, blk=blk, a=a: (ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
             ga = bufs.get(nm + ".ga2", (M, C), adt)
             ops.linear_dx(dqkv, blk["wqkv16t"] if ctx.bf16 else blk["wqkv"], out=ga)
-            g = blk["ln1"].bwd(ctx, ga, dres=g1, out=G[i - 1] if i > 0 else bufs.get(nm + ".g_tok", (M, C), adt),
+            g = blk["ln1"].bwd(ctx, ga, dres=g1, out=G[i - 1] if i > 0 else bufs.get(nm + ".g_tok", (M, C), sdt),
                                dropped=GD[i - 1] if (drop and i > 0) else None, drop_p=p_resid,
                                rng_stream=sb_of(i - 1) + 2, colsum=self.blocks[i - 1]["fc2"].gb if i > 0 else None, defer=side)
             work, side = side, []

@@ -771,9 +771,13 @@ ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 
 
 def layernorm_fwd(x, w, b, y, mean, rstd, act=ACT_NONE, eps=1e-5):
+    """y bf16 (the bf16 mode): x bf16, or fp32 - the transformers' residual stream, which stays fp32 in that mode."""
     M, C = x.shape
-    _call("mmfn_layernorm_fwd_bf16" if x.dtype == BF16 else "mmfn_layernorm_fwd_f32", ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean),
-          ptr(rstd), M, C, eps, act, stream())
+    if y.dtype == BF16:
+        _call("mmfn_layernorm_fwd_bf16", ptr(x), 0 if x.dtype == BF16 else 1, ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), M, C, eps, act,
+              stream())
+        return y
+    _call("mmfn_layernorm_fwd_f32", ptr(x), ptr(w), ptr(b), ptr(y), ptr(mean), ptr(rstd), M, C, eps, act, stream())
     return y
 
 
@@ -782,7 +786,7 @@ def layernorm_bwd(g, x, w, b, mean, rstd, dx, dw, db, act=ACT_NONE, dres=None, d
     """dx_dropped: optional second output dx * dropout keep-scale (the mask of the residual branch that consumes dx).
     dx_colsum: optional [C] output, column sums of dx_dropped (of dx without a dropped copy): the next bias gradient."""
     M, C = x.shape
-    if x.dtype == BF16:   # the two halves separately (same kernels as the fused entry)
+    if g.dtype == BF16:   # the two halves separately (same kernels as the fused entry)
         rows = layernorm_bwd_rows(M)
         part = norm_workspace(x.device).view(torch.float32)[:rows * 3 * C].view(rows, 3, C)
         layernorm_bwd_partial(g, x, w, b, mean, rstd, dx, part, act, dres=dres, dx_dropped=dx_dropped, drop_p=drop_p,
@@ -804,8 +808,16 @@ def layernorm_bwd_partial(g, x, w, b, mean, rstd, dx, partials, act=ACT_NONE, dr
     """First half of layernorm_bwd: dx (and dx_dropped) now, the row reductions as partial rows in `partials`
     ([layernorm_bwd_rows(M), 3 or 2, C] floats) for layernorm_bwd_finalize - which may run later, on another stream."""
     M, C = x.shape
-    _call("mmfn_layernorm_bwd_partial_bf16" if x.dtype == BF16 else "mmfn_layernorm_bwd_partial_f32", ptr(g), ptr(x), ptr(w), ptr(b),
-          ptr(mean), ptr(rstd), ptr(dres), ptr(dx), M, C, act,
+    if g.dtype == BF16:
+        # bf16 mode: g and the dropped copy are GEMM operands (bf16); x / dres / dx are bf16 too, or - inside the fusion transformers -
+        # the fp32 residual stream and its gradient
+        f32_stream = x.dtype == torch.float32
+        assert dx.dtype == x.dtype and (dres is None or dres.dtype == x.dtype) and (dx_dropped is None or dx_dropped.dtype == BF16)
+        _call("mmfn_layernorm_bwd_partial_bf16", ptr(g), ptr(x), 1 if f32_stream else 0, ptr(w), ptr(b), ptr(mean), ptr(rstd), ptr(dres),
+              ptr(dx), M, C, act, ptr(dx_dropped), float(drop_p), ptr(rng_state), rng_stream, 1 if want_colsum else 0, ptr(partials),
+              stream())
+        return dx
+    _call("mmfn_layernorm_bwd_partial_f32", ptr(g), ptr(x), ptr(w), ptr(b), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), M, C, act,
           ptr(dx_dropped), float(drop_p), ptr(rng_state), rng_stream, 1 if want_colsum else 0, ptr(partials), stream())
     return dx
 
@@ -855,7 +867,11 @@ def tokens_fwd(feats, pos, vel_w, vel_b, velocity, tok, drop_p=0.0, rng_state=No
     if tok.shape[1] != 64 * (len(feats) if frames is None else sum(frames)):
         raise ValueError("token buffer has %d tokens, the frames need %d" % (tok.shape[1], 64 * (len(feats) if frames is None else sum(frames))))
     arr = _ptr_array(feats)
-    _call("mmfn_tokens_fwd_bf16" if tok.dtype == BF16 else "mmfn_tokens_fwd_f32", arr, len(feats), _frames(frames, len(feats)), B, S, C, ptr(pos), ptr(vel_w),
+    if feats[0].dtype == BF16:   # bf16 features; the token matrix bf16 or (the transformers' residual stream) fp32
+        _call("mmfn_tokens_fwd_bf16", arr, len(feats), _frames(frames, len(feats)), B, S, C, ptr(pos), ptr(vel_w), ptr(vel_b), ptr(velocity),
+              ptr(tok), 0 if tok.dtype == BF16 else 1, float(drop_p), ptr(rng_state), rng_stream, stream())
+        return tok
+    _call("mmfn_tokens_fwd_f32", arr, len(feats), _frames(frames, len(feats)), B, S, C, ptr(pos), ptr(vel_w),
           ptr(vel_b), ptr(velocity), ptr(tok), float(drop_p), ptr(rng_state), rng_stream, stream())
     return tok
 
@@ -892,7 +908,10 @@ def pool_bcast_add(G, gtok, dF, m, frames=1):
     B, S, _, C = G.shape
     T = gtok.shape[1]
     _groups_ok(B, gtok.shape[0], T, m, frames)
-    _call("mmfn_pool_bcast_add_bf16" if G.dtype == BF16 else "mmfn_pool_bcast_add_f32", ptr(G), ptr(gtok), ptr(dF), B, S, C, T, m, frames, stream())
+    if G.dtype == BF16:   # the token gradient bf16 or (the transformers' fp32 residual stream) fp32
+        _call("mmfn_pool_bcast_add_bf16", ptr(G), ptr(gtok), 0 if gtok.dtype == BF16 else 1, ptr(dF), B, S, C, T, m, frames, stream())
+        return dF
+    _call("mmfn_pool_bcast_add_f32", ptr(G), ptr(gtok), ptr(dF), B, S, C, T, m, frames, stream())
     return dF
 
 
@@ -1060,6 +1079,11 @@ def log_softmax_bwd(g, y, dx, R, C, swap):
 # ---------------------------------------------------------------- bf16 weight shadows
 def cast_to_bf16(src, dst):
     _call("mmfn_cast_f32_to_bf16", ptr(src), ptr(dst), src.numel(), stream())
+    return dst
+
+
+def cast_to_f32(src, dst):
+    _call("mmfn_cast_bf16_to_f32", ptr(src), ptr(dst), src.numel(), stream())
     return dst
 
 

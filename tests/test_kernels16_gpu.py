@@ -94,6 +94,70 @@ def test_layernorm_forward_backward(C):
     assert keep.float().mean() > 0.85
 
 
+@pytest.mark.parametrize("C,drop_p", [(64, 0.0), (256, 0.1), (512, 0.0), (512, 0.1)])
+def test_layernorm_over_the_fp32_residual_stream(C, drop_p):
+    """bf16 mode inside the fusion transformers (model_vec.py:124-132 under torch.autocast: x + Linear(LN(x)) with x fp32): the
+    LayerNorm reads the fp32 stream and writes the bf16 GEMM operand; its backward takes the bf16 operand gradient, adds the fp32
+    stream gradient, writes dx in fp32 and the (dropped) bf16 copy the next GEMM reads.  Against the fp32 kernels on the same
+    numbers: statistics, dx, parameter gradients bit-identical; y and the copy are their bf16 roundings; drop_p = 0 gives the
+    plain copy."""
+    from mmfn_amd import ops
+    M = 1536
+    g16 = _r(M, C, seed=2)
+    gx = torch.Generator().manual_seed(4)
+    x = (torch.randn(M, C, generator=gx) * 1.3 + 0.2).to(DEV)            # NOT bf16-exact: the stream is fp32
+    dres = torch.randn(M, C, generator=gx).to(DEV)
+    w, b = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    rng = torch.tensor([77, 3], dtype=torch.int64, device=DEV)
+    out = []
+    for mixed in (False, True):
+        ydt = BF if mixed else torch.float32
+        y, mean, rstd = torch.empty(M, C, dtype=ydt, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        ops.layernorm_fwd(x, w, b, y, mean, rstd)
+        dx, dxd = torch.empty(M, C, device=DEV), torch.empty(M, C, dtype=ydt, device=DEV)
+        dw, db, cs = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        g = g16 if mixed else g16.float()
+        ops.layernorm_bwd(g, x, w, b, mean, rstd, dx, dw, db, dres=dres, dx_dropped=dxd, drop_p=drop_p,
+                          rng_state=rng if drop_p > 0 else None, rng_stream=5, dx_colsum=cs)
+        out.append((mean, rstd, y, dx, dxd, dw, db, cs))
+    f, h = out
+    assert torch.equal(f[0], h[0]) and torch.equal(f[1], h[1])
+    _same(h[2], f[2])
+    assert torch.equal(f[3], h[3]), float((f[3] - h[3]).abs().max())     # dx: the same fp32 arithmetic on the same numbers
+    _same(h[4], f[4])
+    assert torch.equal(f[5], h[5]) and torch.equal(f[6], h[6])
+    if drop_p == 0.0:
+        assert torch.equal(h[4], h[3].to(BF))
+    # column sums: of the copy that LEAVES (the bf16 kernel sums the fp32 value before rounding, like the fp32 kernel)
+    assert (f[7] - h[7]).abs().max().item() <= 1e-5 * max(1.0, f[7].abs().max().item())
+
+
+def test_tokens_and_pool_adjoint_with_the_fp32_token_stream():
+    """bf16 feature maps, fp32 token matrix / token gradient (the transformers' residual stream): mmfn_tokens_fwd_bf16(tok_is_f32)
+    and mmfn_pool_bcast_add_bf16(gtok_is_f32) against the fp32 kernels on the same numbers; the bf16 GEMM's fp32 residual."""
+    from mmfn_amd import ops, ops16
+    B, S, C, T = 2, 32, 64, 192
+    feats = [_r(B, S, S, C, seed=i) for i in range(3)]
+    pos, vw, vb, vel = torch.randn(T, C, device=DEV), torch.randn(C, device=DEV), torch.randn(C, device=DEV), torch.rand(B, device=DEV)
+    rng = torch.tensor([5, 1], dtype=torch.int64, device=DEV)
+    t32 = ops.tokens_fwd([f.float() for f in feats], pos, vw, vb, vel, torch.empty(B, T, C, device=DEV), 0.1, rng, 3)
+    tmix = ops.tokens_fwd(feats, pos, vw, vb, vel, torch.empty(B, T, C, device=DEV), 0.1, rng, 3)
+    assert tmix.dtype == torch.float32 and torch.equal(tmix, t32)
+    G = _r(B, S, S, C, seed=11)
+    gtok = torch.randn(B, T, C, device=DEV)
+    for m in range(3):
+        d32 = ops.pool_bcast_add(G.float(), gtok, torch.empty(B, S, S, C, device=DEV), m)
+        dmix = ops.pool_bcast_add(G, gtok, torch.empty(B, S, S, C, dtype=BF, device=DEV), m)
+        _same(dmix, d32)
+    # x1 = x + Linear(o): bf16 operands, fp32 residual in, fp32 sum out
+    M, K, N = 384, 256, 256
+    o, wt = _r(M, K, seed=21), _r(N, K, seed=22, scale=0.05)
+    bias, res = torch.randn(N, device=DEV), torch.randn(M, N, device=DEV)
+    got = ops16.linear_fwd(o, wt, bias, out=torch.empty(M, N, device=DEV), res=res, ldr=N)
+    ref = o.float() @ wt.float().t() + bias + res
+    assert got.dtype == torch.float32 and (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 def test_pooling_tokens_upsample_gap_transposes():
     from mmfn_amd import ops
     B, S, C, T = 2, 32, 64, 192

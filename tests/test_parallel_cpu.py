@@ -64,8 +64,20 @@ def _worker(rank, world, port, out):
     g = m.encoder.layer3.weight.grad
     off, n = L.offsets["encoder.layer3.weight"]
     ok_view = torch.equal(g.permute(0, 2, 3, 1).reshape(-1), expect[off:off + n]) and m.encoder.unused.weight.grad is None
+    # bf16 buckets (the bf16 training mode's wire format): cast -> sum -> cast back into the fp32 buffer; small integers are exact
+    dp16 = DataParallel(m, dist, max_bucket_bytes=64, grad_dtype="bf16")
+    vals = (torch.arange(L.total) % 61).float()
+    L.grads.copy_(vals * (rank + 1) + 0.001953125 * rank)     # rank 1 carries a fraction that bf16 drops: 2^-9
+    tail_before = L.grads[L.tail:].clone()
+    dp16.begin()
+    for stage in range(4):
+        dp16.on_stage(stage)
+    dp16.finish()
+    want = sum((vals * (r + 1) + 0.001953125 * r).bfloat16().float() for r in range(world)).bfloat16().float()
+    ok_sum16 = torch.equal(L.grads[:L.tail], want[:L.tail]) and torch.equal(L.grads[L.tail:], tail_before) \
+        and dp16.bytes_per_step() * 2 == dp.bytes_per_step() and L.grads.dtype == torch.float32
     if rank == 0:
-        out.put((same_params, covered, ok_sum, ok_tail, ok_view, dp.world))
+        out.put((same_params, covered, ok_sum, ok_tail, ok_view, dp.world, ok_sum16))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -81,13 +93,14 @@ def test_bucketed_allreduce_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    same_params, covered, ok_sum, ok_tail, ok_view, world = res
+    same_params, covered, ok_sum, ok_tail, ok_view, world, ok_sum16 = res
     assert world == 2
     assert same_params, "rank-0 broadcast did not equalise the parameters"
     assert covered, "gradient buckets must tile the trained range exactly"
     assert ok_sum, "all-reduce (sum) over the trained range"
     assert ok_tail, "never-trained tail must be excluded from the reduction"
     assert ok_view, "p.grad views alias the reduced flat buffer"
+    assert ok_sum16, "bf16 buckets: the fp32 gradient buffer must hold bf16(sum of the bf16-rounded buckets); half the bytes"
 
 
 def test_stage_order_of_real_model():

@@ -130,6 +130,64 @@ def test_single_graph_data_parallel_step_with_captured_collectives():
     assert torch.equal(outs[0][0], outs[1][0])
 
 
+def test_bf16_gradient_buckets_through_the_c_abi_and_inside_one_graph():
+    """mmfn_allreduce_sum_bf16 (include/mmfn_comm.h): the bf16 training mode's buckets are cast to bf16, summed by RCCL, and
+    cast back into the fp32 gradient buffer on the communication stream.  1-rank communicator: the 'sum' is the identity, so
+    after the exchange the gradient buffer must hold exactly the bf16 rounding of the local gradients (and the never-trained
+    tail untouched); the whole step - forward, backward, 17+ (cast, all-reduce, cast) triples, AdamW - captures into ONE hipGraph
+    whose replays equal eager data-parallel steps bit for bit."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    from mmfn_amd.comm import RcclComm
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd.model import MMFN
+    from mmfn_amd.parallel import DataParallel, GraphedStep
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    inp, gt = bench.synth_inputs(2, dev, seed=3, lanes=16, n_lidar=4096)
+    comm = RcclComm(0, 1)
+    nets = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        net = MMFN(GlobalConfig(act_dtype="bf16"), dev)
+        net.train()
+        nets.append(net)
+    dps = [DataParallel(n, _OneRank, comm=comm, max_bucket_bytes=16 << 20) for n in nets]
+    assert all(d.grad_dtype == "bf16" for d in dps) and dps[0].bytes_per_step() == 2 * nets[0]._layout.tail   # the mode's default
+    # the exchange itself
+    eng, dp, L = nets[0]._engine_for(), dps[0], nets[0]._layout
+    eng.rng_state.copy_(nets[1]._engine_for().rng_state)
+    from mmfn_amd import ops
+    ops.rng_advance(eng.rng_state)
+    eng.forward(inp, True, gt)
+    eng.backward()
+    torch.cuda.synchronize()
+    local = L.grads.clone()
+    dp.begin()
+    for key in dp.group_order:
+        dp.reduce(key)
+    dp.finish()
+    torch.cuda.synchronize()
+    assert torch.equal(L.grads[:L.tail], local[:L.tail].bfloat16().float()) and torch.equal(L.grads[L.tail:], local[L.tail:])
+    assert not torch.equal(L.grads[:L.tail], local[:L.tail])
+    # eager data-parallel steps == the single captured graph
+    nets[0].load_state_dict(nets[1].state_dict())
+    eng.rng_state.copy_(nets[1]._engine_for().rng_state)
+    eng.step_count.copy_(nets[1]._engine_for().step_count)
+    for _ in range(3):
+        la = eng.train_step(inp, gt, dp=dp)
+    e1 = nets[1]._engine_for()
+    step = GraphedStep(e1, dps[1], inp, gt, warm=1)
+    assert step.single_graph and step.recorder.n_graphs == 1
+    for _ in range(2):
+        lb = step()
+    torch.cuda.synchronize()
+    assert float(la.item()) == float(lb.item())
+    assert torch.equal(nets[0]._layout.params, nets[1]._layout.params)
+    comm.destroy()
+
+
 @pytest.mark.parametrize("dtype", ["bf16"])   # (f32 on the same data-parallel path: the lock-step test above; each run moves 419 MB
 def test_bench_launches_its_own_ranks(dtype):  # of gradients per step through gloo on the host, ~4 minutes on a slow box)
     """`python bench.py --gpus 2` with no outer launcher (how the driver starts the single-GPU bench): bench.py starts the two
@@ -139,7 +197,7 @@ def test_bench_launches_its_own_ranks(dtype):  # of gradients per step through g
     import json
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(MMFN_BENCH_SINGLE_DEVICE="1", OMP_NUM_THREADS="4")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline",
            "--no-oracle-check", "--profile-steps", "1", "--dtype", dtype]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     tail = (r.stdout + r.stderr)[-3000:]

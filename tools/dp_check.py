@@ -61,7 +61,8 @@ def main():
     if os.environ.get("MMFN_DP_TRANSPORT", "auto") != "torch" and backend == "nccl":
         # buckets through libmmfn_comm.so (C ABI over RCCL; the step is then ONE hipGraph with the collectives inside) - the
         # transport bench.py selects by itself when the library's communicator comes up
-        comm, _ = bench.open_capi_transport(rank, world, dist, dev, required=os.environ.get("MMFN_DP_TRANSPORT") == "capi")
+        from mmfn_amd.comm import open_transport
+        comm, _ = open_transport(rank, world, dist, dev, required=os.environ.get("MMFN_DP_TRANSPORT") == "capi")
     dp = DataParallel(net, dist, comm=comm); dp.broadcast_parameters()
     batch = int(os.environ.get("DP_CHECK_BATCH", "2"))   # per rank; the nccl test runs the benched 32
     inp, gt = bench.synth_inputs(batch, dev, seed=7 + rank, lanes=16 if batch <= 2 else 64, n_lidar=4096 if batch <= 2 else 16384)
