@@ -62,18 +62,87 @@ def test_bf16_mode_tracks_the_fp32_path(variant, batch):
     if variant == "vec":
         assert dt["vec.gen.pre"] == torch.float32 and dt["vec.out"] == torch.bfloat16
     assert dt["gpt4.S.gh"] == torch.bfloat16 and dt["img.l3.1.c2.dconv"] == torch.bfloat16
+    # ... and the transformers' residual stream and its gradient stay fp32, like torch.autocast's (x + Linear(LN(x)))
+    assert dt["gpt4.b0.x1"] == torch.float32 and dt["gpt4.x0"] == torch.float32 and dt["gpt4.S.g"] == torch.float32
+    assert dt["gpt4.S.a"] == torch.bfloat16 and dt["gpt4.S.gdrop"] == torch.bfloat16
     cos = _stage_cosines(a._layout, b._layout)
-    # stage 0 (fusion scale 4 + head: the gradient before it has passed the deep BatchNorm stacks) must be clean; the others are
-    # bounded by what torch.autocast(bfloat16) itself reaches on this network (CPU oracle, same init: 0.998 / 0.84 / 0.79 / 0.79
-    # at batch 8 - DESIGN.md section 7), minus a margin for the bf16 residual stream autocast keeps in fp32
-    assert cos[0] >= 0.97, cos
-    assert min(cos[1:]) >= 0.60, cos
-    # eval-mode forward (running statistics): waypoints to bf16 accuracy of their scale
+    print("\n[%s B=%d] bf16 mode vs fp32 path: loss %.6f / %.6f, per-stage gradient cosine %s" % (
+        variant, batch, lb, la, " ".join("%.4f" % c for c in cos)))
+    # sanity floors only: the yardstick test is test_bf16_mode_gradient_direction_against_torch_autocast below (measured at
+    # vec B=32: 0.994 / 0.838 / 0.797 / 0.789; round 3, with a bf16 residual stream in the transformers: 0.989 / 0.763 / 0.715 / 0.718)
+    assert cos[0] >= (0.985 if batch >= 8 else 0.97), cos
+    assert min(cos[1:]) >= (0.70 if batch >= 8 else 0.55), cos
+    # eval-mode forward: waypoints to bf16 accuracy of their scale.  One train-mode forward with BatchNorm momentum 1.0 first
+    # (running statistics := batch statistics, as oracle/make_golden.py does): with the freshly initialised running statistics
+    # (0, 1) the eval network runs 85 BatchNorms far off their operating point and any rounding difference is amplified
+    import torch.nn as nn
+    for net, eng in ((a, ea), (b, eb)):
+        bns = [m for m in net.modules() if isinstance(m, nn.BatchNorm2d)]
+        for m in bns:
+            m.momentum = 1.0
+        eng.forward(inp, True, gt)
+        for m in bns:
+            m.momentum = 0.1
     a.eval(), b.eval()
     with torch.no_grad():
         pa, _ = ea.forward(inp, False, None)
         pb, _ = eb.forward(inp, False, None)
-    assert float((pa - pb).abs().max()) <= 5e-2 * float(pa.abs().max())   # ~100 bf16 layers deep
+    err, scale = float((pa - pb).abs().max()), float(pa.abs().max())
+    assert err <= 5e-2 * scale, (err, scale)   # ~100 bf16 layers deep
+
+
+@pytest.mark.parametrize("batch", [8, 32])
+def test_bf16_mode_gradient_direction_against_torch_autocast(batch):
+    """The yardstick the round-3 review asked for.  What does bf16 arithmetic do to THIS network's gradient?  PyTorch's own
+    answer: the CPU oracle under torch.autocast(bfloat16) against itself in fp32 - same reference-style initialisation
+    (seed 42), same batch, per backward stage.  The HIP bf16 mode against the HIP fp32 path must reach that cosine - 0.03 in
+    every stage (measured: it is ABOVE autocast in every stage - batch 8: 0.9985 / 0.856 / 0.816 / 0.804 against 0.9982 / 0.839 /
+    0.795 / 0.783 - since the transformers' residual stream stays fp32 like autocast's; with the bf16 stream of round 3 the mode
+    sat 0.035-0.08 BELOW it, and the CPU experiment tools/experiments/bf16_where.py reproduces that drop by rounding the stream
+    alone).  And the loss of the bf16 step against the ORACLE (fp32, CPU): within 2e-3 relative."""
+    import bench
+    from mmfn_amd.params import FlatLayout
+    from oracle import harness
+    torch.set_num_threads(bench.usable_cores())
+    a, b, inp, gt = _pair(batch)
+    ea, eb = a._engine_for(), b._engine_for()
+    _, la = ea.forward(inp, True, gt)
+    ea.backward()
+    _, lb = eb.forward(inp, True, gt)
+    eb.backward()
+    torch.cuda.synchronize()
+    cos_hip = _stage_cosines(a._layout, b._layout)
+    oracle = harness.build_oracle("vec", dropout=0.0)
+    oracle.load_state_dict({k: v.detach().cpu() for k, v in a.state_dict().items()}, strict=True)   # the weights before the step
+    cpu = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in inp.items()}
+    args = harness.forward_args(bench.oracle_batch_from_inputs(cpu, "vec"), "vec")
+
+    def oracle_grads(autocast):
+        oracle.train()
+        for p in oracle.parameters():
+            p.grad = None
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            pred = oracle(*args)
+        loss = harness.l1_waypoint_loss(pred.float(), gt.cpu())
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.detach().clone() for k, p in oracle.named_parameters() if p.grad is not None}
+
+    # (BatchNorm running statistics move in these train-mode forwards; the gradients do not depend on them)
+    lo32, go32 = oracle_grads(False)
+    lo16, go16 = oracle_grads(True)
+    cos_ref = []
+    for st in range(4):
+        names = [k for k in go32 if FlatLayout.stage_of(k) == st]
+        x = torch.cat([go32[k].flatten().double() for k in names])
+        y = torch.cat([go16[k].flatten().double() for k in names])
+        cos_ref.append(float(torch.dot(x, y) / (x.norm() * y.norm())))
+    print("\n[vec B=%d] per-stage gradient cosine to the fp32 gradient: HIP bf16 mode %s | torch.autocast(bfloat16) on the CPU oracle %s"
+          % (batch, " ".join("%.4f" % c for c in cos_hip), " ".join("%.4f" % c for c in cos_ref)))
+    print("    loss: HIP bf16 %.6f  HIP fp32 %.6f  oracle fp32 %.6f  oracle autocast %.6f" % (float(lb), float(la), lo32, lo16))
+    for st in range(4):
+        assert cos_hip[st] >= cos_ref[st] - 0.03, (st, cos_hip, cos_ref)
+    assert abs(float(lb) - lo32) <= 2e-3 * abs(lo32), (float(lb), lo32)
+    assert abs(float(la) - lo32) <= 1e-4
 
 
 def test_bf16_steps_reduce_the_loss_like_fp32_steps():
