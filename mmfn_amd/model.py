@@ -56,8 +56,23 @@ class _AutogradBridge(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dpred):
         m = ctx.module
+        L = m._layout
+        # torch semantics: backward ACCUMULATES into a .grad that exists and writes one that does not (after
+        # optimizer.zero_grad() / p.grad = None, phase2_train_net.py:60).  The explicit backward overwrites the flat gradient
+        # buffer, so when the previous gradients are still attached they are parked and added back (two extra passes over the
+        # buffer, on this path only; the fused Engine.train_step never accumulates)
+        held = next((p.grad for n, p in m.named_parameters() if n not in L.unused), None)
+        accumulate = held is not None and held.data_ptr() >= L.grads.data_ptr() and \
+            held.data_ptr() < L.grads.data_ptr() + L.grads.numel() * 4
+        if accumulate:
+            if getattr(L, "grads_parked", None) is None:
+                L.grads_parked = torch.empty_like(L.grads)
+            L.grads_parked.copy_(L.grads)
         m._engine_for().backward(dpred.contiguous(), 1.0)
-        m._layout.attach_grads()
+        if accumulate:
+            from . import ops
+            ops.axpby(L.grads[:L.tail], L.grads_parked[:L.tail], 1.0, 1.0)
+        L.attach_grads()
         m.weights_changed()   # an optimizer step on p.grad follows
         return None, None, None
 

@@ -235,6 +235,41 @@ def test_fused_train_step_equals_autograd_path():
             assert (sa[k] - sb[k]).abs().max().item() <= 1e-6, k
 
 
+def test_backward_accumulates_into_existing_gradients_like_torch():
+    """loss.backward() twice without zeroing: .grad holds the SUM (torch.autograd semantics the reference's loop relies on
+    implicitly, phase2_train_net.py:60 zero_grad / :106 backward); after p.grad = None / zero_grad() the next backward starts
+    afresh.  The explicit HIP backward overwrites its flat buffer, so the bridge parks and re-adds what was attached."""
+    oracle, net, batch, args = _setup("vec")
+    dargs = _dev_args(args)
+    gt = batch["gt_wp"].to(DEV)
+    net.train()
+    loss = lambda: torch.nn.functional.l1_loss(net(*dargs), gt, reduction="none").mean()
+    loss().backward()
+    once = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    assert len(once) > 1000
+    loss().backward()                                   # second backward, nothing zeroed: 2 x the gradient, exactly
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, 2.0 * once[n]), n
+    net.zero_grad()                                     # set_to_none: a fresh start
+    assert all(p.grad is None for p in net.parameters())
+    loss().backward()
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, once[n]), n
+    # the oracle does the same
+    for p in oracle.parameters():
+        p.grad = None
+    oracle.train()
+    for _ in range(2):
+        torch.nn.functional.l1_loss(oracle(*args), batch["gt_wp"], reduction="none").mean().backward()
+    ref = dict(oracle.named_parameters())["join.0.weight"].grad
+    net.zero_grad()
+    loss().backward(); loss().backward()
+    got = dict(net.named_parameters())["join.0.weight"].grad.cpu()
+    assert (got - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+
+
 def test_raw_sensor_ingest_path_equals_tensor_path():
     """u8 camera frames + XYZI points through the GPU ingest/splat kernels == preprocessed tensors."""
     oracle, net, batch, args = _setup("vec")

@@ -2,6 +2,7 @@ cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out/profiles
 (timeout 1500 python -m pytest tests/test_bf16_mode_gpu.py -x -q -s 2>&1 | grep -v "^$" | grep "bf16 mode\|autocast\|loss:\|passed\|failed\|Error\|assert" | cut -c1-400) > gpurun_out/r7_tests.log 2>&1
+timeout 600 python -m pytest tests/test_e2e_gpu.py -x -q -k "accumulates or fused_train_step" 2>&1 | tail -4 >> gpurun_out/r7_tests.log
 cat gpurun_out/r7_tests.log
 # fp32 profile of the round
 timeout 1500 bash tools/profile_round.sh r04a > gpurun_out/r7_prof.log 2>&1
