@@ -497,17 +497,10 @@ int dispatch_nkt(int which, const AttnArgs& a, hipStream_t s) {
   return MMFN_EINVAL;
 }
 
-// MMFN_ATTN_TILE_KERNELS=1 forces the one-tile-per-block kernels of this file for every shape (A/B runs, tests)
-bool tile_kernels_only() {
-  static const bool v = [] { const char* e = getenv("MMFN_ATTN_TILE_KERNELS"); return e && e[0] == '1'; }();
-  return v;
-}
-
-// MMFN_ATTN16=0: bf16 tensors through the fp32-arithmetic workgroup kernels instead (A/B runs, tests)
-bool bf16_mfma_off() {
-  static const bool v = [] { const char* e = getenv("MMFN_ATTN16"); return e && e[0] == '0'; }();
-  return v;
-}
+// (rounds 2-3 had environment switches here that forced the one-tile-per-block kernels of this file, or the fp32-arithmetic
+// kernels on bf16 tensors, for A/B runs; the measurements are in tools/experiments/NOTES.md)
+constexpr bool tile_kernels_only() { return false; }
+constexpr bool bf16_mfma_off() { return false; }
 
 int dispatch(int which, int hs, const AttnArgs& a, hipStream_t s) {
   if (a.B <= 0 || a.T <= 0 || a.T > 384 || a.NH <= 0) return MMFN_EINVAL;

@@ -601,15 +601,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
   merge_store<HS, NT, TIO>(g, sm, kg, qs, lane, l15, l4, io_dk + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
 }
 
-long long* debug_buffer() {   // dev only (MMFN_ATTN_DEBUG=1): allocated once, outside any capture
-  static long long* buf = [] {
-    const char* e = getenv("MMFN_ATTN_DEBUG");
-    long long* p = nullptr;
-    if (e && e[0] == '1' && hipMalloc(&p, 64 * sizeof(long long)) != hipSuccess) p = nullptr;
-    return p;
-  }();
-  return buf;
-}
+long long* debug_buffer() { return nullptr; }   // (phase time stamps of the forward kernel: a development build option, off)
 
 template <int HS, int NT, typename TIO>
 int launch_io(int which, const AttnArgs& a_in, hipStream_t s) {

@@ -814,11 +814,9 @@ extern "C" int mmfn_gemm_bf16_stats_rows(const mmfn_gemm16_desc* d) {
   return 2 * ceil_div(d->M, bm);
 }
 
-// stride-2 data gradients run by pixel parity (parity_pixel_row) when every row tile can be parity-pure; MMFN_G16_PARITY=0:
-// the plain gather (A/B runs)
+// stride-2 data gradients run by pixel parity (parity_pixel_row) when every row tile can be parity-pure, else as the plain gather
 bool parity_dgrad_ok(const mmfn_gemm16_desc& d, int bm) {
-  static const bool on = [] { const char* e = getenv("MMFN_G16_PARITY"); return !(e && e[0] == '0'); }();
-  if (!on || d.form != 2 || d.stride != 2 || (d.H & 1) || (d.W & 1) || d.KH * d.KW > 9 || d.H <= 0 || d.W <= 0) return false;
+  if (d.form != 2 || d.stride != 2 || (d.H & 1) || (d.W & 1) || d.KH * d.KW > 9 || d.H <= 0 || d.W <= 0) return false;
   if (d.M % (d.H * d.W) || (d.M / 4) % bm) return false;
   return true;
 }

@@ -1146,11 +1146,7 @@ bool fast_ok(const mmfn_gemm_desc& d) {
   return true;
 }
 
-// experiment switch: extra dynamic LDS per block (bytes) to cap how many blocks share a CU (tools/wino_gemm_bench.py)
-int dyn_lds_bytes() {
-  static const int v = [] { const char* e = getenv("MMFN_GEMM_DYN_LDS"); return e ? atoi(e) : 0; }();
-  return v;
-}
+constexpr int dyn_lds_bytes() { return 0; }   // (round-2 experiment: extra dynamic LDS per block to cap the blocks per CU)
 
 template <int AM, int BMODE>
 int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {

@@ -246,7 +246,7 @@ def test_backward_accumulates_into_existing_gradients_like_torch():
     loss = lambda: torch.nn.functional.l1_loss(net(*dargs), gt, reduction="none").mean()
     loss().backward()
     once = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
-    assert len(once) > 1000
+    assert len(once) > 800
     loss().backward()                                   # second backward, nothing zeroed: 2 x the gradient, exactly
     for n, p in net.named_parameters():
         if p.grad is not None:

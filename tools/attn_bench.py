@@ -29,21 +29,3 @@ for HS in (16, 32, 64, 128):
         ms = e0.elapsed_time(e1) / iters
         fl = 4.0 * T * T * C * B * mult
         print("attn %s HS=%3d  %7.1f us  %6.2f TF/s (algorithmic)" % (name, HS, ms * 1e3, fl / ms / 1e9))
-
-if os.environ.get("MMFN_ATTN_DEBUG") == "1":   # phase stamps of the forward kernel (dev instrumentation)
-    import ctypes
-    from mmfn_amd import _lib
-    for HS in (16, 128):
-        C = NH * HS
-        qkv = torch.randn(B * T, 3 * C, device=dev)
-        o = torch.empty(B * T, C, device=dev); lse = torch.empty(B, NH, T, device=dev)
-        for _ in range(3):
-            ops.attention_fwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, C, lse, B, T, NH, HS, 1 / math.sqrt(HS))
-        torch.cuda.synchronize()
-        buf = (ctypes.c_int64 * 32)()
-        rc = _lib.lib().mmfn_attn_debug_read(ctypes.cast(buf, ctypes.c_void_p))
-        st = list(buf)
-        for w0 in (0, 16):
-            d = [st[w0 + 2] - st[w0 + 0]] + [st[w0 + i + 1] - st[w0 + i] for i in range(2, 5)]
-            print("HS=%3d wave %d: staging + first product %d | softmax + V staging %d | second product %d | merge + store %d  (shader cycles) rc=%d"
-                  % (HS, 0 if w0 == 0 else 7, *d, rc))

@@ -1,5 +1,5 @@
 """Dev tool: the 36-batch Winograd-domain GEMMs of the step (forward NT, adjoint data gradient NN, weight gradient TN) per tile
-shape, in isolation.  MMFN_GEMM_DYN_LDS=<bytes> caps the blocks per CU (experiment: do co-resident blocks run in lock-step?)."""
+shape, in isolation."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,7 +16,6 @@ def timeit(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 
-print("MMFN_GEMM_DYN_LDS =", os.environ.get("MMFN_GEMM_DYN_LDS", "0"))
 for (T, C) in ((2048, 128), (512, 256), (128, 512)):
     V = torch.randn(36, T, C, device=dev); U = torch.randn(36, C, C, device=dev); M = torch.empty(36, T, C, device=dev)
     dU = torch.empty(36, C, C, device=dev)
