@@ -86,11 +86,17 @@ __device__ __forceinline__ void strow(float* p, const float* src) {
   }
 }
 
+// Register budget: up to 8 key tiles (256 keys) the kernels fit 256 VGPRs at two waves per SIMD.  The 12-tile instantiations
+// (257-384 keys: several frames per sample) keep 2 x 6 accumulator tiles of S^T / dP^T live and spilled 132-368 bytes per lane to
+// scratch in rounds 1-3; they are compiled for ONE wave per SIMD instead (amdgpu_waves_per_eu(1, 1)): the unified register file
+// then gives a wave 512 registers and the overflow lives in AGPRs - ScratchSize 0 for every kernel of this file
+// (-Rpass-analysis=kernel-resource-usage).  Their grids (12 query tiles x heads x batch blocks of two waves) are about one wave
+// per SIMD anyway.
 // Two waves per 32-query tile, each owning half of the key tiles: the per-wave state halves (S^T is NKT/2
 // accumulator tiles), so two waves fit on a SIMD and one wave's softmax / load latency hides under the other's
 // MFMAs.  The halves meet through LDS: (row max, row sum) first, then the partial O tiles, merged flash-style.
 template <int HS, int NKT>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NKT > 8 ? 1 : 2, NKT > 8 ? 1 : 2))) void attn_fwd_kernel(const AttnArgs a) {
   constexpr int NC = HS / 8;
   constexpr int ND = (HS + 31) / 32;
   constexpr int NK2 = NKT / 2;
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
 // query-owned backward pass: delta = sum_j P_j dP_j, dQ.  Same two-wave key split as the forward: the halves
 // exchange their partial (sum P dP, sum P) before forming dS, and their partial dQ tiles at the end.
 template <int HS, int NKT>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NKT > 8 ? 1 : 2, NKT > 8 ? 1 : 2))) void attn_bwd_dq_kernel(const AttnArgs a) {
   constexpr int NC = HS / 8;
   constexpr int ND = (HS + 31) / 32;
   constexpr int NK2 = NKT / 2;
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void a
 // key-owned backward pass: dK, dV.  Two waves per 32-key tile, each owning half of the query tiles; the partial
 // dK / dV tiles are summed through LDS.
 template <int HS, int NKT>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2))) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(NKT > 8 ? 1 : 2, NKT > 8 ? 1 : 2))) void attn_bwd_dkv_kernel(const AttnArgs a) {
   constexpr int NC = HS / 8;
   constexpr int ND = (HS + 31) / 32;
   constexpr int NK2 = NKT / 2;

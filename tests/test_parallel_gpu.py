@@ -135,10 +135,12 @@ def test_bf16_gradient_buckets_through_the_c_abi_and_inside_one_graph():
     cast back into the fp32 gradient buffer on the communication stream.  1-rank communicator: the 'sum' is the identity, so
     after the exchange the gradient buffer must hold exactly the bf16 rounding of the local gradients (and the never-trained
     tail untouched); the whole step - forward, backward, 17+ (cast, all-reduce, cast) triples, AdamW - captures into ONE hipGraph
-    whose replays equal eager data-parallel steps bit for bit."""
+    whose replays equal eager data-parallel steps bit for bit.  (One network, one DataParallel, one communication stream
+    throughout: the communicator is only ever driven from that stream.)"""
     import torch
     sys.path.insert(0, ROOT)
     import bench
+    from mmfn_amd import ops
     from mmfn_amd.comm import RcclComm
     from mmfn_amd.config import GlobalConfig
     from mmfn_amd.model import MMFN
@@ -147,18 +149,23 @@ def test_bf16_gradient_buckets_through_the_c_abi_and_inside_one_graph():
     torch.cuda.set_device(0)
     inp, gt = bench.synth_inputs(2, dev, seed=3, lanes=16, n_lidar=4096)
     comm = RcclComm(0, 1)
-    nets = []
-    for _ in range(2):
-        torch.manual_seed(5)
-        net = MMFN(GlobalConfig(act_dtype="bf16"), dev)
-        net.train()
-        nets.append(net)
-    dps = [DataParallel(n, _OneRank, comm=comm, max_bucket_bytes=16 << 20) for n in nets]
-    assert all(d.grad_dtype == "bf16" for d in dps) and dps[0].bytes_per_step() == 2 * nets[0]._layout.tail   # the mode's default
-    # the exchange itself
-    eng, dp, L = nets[0]._engine_for(), dps[0], nets[0]._layout
-    eng.rng_state.copy_(nets[1]._engine_for().rng_state)
-    from mmfn_amd import ops
+    torch.manual_seed(5)
+    net = MMFN(GlobalConfig(act_dtype="bf16"), dev)
+    net.train()
+    dp = DataParallel(net, _OneRank, comm=comm, max_bucket_bytes=16 << 20)
+    eng, L = net._engine_for(), net._layout
+    assert dp.grad_dtype == "bf16" and dp.bytes_per_step() == 2 * L.tail and dp.n_buckets() >= 17   # the mode's default
+    init = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    rng0, step0 = eng.rng_state.clone(), eng.step_count.clone()
+
+    def reset():
+        net.load_state_dict(init)
+        eng.rng_state.copy_(rng0)
+        eng.step_count.copy_(step0)
+        L.exp_avg.zero_()
+        L.exp_avg_sq.zero_()
+
+    # ---- the exchange itself
     ops.rng_advance(eng.rng_state)
     eng.forward(inp, True, gt)
     eng.backward()
@@ -171,20 +178,22 @@ def test_bf16_gradient_buckets_through_the_c_abi_and_inside_one_graph():
     torch.cuda.synchronize()
     assert torch.equal(L.grads[:L.tail], local[:L.tail].bfloat16().float()) and torch.equal(L.grads[L.tail:], local[L.tail:])
     assert not torch.equal(L.grads[:L.tail], local[:L.tail])
-    # eager data-parallel steps == the single captured graph
-    nets[0].load_state_dict(nets[1].state_dict())
-    eng.rng_state.copy_(nets[1]._engine_for().rng_state)
-    eng.step_count.copy_(nets[1]._engine_for().step_count)
+    # ---- three eager data-parallel steps ...
+    reset()
     for _ in range(3):
         la = eng.train_step(inp, gt, dp=dp)
-    e1 = nets[1]._engine_for()
-    step = GraphedStep(e1, dps[1], inp, gt, warm=1)
+    torch.cuda.synchronize()
+    want, la = L.params.clone(), float(la.item())
+    # ... == one eager step + two replays of the single captured graph
+    reset()
+    step = GraphedStep(eng, dp, inp, gt, warm=1)
     assert step.single_graph and step.recorder.n_graphs == 1
     for _ in range(2):
         lb = step()
     torch.cuda.synchronize()
-    assert float(la.item()) == float(lb.item())
-    assert torch.equal(nets[0]._layout.params, nets[1]._layout.params)
+    assert la == float(lb.item())
+    assert torch.equal(want, L.params)
+    del step
     comm.destroy()
 
 
