@@ -121,6 +121,7 @@ enum {
                                   bf16 MFMA, fp32 accumulate / epilogue / output (autocast-style; BASELINE configs[2]) */
   MMFN_EPI_BF16X3 = 256    /* fp32 arithmetic on the bf16 MFMA pipe (plain GEMM forms): each operand element split exactly
                               into three bf16 terms, six cross products accumulated in fp32: product error < 2^-22 relative */,
+  MMFN_EPI_LN_FOLD = 4096, /* see mmfn_gemm_desc.ln_c1 */
   MMFN_EPI_RELU_LAST = 512 /* max(v, 0) as the LAST step, after residual / accumulate: conv + folded BatchNorm + skip + ReLU in one
                               launch (eval mode, mmfn_bn_fold_f32) */
 };
@@ -150,6 +151,18 @@ typedef struct mmfn_gemm_desc {
   int32_t batch;
   int32_t dg_parity; /* internal: set by the launcher for stride-2 dgrad (output-parity decomposition) */
   int64_t strideA, strideB, strideC;
+  /* MMFN_EPI_LN_FOLD (NT form, K = the LayerNorm width): C = LN(A) . B^T + b computed as
+   *   rstd_m * (A . B'^T - mean_m * c1_n) + c2_n,   B' = B . diag(gamma), c1_n = sum_k B'_nk, c2_n = sum_k beta_k B_nk + b_n
+   * (mmfn_ln_fold_weights_f32 derives B', c1, c2 once per step): the GEMM reads the raw rows through the unchanged
+   * global -> LDS path, accumulates each row's sum and sum of squares from the A fragments it feeds the MFMAs anyway, and applies
+   * the normalisation in the epilogue - native_layer_norm + addmm of model_vec.py:117-118,82-98 (ln1 -> key/query/value) and
+   * :119,121 (ln2 -> mlp.0) in one launch.  B = B', bias = c2, ln_c1 = c1; ln_mean / ln_rstd (optional, [M]) receive the row
+   * statistics the LayerNorm backward needs.  No split-K, M and N multiples of the tile. */
+  const float* ln_c1;
+  float* ln_mean;
+  float* ln_rstd;
+  float ln_eps;
+  int32_t reserved0;
 } mmfn_gemm_desc;
 
 /* ---- bf16 training mode (BASELINE configs[2]): GEMM / implicit-GEMM convolution with bf16 operands in HBM ------------- */
@@ -252,6 +265,11 @@ int mmfn_bn_bwd_f32(const float* g, const float* y, const float* x, int64_t M, i
 int mmfn_bn_bwd_reduce_f32(const float* g, const float* y, const float* x, int64_t M, int C, const float* mean,
                            const float* rstd, const float* relu_weight, const float* relu_bias, float* dweight, float* dbias,
                            float* means, void* workspace, void* stream);
+/* Operands of MMFN_EPI_LN_FOLD (mmfn_gemm_desc.ln_c1) for every (LayerNorm -> Linear) pair of the step in one launch.  table: DEVICE
+ * array of n_entries records { const float* W [N][K]; const float* gamma, *beta [K]; const float* bias [N] or NULL; float* Wf
+ * [N][K]; float* c1, *c2 [N]; int32 N, K; int64 row0 } (72 bytes; row0 = running sum of N, ascending), total_rows = sum of N:
+ *   Wf[n][k] = W[n][k] * gamma[k],  c1[n] = sum_k Wf[n][k],  c2[n] = sum_k beta[k] * W[n][k] + bias[n]   (sums in fp64) */
+int mmfn_ln_fold_weights_f32(const void* table, int n_entries, int64_t total_rows, void* stream);
 /* LayerNorm over rows of x[M,C] (C % 64 == 0, C <= 512), optional fused activation on the output
  * (act: 0 none, 1 ReLU, 2 exact GELU).  Replaces aten native_layer_norm (+relu/gelu) of
  * model_vec.py:117-118,162 (GPT) and :252,335-336,345-346,352-353 (VectorNet). */

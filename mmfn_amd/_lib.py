@@ -15,6 +15,7 @@ A_ROWMAJOR, A_COLMAJOR, A_IM2COL, A_DGRAD = 0, 1, 2, 3
 B_NK, B_KN, B_IM2COL, B_DGRADW = 0, 1, 2, 3
 EPI_BIAS, EPI_RELU, EPI_GELU, EPI_MASK_AUX, EPI_DROPOUT, EPI_RESIDUAL, EPI_ACCUM, EPI_BF16_OPERANDS, EPI_BF16X3 = 1, 2, 4, 8, 16, 32, 64, 128, 256
 EPI_RELU_LAST = 512
+EPI_LN_FOLD = 4096
 
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -34,6 +35,7 @@ class GemmDesc(ctypes.Structure):
         ("flags", _i32), ("splitk", _i32), ("tile", _i32),
         ("rng_stream", ctypes.c_uint32), ("drop_p", _f32),
         ("batch", _i32), ("dg_parity", _i32), ("strideA", _i64), ("strideB", _i64), ("strideC", _i64),
+        ("ln_c1", _vp), ("ln_mean", _vp), ("ln_rstd", _vp), ("ln_eps", _f32), ("reserved0", _i32),
     ]
 
 

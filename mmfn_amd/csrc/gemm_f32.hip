@@ -417,7 +417,12 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 // vmcnt(n) only (expcnt / lgkmcnt untouched): gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
 #define MMFN_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x70 | 0xF00)
 
-template <int AM, int BMODE, int BM, int BN>
+// LNF (NT form only): MMFN_EPI_LN_FOLD - LayerNorm of the A rows folded into the product (mmfn_gemm_desc.ln_c1): every lane
+// sums the A fragment values it feeds to the MFMAs (lane (l31, h) of a wave row sees row l31's k values of its half h: the two
+// halves together see the whole row once), the halves are combined with one shuffle, the row statistics go through 2 * BM
+// floats of LDS to the lanes that hold that row's accumulators, and the interior-tile epilogue starts from
+// rstd * (acc - mean * c1[n]) + c2[n] instead of acc + bias[n].
+template <int AM, int BMODE, int BM, int BN, bool LNF = false>
 __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, const int tiles_n,
                                                            const int log2_ow, const int log2_ohw) {
   const mmfn_gemm_desc d = d_in.dg_parity ? d_in : batch_view(d_in);
@@ -603,6 +608,9 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   f32x4 ra[UA], rb[UB];
+  float ln_s1[TM], ln_s2[TM];   // LNF: this lane's partial (sum x, sum x^2) of rows wm*TM*32 + i*32 + l31
+#pragma unroll
+  for (int i = 0; i < TM; ++i) { ln_s1[i] = 0.f; ln_s2[i] = 0.f; }
   // stage(kt, dst): global -> LDS for one k-tile.  With USE_GLDS the 16-byte pieces go straight to LDS
   // (global_load_lds: wave-uniform LDS base + lane*16, so the image is lane-linear and the slot swizzle
   // is applied to the SOURCE address); otherwise through registers (issue now, ds_write after the MFMAs).
@@ -670,6 +678,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
 #pragma unroll
           for (int j = 0; j < 4; ++j) a[i][j] = As[(c * 8 + h * 4 + j) * BM + row];
         }
+        if (LNF) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { ln_s1[i] += a[i][j]; ln_s2[i] = fmaf(a[i][j], a[i][j], ln_s2[i]); }
+        }
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
@@ -700,6 +712,23 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
     }
   }
 
+  __shared__ float ln_stat[LNF ? 2 * BM : 1];
+  if (LNF) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float s1 = ln_s1[i] + __shfl_xor(ln_s1[i], 32, 64), s2 = ln_s2[i] + __shfl_xor(ln_s2[i], 32, 64);
+      const float mu = s1 / (float)d.K;
+      const float var = fmaxf(s2 / (float)d.K - mu * mu, 0.f);
+      const float rs = 1.0f / sqrtf(var + d.ln_eps);
+      if (wn == 0 && h == 0) {
+        const int rl = wm * TM * 32 + i * 32 + l31;
+        ln_stat[rl] = mu;
+        ln_stat[BM + rl] = rs;
+        if (n0 == 0 && d.ln_mean) { d.ln_mean[m0 + rl] = mu; d.ln_rstd[m0 + rl] = rs; }
+      }
+    }
+    __syncthreads();
+  }
   uint64_t key = 0;
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
   const bool to_slab = d.splitk > 1;
@@ -740,10 +769,17 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
 #pragma unroll
       for (int q = 0; q < TN; ++q) {
         const float bias = (f & MMFN_EPI_BIAS) ? d.bias[lcol + q * 32] : 0.0f;
+        const float c1 = LNF ? d.ln_c1[lcol + q * 32] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int dr = i * 32 + (r & 3) + 8 * (r >> 2);
-          float v = acc[i][q][r] + bias;
+          float v;
+          if (LNF) {
+            const int rl = wm * TM * 32 + dr + 4 * h;
+            v = fmaf(ln_stat[BM + rl], fmaf(-ln_stat[rl], c1, acc[i][q][r]), bias);   // rstd * (acc - mean * c1) + c2
+          } else {
+            v = acc[i][q][r] + bias;
+          }
           if (relu1) v = fmaxf(v, 0.0f);
           if (a0) v = a0[(size_t)dr * d.ldaux + q * 32] > 0.0f ? v : 0.0f;
           if (drop)
@@ -1172,6 +1208,22 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
       MMFN_LAUNCH_CHECK();
       return 0;
     }
+    if (d.flags & MMFN_EPI_LN_FOLD) {
+      if (AM != MMFN_A_ROWMAJOR || BMODE != MMFN_B_NK) return MMFN_EINVAL;
+      const int bm = (tile == 1 || tile == 3) ? 128 : 64, bn = (tile == 1 || tile == 4) ? 128 : 64;
+      if (d.M % bm || d.N % bn || d.batch > 1) return MMFN_EINVAL;
+      dd.splitk = 1;
+      const int tn = d.N / bn;
+      dim3 grid((d.M / bm) * tn, 1, 1);
+      if (AM == MMFN_A_ROWMAJOR && BMODE == MMFN_B_NK) {   // (only this form instantiates the LNF kernels)
+        if (tile == 1) hipLaunchKernelGGL((gemm_f32_fast_kernel<MMFN_A_ROWMAJOR, MMFN_B_NK, 128, 128, true>), grid, dim3(NT), 0, s, dd, 1 << 20, tn, 0, 0);
+        else if (tile == 3) hipLaunchKernelGGL((gemm_f32_fast_kernel<MMFN_A_ROWMAJOR, MMFN_B_NK, 128, 64, true>), grid, dim3(NT), 0, s, dd, 1 << 20, tn, 0, 0);
+        else if (tile == 4) hipLaunchKernelGGL((gemm_f32_fast_kernel<MMFN_A_ROWMAJOR, MMFN_B_NK, 64, 128, true>), grid, dim3(NT), 0, s, dd, 1 << 20, tn, 0, 0);
+        else hipLaunchKernelGGL((gemm_f32_fast_kernel<MMFN_A_ROWMAJOR, MMFN_B_NK, 64, 64, true>), grid, dim3(NT), 0, s, dd, 1 << 20, tn, 0, 0);
+      }
+      MMFN_LAUNCH_CHECK();
+      return 0;
+    }
     const int l_ow = (BMODE == MMFN_B_IM2COL) ? ilog2_exact(d.OW) : 0;
     const int l_ohw = (BMODE == MMFN_B_IM2COL) ? ilog2_exact(d.OH * d.OW) : 0;
 #define MMFN_LAUNCH_FAST(BM_, BN_)                                                                                   \
@@ -1193,6 +1245,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
     return 0;
   }
 #endif
+  if (d.flags & MMFN_EPI_LN_FOLD) return MMFN_EINVAL;   // (needs the fast kernel: 16-byte aligned operands, K a multiple of 16)
 #define MMFN_LAUNCH_TILE(BM_, BN_)                                                                              \
   {                                                                                                             \
     const int tn = ceil_div(d.N, BN_);                                                                          \
@@ -1360,6 +1413,11 @@ extern "C" int mmfn_gemm_f32(const mmfn_gemm_desc* dp, void* stream) {
   if ((d.flags & MMFN_EPI_BIAS) && !d.bias) return MMFN_EINVAL;
   if ((d.flags & MMFN_EPI_RESIDUAL) && !d.res) return MMFN_EINVAL;
   if ((d.flags & MMFN_EPI_MASK_AUX) && !d.aux) return MMFN_EINVAL;
+  if (d.flags & MMFN_EPI_LN_FOLD) {
+    if (!(d.flags & MMFN_EPI_BIAS) || !d.ln_c1 || (d.flags & (MMFN_EPI_BF16_OPERANDS | MMFN_EPI_BF16X3 | MMFN_EPI_GELU | MMFN_EPI_ACCUM)) ||
+        d.a_mode != MMFN_A_ROWMAJOR || d.b_mode != MMFN_B_NK || (d.ln_mean && !d.ln_rstd) || d.ln_eps <= 0.f)
+      return MMFN_EINVAL;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (bf16_ok(d)) return launch_bf16(d, s);
   int tile, sk;

@@ -161,6 +161,54 @@ __global__ __launch_bounds__(256) void shadow_transpose_kernel(const ShadowEntry
 }
 }  // namespace
 
+// ---- LayerNorm folded into the Linear that consumes it (mmfn_gemm_desc.ln_c1): per output row n of every registered Linear
+//   Wf[n][k] = W[n][k] * gamma[k],   c1[n] = sum_k Wf[n][k],   c2[n] = sum_k beta[k] * W[n][k] + bias[n]
+// One wave per row, all layers of the step in one launch (the weights change only at the optimizer step).
+namespace {
+struct LnFoldEntry {   // 72 bytes
+  const float* W; const float* gamma; const float* beta; const float* bias;
+  float* Wf; float* c1; float* c2;
+  int32_t N, K;
+  int64_t row0;        // first global row index of this entry
+};
+
+__global__ __launch_bounds__(256) void ln_fold_weights_kernel(const LnFoldEntry* __restrict__ table, int n_entries, int64_t total_rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= total_rows) return;
+  int lo = 0, hi = n_entries - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].row0 <= row) lo = mid; else hi = mid - 1;
+  }
+  const LnFoldEntry e = table[lo];
+  const int n = (int)(row - e.row0);
+  const float* w = e.W + (size_t)n * e.K;
+  float* wf = e.Wf + (size_t)n * e.K;
+  double s1 = 0.0, s2 = 0.0;
+  for (int k = lane; k < e.K; k += 64) {
+    const float v = w[k], f = v * e.gamma[k];
+    wf[k] = f;
+    s1 += (double)f;
+    s2 += (double)e.beta[k] * (double)v;
+  }
+  s1 = wave_sum_d(s1);
+  s2 = wave_sum_d(s2);
+  if (lane == 0) {
+    e.c1[n] = (float)s1;
+    e.c2[n] = (float)(s2 + (e.bias ? (double)e.bias[n] : 0.0));
+  }
+}
+}  // namespace
+
+extern "C" int mmfn_ln_fold_weights_f32(const void* table, int n_entries, int64_t total_rows, void* stream) {
+  if (!table || n_entries <= 0 || total_rows <= 0) return MMFN_EINVAL;
+  hipLaunchKernelGGL(ln_fold_weights_kernel, dim3((unsigned)((total_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     (const LnFoldEntry*)table, n_entries, total_rows);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmfn_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
   if (n <= 0) return 0;
   if (n % 4 || !in || !out) return MMFN_EINVAL;

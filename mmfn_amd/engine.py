@@ -552,6 +552,12 @@ class LayerNorm(object):
 
 
 # ----------------------------------------------------------------------------- GPT fusion transformer
+# fp32 path: ln1 -> key/query/value and ln2 -> mlp.0 as ONE launch each (MMFN_EPI_LN_FOLD: the LayerNorm folded into the GEMM,
+# include/mmfn_hip.h mmfn_gemm_desc.ln_c1); the normalised tensor only the weight gradient needs is recomputed on the side stream
+# in the backward.  A/B switch; 0 = a LayerNorm launch in front of each of the two GEMMs (the round-3 forward).
+LN_FOLD = os.environ.get("MMFN_LN_FOLD", "1") == "1"
+
+
 class GPT(object):
     """model_vec.py:136-246 (GPT), :112-133 (Block), :73-109 (SelfAttention)."""
 
@@ -580,6 +586,7 @@ class GPT(object):
             blk["wqkv_name"] = bp + ".attn.key.weight"
             blk["wqkv16"] = blk["wqkv16t"] = None   # bf16 shadows (Engine._build_shadows)
             blk["bqkv"], blk["g_bqkv"] = layout.packed(bp + ".attn.key.bias", 3 * C)
+            blk["fold"] = None   # (wqkv * gamma1, c1, c2, fc1.w * gamma2, c1, c2): Engine._build_ln_fold
             self.blocks.append(blk)
         self.ln_f = LayerNorm(name + ".ln_f", layout, prefix + ".ln_f")
 
@@ -608,11 +615,22 @@ class GPT(object):
         S_a, S_a2 = bufs.get(nm + ".S.a", (nb, M, C), adt), bufs.get(nm + ".S.a2", (nb, M, C), adt)
         S_o, S_h = bufs.get(nm + ".S.att", (nb, M, C), adt), bufs.get(nm + ".S.h", (nb, M, 4 * C), adt)
         self.stacks = (S_a, S_a2, S_o, S_h)
+        fold = (not ctx.bf16) and ops.current_precision() == "f32" and self.blocks[0]["fold"] is not None and M % 64 == 0
+        self.folded_fwd = fold
         for i, blk in enumerate(self.blocks):
             sb = self.stream_base + 1 + 3 * i
-            a = blk["ln1"].fwd(ctx, x, out=S_a[i])
             qkv = bufs.get("%s.b%d.qkv" % (nm, i), (M, 3 * C), adt)
-            ops.linear_fwd(a, blk["wqkv16"] if ctx.bf16 else blk["wqkv"], blk["bqkv"], out=qkv)
+            if fold:
+                # LN(x) . Wqkv^T + b in one launch; a = LN(x) is (re)computed by the backward's side work, where it is needed
+                ln = blk["ln1"]
+                mu, rs = bufs.get(ln.name + ".mu", (M,)), bufs.get(ln.name + ".rs", (M,))
+                wf, c1, c2 = blk["fold"][:3]
+                ops.linear_fwd(x, wf, c2, out=qkv, ln_fold=(c1, mu, rs, 1e-5))
+                ln.saved = (x, mu, rs, ACT_NONE)
+                a = S_a[i]
+            else:
+                a = blk["ln1"].fwd(ctx, x, out=S_a[i])
+                ops.linear_fwd(a, blk["wqkv16"] if ctx.bf16 else blk["wqkv"], blk["bqkv"], out=qkv)
             o = S_o[i]
             lse = bufs.get("%s.b%d.lse" % (nm, i), (B, nh, T))
             # packed columns: [key | query | value]  (reference registration order, model_vec.py:82-84)
@@ -621,9 +639,17 @@ class GPT(object):
             x1 = bufs.get("%s.b%d.x1" % (nm, i), (M, C), sdt)
             ops.linear_fwd(o, Wf(blk["proj"]), blk["proj"].b, out=x1, res=x, ldr=C, drop_p=p_resid, rng_state=ctx.rng_state,
                            rng_stream=sb + 1)
-            a2 = blk["ln2"].fwd(ctx, x1, out=S_a2[i])
             h = S_h[i]
-            ops.linear_fwd(a2, Wf(blk["fc1"]), blk["fc1"].b, out=h, relu=True)
+            if fold:
+                ln = blk["ln2"]
+                mu, rs = bufs.get(ln.name + ".mu", (M,)), bufs.get(ln.name + ".rs", (M,))
+                wf, c1, c2 = blk["fold"][3:]
+                ops.linear_fwd(x1, wf, c2, out=h, relu=True, ln_fold=(c1, mu, rs, 1e-5))
+                ln.saved = (x1, mu, rs, ACT_NONE)
+                a2 = S_a2[i]
+            else:
+                a2 = blk["ln2"].fwd(ctx, x1, out=S_a2[i])
+                ops.linear_fwd(a2, Wf(blk["fc1"]), blk["fc1"].b, out=h, relu=True)
             x2 = bufs.get("%s.b%d.x2" % (nm, i), (M, C), sdt)
             ops.linear_fwd(h, Wf(blk["fc2"]), blk["fc2"].b, out=x2, res=x1, ldr=C, drop_p=p_resid, rng_state=ctx.rng_state,
                            rng_stream=sb + 2)
@@ -667,6 +693,8 @@ class GPT(object):
         # weight gradient and per LayerNorm reduction (7 per block) that was 0.3 ms per transformer.
         side = []
         pending = None
+        refold = getattr(self, "folded_fwd", False)   # the forward ran ln1 / ln2 inside the QKV / mlp.0 GEMMs (LN_FOLD)
+        scr_mu, scr_rs = bufs.get(nm + ".ln.scratch.mu", (M,)), bufs.get(nm + ".ln.scratch.rs", (M,))
         g = self.ln_f.bwd(ctx, g_y.view(M, C), out=G[nblk - 1], dropped=GD[nblk - 1] if drop else None, drop_p=p_resid,
                           rng_stream=sb_of(nblk - 1) + 2, colsum=self.blocks[nblk - 1]["fc2"].gb, defer=side)
         for i in range(nblk - 1, -1, -1):
@@ -692,6 +720,10 @@ class GPT(object):
             if ghpart is not None:
                 side.append(lambda gh=gh, blk=blk, a2=a2, p=ghpart, r=ghrows: (ops16.colsum_partials(p, r, 4 * C, blk["fc1"].gb),
                                                                                ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
+            elif refold:
+                # the forward folded ln2 into mlp.0's GEMM: the normalised tensor the weight gradient contracts with is made here
+                side.append(lambda gh=gh, blk=blk, a2=a2, x1=x1: (ops.layernorm_fwd(x1, blk["ln2"].w, blk["ln2"].b, a2, scr_mu, scr_rs),
+                                                                  ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
             else:
                 side.append(lambda gh=gh, blk=blk, a2=a2: (ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
             ga2 = bufs.get(nm + ".ga", (M, C), adt)
@@ -707,7 +739,11 @@ class GPT(object):
             delta = bufs.get(nm + ".delta", (B, nh, T))
             ops.attention_bwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, go, C, lse, delta, dqkv[:, C:], dqkv, dqkv[:, 2 * C:],
                               3 * C, B, T, nh, hs, scale, drop_p=p_attn, rng_state=ctx.rng_state, rng_stream=sb)
-            side.append(lambda dqkv=dqkv, blk=blk, a=a: (ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
+            if refold:
+                side.append(lambda dqkv=dqkv, blk=blk, a=a, x=x: (ops.layernorm_fwd(x, blk["ln1"].w, blk["ln1"].b, a, scr_mu, scr_rs),
+                                                                  ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
+            else:
+                side.append(lambda dqkv=dqkv, blk=blk, a=a: (ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
             ga = bufs.get(nm + ".ga2", (M, C), adt)
             ops.linear_dx(dqkv, blk["wqkv16t"] if ctx.bf16 else blk["wqkv"], out=ga)
             g = blk["ln1"].bwd(ctx, ga, dres=g1, out=G[i - 1] if i > 0 else bufs.get(nm + ".g_tok", (M, C), sdt),
@@ -1131,6 +1167,9 @@ class Engine(object):
         if self.act_dtype == torch.bfloat16:
             self.gemm_dtype = "f32"   # the fp32 islands of the bf16 mode (stems, VectorNet, head) are plain fp32
             self._build_shadows()
+        self.ln_fold_table = None
+        if LN_FOLD and self.act_dtype == torch.float32:
+            self._build_ln_fold()
         self.wino_layers = {}     # ConvBN name -> (filter storage, transformed-filter buffer): filled by the first training forward
         self.wino_table = None
         self.opt_group_of = None
@@ -1139,6 +1178,21 @@ class Engine(object):
         self._hyper_pinned, self._hyper_slot = None, 0
         self.n_lanes = int(os.environ.get("MMFN_BRANCH_LANES", "3"))
         self.offload_wgrad = True   # transformer weight / bias gradients on the side stream (worth 3.9 ms per step)
+
+    # ------------------------------------------------------------------ LayerNorm folded into the Linear behind it (fp32 path)
+    def _build_ln_fold(self):
+        """Per transformer block: (Wqkv . diag(gamma1), c1, c2) and (W_mlp0 . diag(gamma2), c1, c2) for MMFN_EPI_LN_FOLD, refreshed by
+        one grouped launch per forward (ops.ln_fold_weights): the weights change at every optimizer step."""
+        dev, entries = self.device, []
+        for gpt in self.gpts:
+            C = gpt.C
+            for blk in gpt.blocks:
+                mk = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+                f = (mk(3 * C, C), mk(3 * C), mk(3 * C), mk(4 * C, C), mk(4 * C), mk(4 * C))
+                blk["fold"] = f
+                entries.append((blk["wqkv"], blk["ln1"].w, blk["ln1"].b, blk["bqkv"], f[0], f[1], f[2]))
+                entries.append((blk["fc1"].w, blk["ln2"].w, blk["ln2"].b, blk["fc1"].b, f[3], f[4], f[5]))
+        self.ln_fold_table = ops.make_ln_fold_table(entries, dev)
 
     # ------------------------------------------------------------------ bf16 weight shadows
     def _build_shadows(self):
@@ -1294,6 +1348,8 @@ class Engine(object):
             if folded:
                 raise ValueError("BatchNorm folding is an fp32-mode option")
             self.refresh_shadows()
+        if self.ln_fold_table is not None and ops.current_precision() == "f32":
+            ops.ln_fold_weights(*self.ln_fold_table)
         img, lid, mp = self._ingest(ctx, inp)
         vel = inp["velocity"]
         trunks = [self.img, self.lid, self.map]

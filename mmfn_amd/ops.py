@@ -12,7 +12,8 @@ import torch
 
 from . import _lib
 from ._lib import (A_COLMAJOR, A_DGRAD, A_IM2COL, A_ROWMAJOR, B_DGRADW, B_IM2COL, B_KN, B_NK,
-                   EPI_ACCUM, EPI_BF16_OPERANDS, EPI_BF16X3, EPI_BIAS, EPI_DROPOUT, EPI_GELU, EPI_MASK_AUX, EPI_RELU, EPI_RELU_LAST, EPI_RESIDUAL,
+                   EPI_ACCUM, EPI_BF16_OPERANDS, EPI_BF16X3, EPI_BIAS, EPI_DROPOUT, EPI_GELU, EPI_LN_FOLD, EPI_MASK_AUX, EPI_RELU, EPI_RELU_LAST,
+                   EPI_RESIDUAL,
                    GemmDesc, check, lib, ptr, stream)
 
 BF16 = torch.bfloat16   # activations of the bf16 training mode: the wrappers below dispatch on the tensors' dtype
@@ -45,6 +46,11 @@ class precision(object):
     def __exit__(self, *exc):
         global _gemm_dtype
         _gemm_dtype = self.prev
+
+
+def current_precision():
+    """The arithmetic plain GEMMs launched now would run in (see `precision`)."""
+    return _gemm_dtype
 
 
 class lane(object):
@@ -267,7 +273,9 @@ def _f32c(t, name):
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=None, res=None, ldr=0,
          aux=None, ldaux=0, relu=False, gelu=False, accum=False, relu_last=False, drop_p=0.0, rng_state=None, rng_stream=0,
-         conv=None, splitk=0, tile=0, batch=1, strideA=0, strideB=0, strideC=0):
+         conv=None, splitk=0, tile=0, batch=1, strideA=0, strideB=0, strideC=0, ln_fold=None):
+    """ln_fold = (c1 [N], mean [M] or None, rstd [M] or None, eps): C = LayerNorm(A) . B^T + bias with B / bias the folded operands
+    of ln_fold_weights (MMFN_EPI_LN_FOLD, include/mmfn_hip.h); mean / rstd receive the row statistics."""
     d = GemmDesc()
     d.batch, d.strideA, d.strideB, d.strideC = batch, strideA, strideB, strideC
     d.A, d.B, d.C = ptr(A), ptr(B), ptr(C)
@@ -297,6 +305,12 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=N
         flags |= EPI_ACCUM
     if relu_last:
         flags |= EPI_RELU_LAST
+    if ln_fold is not None:
+        c1, ln_mean, ln_rstd, ln_eps = ln_fold
+        assert bias is not None and a_mode == A_ROWMAJOR and b_mode == B_NK and batch <= 1
+        flags |= EPI_LN_FOLD
+        d.ln_c1, d.ln_mean, d.ln_rstd, d.ln_eps = ptr(c1), ptr(ln_mean), ptr(ln_rstd), float(ln_eps)
+        splitk = 1
     # bf16 mode: plain GEMMs and - as DIRECT convolutions - the im2col forward / flipped data gradient and the weight gradient
     # (the library falls back to the fp32 kernel for what the bf16 kernel does not cover: 7x7 stems, stride-2 data gradients)
     bf16 = _gemm_dtype != "f32" and (conv is None or (_gemm_dtype == "bf16" and (
@@ -307,17 +321,22 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=N
     d.splitk = splitk
     d.tile = tile
     L = lib()
-    if tile == 0 and splitk == 0 and (USE_TABLE or AUTOTUNE):
+    if tile == 0 and (splitk == 0 or ln_fold is not None) and (USE_TABLE or AUTOTUNE):
         key = ((_gemm_dtype + "|") if bf16 else "") + _tune_key(a_mode, b_mode, M, N, K, batch, conv)
         cfg = _tuned.get(key)
-        if cfg is None and AUTOTUNE and _profiler is None and not torch.cuda.is_current_stream_capturing():
+        if cfg is None and AUTOTUNE and _profiler is None and not torch.cuda.is_current_stream_capturing() and ln_fold is None:
             cfg = _autotune(d, C, key)
         if cfg is not None and (len(cfg) == 2 or F32X3):
             d.tile, d.splitk = cfg[0], cfg[1]
-            if len(cfg) == 3:
+            if len(cfg) == 3 and ln_fold is None:
                 d.flags |= cfg[2]
         elif cfg is not None:  # table entry wants the emulation kernel but it is switched off: library default
             pass
+    if ln_fold is not None:   # the plain GEMM's tile of the same shape when it tiles M and N exactly, else 64 x 64; never split
+        bm, bn = {1: (128, 128), 3: (128, 64), 4: (64, 128)}.get(d.tile, (64, 64))
+        if d.tile == 0 or M % bm or N % bn:
+            d.tile = 2
+        d.splitk = 1
     need = L.mmfn_gemm_workspace_bytes(ctypes.byref(d))
     if need > 0:
         d.workspace = ptr(workspace(need, C.device))
@@ -1077,6 +1096,27 @@ def log_softmax_bwd(g, y, dx, R, C, swap):
 
 
 # ---------------------------------------------------------------- bf16 weight shadows
+def make_ln_fold_table(entries, device):
+    """entries: [(W [N,K], gamma [K], beta [K], bias [N] or None, Wf [N,K], c1 [N], c2 [N])] -> (device table, n, total rows) for
+    ln_fold_weights."""
+    import struct
+    blob, row0 = b"", 0
+    for W, gamma, beta, bias, Wf, c1, c2 in entries:
+        N, K = W.shape
+        assert W.is_contiguous() and Wf.is_contiguous() and Wf.shape == W.shape and gamma.numel() == K and c1.numel() == N
+        blob += struct.pack("<QQQQQQQiiq", W.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                            Wf.data_ptr(), c1.data_ptr(), c2.data_ptr(), N, K, row0)
+        row0 += N
+    t = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    return t, len(entries), row0
+
+
+def ln_fold_weights(table, n, total_rows):
+    """The folded operands of every (LayerNorm -> Linear) pair of the step in one launch (once per forward: weights change at the
+    optimizer step)."""
+    _call("mmfn_ln_fold_weights_f32", ptr(table), n, total_rows, stream())
+
+
 def cast_to_bf16(src, dst):
     _call("mmfn_cast_f32_to_bf16", ptr(src), ptr(dst), src.numel(), stream())
     return dst

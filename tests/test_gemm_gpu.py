@@ -67,6 +67,44 @@ def test_epilogue_flags():
     assert not torch.equal(y1 != 0, y3 != 0)
 
 
+@pytest.mark.parametrize("M,C,N,relu", [(384, 64, 192, False), (6144, 512, 1536, False), (6144, 512, 2048, True), (1024, 256, 768, False),
+                                          (768, 128, 512, True)])
+def test_layernorm_folded_into_the_gemm(M, C, N, relu):
+    """MMFN_EPI_LN_FOLD: LN(x) W^T + b as ONE launch - the GEMM runs on the raw rows against W . diag(gamma) and applies
+    rstd * (acc - mean * c1) + c2 in its epilogue, the row statistics accumulated from the A fragments (model_vec.py:117-118 ->
+    82-98 ln1 -> key/query/value, :119-121 ln2 -> mlp.0).  Against layernorm_fwd + linear_fwd of the same operands, every
+    tile shape that divides (M, N); the statistics it writes against the LayerNorm kernel's."""
+    from mmfn_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + C + N)
+    x = (torch.randn(M, C, generator=g) * 1.7 + 0.6).to(dev)          # residual-stream-like: mean of the order of the spread
+    w = (torch.randn(N, C, generator=g) * C ** -0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev)
+    a, mu0, rs0 = torch.empty(M, C, device=dev), torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.layernorm_fwd(x, gamma, beta, a, mu0, rs0)
+    ref = ops.linear_fwd(a, w, b, relu=relu)
+    wf, c1, c2 = torch.empty_like(w), torch.empty(N, device=dev), torch.empty(N, device=dev)
+    ops.ln_fold_weights(*ops.make_ln_fold_table([(w, gamma, beta, b, wf, c1, c2)], dev))
+    assert (wf - w * gamma).abs().max().item() == 0.0
+    assert (c1 - (w * gamma).double().sum(1).float()).abs().max().item() <= 1e-6 * max(1.0, c1.abs().max().item())
+    assert (c2 - ((w.double() * beta.double()).sum(1) + b.double()).float()).abs().max().item() <= 1e-6 * max(1.0, c2.abs().max().item())
+    scale = ref.abs().max().item()
+    tiles = [0] + [t for t, (bm, bn) in ((1, (128, 128)), (2, (64, 64)), (3, (128, 64)), (4, (64, 128))) if M % bm == 0 and N % bn == 0]
+    for tile in tiles:
+        mu, rs = torch.full((M,), float("nan"), device=dev), torch.full((M,), float("nan"), device=dev)
+        out = torch.full((M, N), float("nan"), device=dev)
+        ops.linear_fwd(x, wf, c2, out=out, relu=relu, tile=tile, ln_fold=(c1, mu, rs, 1e-5))
+        err = (out - ref).abs().max().item()
+        assert err <= 3e-5 * scale, (tile, err, scale)
+        assert (mu - mu0).abs().max().item() <= 1e-6 * max(1.0, mu0.abs().max().item())
+        assert ((rs - rs0) / rs0).abs().max().item() <= 2e-5, ((rs - rs0) / rs0).abs().max().item()
+    # a tile that does not divide N: the wrapper falls back to 64 x 64 (the C entry itself refuses)
+    if N % 128:
+        out = ops.gemm(x, wf, torch.empty(M, N, device=dev), M, N, C, C, C, N, bias=c2, relu=relu, tile=1, ln_fold=(c1, None, None, 1e-5))
+        assert (out - ref).abs().max().item() <= 3e-5 * scale
+
+
 @pytest.mark.parametrize("relu", [False, True])
 def test_nan_propagates_alike_through_interior_and_edge_tiles(relu):
     """A NaN accumulator must leave the GEMM the same way from an interior tile (flag-hoisted epilogue) and from an edge tile

@@ -159,9 +159,10 @@ def test_comm_library_exports_every_declared_symbol():
     text = re.sub(r"/\*.*?\*/", " ", open(comm.HEADER_PATH).read(), flags=re.S)
     declared = re.findall(r"\bint\s+(mmfn_\w+)\s*\(", text)
     assert set(declared) == {"mmfn_comm_abi_version", "mmfn_comm_unique_id", "mmfn_comm_init", "mmfn_comm_destroy", "mmfn_comm_ranks",
-                             "mmfn_allreduce_sum_f32", "mmfn_broadcast_bytes"}
+                             "mmfn_allreduce_sum_f32", "mmfn_allreduce_sum_bf16", "mmfn_broadcast_bytes"}
     handle = comm.lib()
     for name in declared:
         assert hasattr(handle, name), name
     assert handle.mmfn_comm_abi_version() == 1
     assert handle.mmfn_allreduce_sum_f32(None, None, 0, None) == -1     # argument checking happens before any RCCL call
+    assert handle.mmfn_allreduce_sum_bf16(None, None, 0, None) == -1
