@@ -608,9 +608,12 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   f32x4 ra[UA], rb[UB];
-  float ln_s1[TM], ln_s2[TM];   // LNF: this lane's partial (sum x, sum x^2) of rows wm*TM*32 + i*32 + l31
+  // LNF: this lane's partial (sum x, sum x^2) of rows wm*TM*32 + i*32 + l31.  fp64: E[x^2] - mean^2 cancels badly in fp32 when a
+  // row's mean is large against its spread, and the extra VALU work (3 instructions per fragment value) sits in the shadow of the
+  // MFMAs (8-16 per k-tile at 64 cycles each)
+  double ln_s1[TM], ln_s2[TM];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) { ln_s1[i] = 0.f; ln_s2[i] = 0.f; }
+  for (int i = 0; i < TM; ++i) { ln_s1[i] = 0.0; ln_s2[i] = 0.0; }
   // stage(kt, dst): global -> LDS for one k-tile.  With USE_GLDS the 16-byte pieces go straight to LDS
   // (global_load_lds: wave-uniform LDS base + lane*16, so the image is lane-linear and the slot swizzle
   // is applied to the SOURCE address); otherwise through registers (issue now, ds_write after the MFMAs).
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
         }
         if (LNF) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { ln_s1[i] += a[i][j]; ln_s2[i] = fmaf(a[i][j], a[i][j], ln_s2[i]); }
+          for (int j = 0; j < 4; ++j) { const double v = (double)a[i][j]; ln_s1[i] += v; ln_s2[i] = fma(v, v, ln_s2[i]); }
         }
       }
 #pragma unroll
@@ -716,10 +719,11 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
   if (LNF) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const float s1 = ln_s1[i] + __shfl_xor(ln_s1[i], 32, 64), s2 = ln_s2[i] + __shfl_xor(ln_s2[i], 32, 64);
-      const float mu = s1 / (float)d.K;
-      const float var = fmaxf(s2 / (float)d.K - mu * mu, 0.f);
-      const float rs = 1.0f / sqrtf(var + d.ln_eps);
+      const double s1 = ln_s1[i] + __shfl_xor(ln_s1[i], 32, 64), s2 = ln_s2[i] + __shfl_xor(ln_s2[i], 32, 64);
+      const double mud = s1 / (double)d.K;
+      const double var = fmax(s2 / (double)d.K - mud * mud, 0.0);
+      const float mu = (float)mud;
+      const float rs = (float)(1.0 / sqrt(var + (double)d.ln_eps));
       if (wn == 0 && h == 0) {
         const int rl = wm * TM * 32 + i * 32 + l31;
         ln_stat[rl] = mu;
