@@ -1214,7 +1214,8 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
     }
     if (d.flags & MMFN_EPI_LN_FOLD) {
       if (AM != MMFN_A_ROWMAJOR || BMODE != MMFN_B_NK) return MMFN_EINVAL;
-      const int bm = (tile == 1 || tile == 3) ? 128 : 64, bn = (tile == 1 || tile == 4) ? 128 : 64;
+      int bm = (tile == 1 || tile == 3) ? 128 : 64, bn = (tile == 1 || tile == 4) ? 128 : 64;
+      if (d.M % bm || d.N % bn) { tile = 2; bm = bn = 64; }   // the epilogue of this form only exists for interior tiles
       if (d.M % bm || d.N % bn || d.batch > 1) return MMFN_EINVAL;
       dd.splitk = 1;
       const int tn = d.N / bn;

@@ -332,11 +332,8 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=N
                 d.flags |= cfg[2]
         elif cfg is not None:  # table entry wants the emulation kernel but it is switched off: library default
             pass
-    if ln_fold is not None:   # the plain GEMM's tile of the same shape when it tiles M and N exactly, else 64 x 64; never split
-        bm, bn = {1: (128, 128), 3: (128, 64), 4: (64, 128)}.get(d.tile, (64, 64))
-        if d.tile == 0 or M % bm or N % bn:
-            d.tile = 2
-        d.splitk = 1
+    if ln_fold is not None:   # the plain GEMM's tile of the same shape (table entry or the library's model); never split - a tile
+        d.splitk = 1          # that does not divide M x N falls back to 64 x 64 inside the launcher
     need = L.mmfn_gemm_workspace_bytes(ctypes.byref(d))
     if need > 0:
         d.workspace = ptr(workspace(need, C.device))
