@@ -604,6 +604,17 @@ def main():
                           "time of the launches that implement them; the Winograd F(4x4,3x3) path executes 4x fewer on the MFMA units "
                           "(executed_gflop_per_step, executed_tflops), so a convolution-only workload can exceed 1.0 here",
         }
+        if image_only and args.dtype == "f32":
+            # the convolution-only workload (BASELINE configs[3], "conv MFMA roofline run"): every FLOP of it is a 3x3 / 7x7 / 1x1
+            # convolution and three quarters of the 3x3 MACs are never executed (Winograd), so the algorithmic fraction exceeds 1
+            # and says nothing about the matrix pipe - the line leads with what the MFMA units really execute
+            r = result["roofline"]
+            r["frac_algorithmic"], r["achieved_algorithmic"] = r["frac"], r["achieved"]
+            r["achieved"] = r["executed_tflops"]
+            r["frac"] = round(r["executed_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
+            r["accounting"] = ("achieved / frac = FLOPs the MFMA units EXECUTE (Winograd F(4x4,3x3) executes 1/4 of a 3x3 convolution's MACs) over the "
+                               "time of the launches incl. the transform kernels; achieved_algorithmic / frac_algorithmic count SURVEY 8d's "
+                               "algorithmic FLOPs and exceed 1.0 on this convolution-only workload")
         if args.dtype != "f32":
             # bf16 mode: the dominant kernel is the bf16-operand GEMM; price ITS launches against the dense bf16 MFMA peak.
             # What stays on the fp32 instruction (conv weight gradients in the Winograd domain, 7x7 stems, stride-2 data

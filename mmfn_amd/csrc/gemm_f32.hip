@@ -422,8 +422,10 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 // halves together see the whole row once), the halves are combined with one shuffle, the row statistics go through 2 * BM
 // floats of LDS to the lanes that hold that row's accumulators, and the interior-tile epilogue starts from
 // rstd * (acc - mean * c1[n]) + c2[n] instead of acc + bias[n].
+// (amdgpu_waves_per_eu: the LNF 128x128 instantiation took 192 registers = two blocks per CU; held to three like the plain form)
 template <int AM, int BMODE, int BM, int BN, bool LNF = false>
-__global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, const int tiles_n,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(LNF && BM == 128 && BN == 128 ? 3 : 1)))
+void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, const int tiles_n,
                                                            const int log2_ow, const int log2_ohw) {
   const mmfn_gemm_desc d = d_in.dg_parity ? d_in : batch_view(d_in);
   // Stride-2 transposed convolution, decomposed by output-pixel parity (blockIdx.z = 2*py + px): an input
@@ -608,9 +610,9 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   f32x4 ra[UA], rb[UB];
-  // LNF: this lane's partial (sum x, sum x^2) of rows wm*TM*32 + i*32 + l31.  fp64: E[x^2] - mean^2 cancels badly in fp32 when a
-  // row's mean is large against its spread, and the extra VALU work (3 instructions per fragment value) sits in the shadow of the
-  // MFMAs (8-16 per k-tile at 64 cycles each)
+  // LNF: this lane's partial (sum x, sum x^2) of rows wm*TM*32 + i*32 + l31.  Running sums in fp64 (E[x^2] - mean^2 cancels badly
+  // in fp32 when a row's mean is large against its spread), fed once per k-tile from fp32 partial sums of that tile's 8 values per
+  // lane: two fp64 additions per row and k-tile instead of three fp64 instructions per value
   double ln_s1[TM], ln_s2[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) { ln_s1[i] = 0.0; ln_s2[i] = 0.0; }
@@ -668,6 +670,9 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
     }
     const float* As = smem + cur * STG;
     const float* Bs = As + A_ELEMS;
+    float ln_p1[TM], ln_p2[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { ln_p1[i] = 0.f; ln_p2[i] = 0.f; }
 #pragma unroll
     for (int c = 0; c < BK / 8; ++c) {
       float a[TM][4], b[TN][4];
@@ -681,9 +686,9 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
 #pragma unroll
           for (int j = 0; j < 4; ++j) a[i][j] = As[(c * 8 + h * 4 + j) * BM + row];
         }
-        if (LNF) {
+        if (LNF) {   // the k-tile's 16 values per row in fp32, the running sums over the k-tiles in fp64 (below)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { const double v = (double)a[i][j]; ln_s1[i] += v; ln_s2[i] = fma(v, v, ln_s2[i]); }
+          for (int j = 0; j < 4; ++j) { ln_p1[i] += a[i][j]; ln_p2[i] = fmaf(a[i][j], a[i][j], ln_p2[i]); }
         }
       }
 #pragma unroll
@@ -704,6 +709,10 @@ __global__ __launch_bounds__(NT) void gemm_f32_fast_kernel(const mmfn_gemm_desc 
 #pragma unroll
           for (int q = 0; q < TN; ++q)
             acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[q][j], acc[i][q], 0, 0, 0);
+    }
+    if (LNF) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) { ln_s1[i] += (double)ln_p1[i]; ln_s2[i] += (double)ln_p2[i]; }
     }
     if (NS > 2) {
       cur = cur + 1 == NS ? 0 : cur + 1;

@@ -553,9 +553,12 @@ class LayerNorm(object):
 
 # ----------------------------------------------------------------------------- GPT fusion transformer
 # fp32 path: ln1 -> key/query/value and ln2 -> mlp.0 as ONE launch each (MMFN_EPI_LN_FOLD: the LayerNorm folded into the GEMM,
-# include/mmfn_hip.h mmfn_gemm_desc.ln_c1); the normalised tensor only the weight gradient needs is recomputed on the side stream
-# in the backward.  A/B switch; 0 = a LayerNorm launch in front of each of the two GEMMs (the round-3 forward).
-LN_FOLD = os.environ.get("MMFN_LN_FOLD", "1") == "1"
+# include/mmfn_hip.h mmfn_gemm_desc.ln_c1); in a training step the normalised tensor that only the weight gradient needs is
+# recomputed on the side stream in the backward.  MMFN_LN_FOLD = "eval" (default): eval-mode forwards only - validation and the
+# batch-1 closed-loop tick, where 64 launches less on a dependent chain of ~330 are worth 4 % (4.05 vs 4.22 ms per tick);
+# "1": training too - measured SLOWER there (32.01 vs 31.74 ms per step, DESIGN.md section 5: the folded GEMMs cost what the
+# LayerNorm launches saved, and the recomputation competes with the backward's side work); "0": never.
+LN_FOLD = os.environ.get("MMFN_LN_FOLD", "eval")
 
 
 class GPT(object):
@@ -615,7 +618,8 @@ class GPT(object):
         S_a, S_a2 = bufs.get(nm + ".S.a", (nb, M, C), adt), bufs.get(nm + ".S.a2", (nb, M, C), adt)
         S_o, S_h = bufs.get(nm + ".S.att", (nb, M, C), adt), bufs.get(nm + ".S.h", (nb, M, 4 * C), adt)
         self.stacks = (S_a, S_a2, S_o, S_h)
-        fold = (not ctx.bf16) and ops.current_precision() == "f32" and self.blocks[0]["fold"] is not None and M % 64 == 0
+        fold = (not ctx.bf16) and ops.current_precision() == "f32" and self.blocks[0]["fold"] is not None and M % 64 == 0 \
+            and ctx.engine.ln_fold_now(ctx.training)
         self.folded_fwd = fold
         for i, blk in enumerate(self.blocks):
             sb = self.stream_base + 1 + 3 * i
@@ -1168,7 +1172,8 @@ class Engine(object):
             self.gemm_dtype = "f32"   # the fp32 islands of the bf16 mode (stems, VectorNet, head) are plain fp32
             self._build_shadows()
         self.ln_fold_table = None
-        if LN_FOLD and self.act_dtype == torch.float32:
+        self.ln_fold_mode = LN_FOLD if LN_FOLD in ("eval", "1") else "0"
+        if self.ln_fold_mode != "0" and self.act_dtype == torch.float32:
             self._build_ln_fold()
         self.wino_layers = {}     # ConvBN name -> (filter storage, transformed-filter buffer): filled by the first training forward
         self.wino_table = None
@@ -1180,6 +1185,9 @@ class Engine(object):
         self.offload_wgrad = True   # transformer weight / bias gradients on the side stream (worth 3.9 ms per step)
 
     # ------------------------------------------------------------------ LayerNorm folded into the Linear behind it (fp32 path)
+    def ln_fold_now(self, training):
+        return self.ln_fold_table is not None and (self.ln_fold_mode == "1" or not training)
+
     def _build_ln_fold(self):
         """Per transformer block: (Wqkv . diag(gamma1), c1, c2) and (W_mlp0 . diag(gamma2), c1, c2) for MMFN_EPI_LN_FOLD, refreshed by
         one grouped launch per forward (ops.ln_fold_weights): the weights change at every optimizer step."""
@@ -1348,7 +1356,7 @@ class Engine(object):
             if folded:
                 raise ValueError("BatchNorm folding is an fp32-mode option")
             self.refresh_shadows()
-        if self.ln_fold_table is not None and ops.current_precision() == "f32":
+        if self.ln_fold_now(training) and ops.current_precision() == "f32":
             ops.ln_fold_weights(*self.ln_fold_table)
         img, lid, mp = self._ingest(ctx, inp)
         vel = inp["velocity"]

@@ -545,7 +545,7 @@ def test_batchnorm_apply_inside_the_winograd_input_transform_changes_no_bit(vari
 
 @pytest.mark.parametrize("variant", ["vec", "rad"])
 def test_layernorm_inside_the_qkv_and_mlp_gemms_tracks_the_separate_launches(variant, monkeypatch):
-    """MMFN_LN_FOLD (default on, fp32 path): ln1 -> key/query/value and ln2 -> mlp.0 of every transformer block run as one GEMM
+    """MMFN_LN_FOLD (fp32 path; default: eval-mode forwards only, "1": training steps too): ln1 -> key/query/value and ln2 -> mlp.0 of every transformer block run as one GEMM
     launch each (MMFN_EPI_LN_FOLD), the normalised tensors the weight gradients need are recomputed on the side stream in the
     backward.  Different rounding, same function: train loss, eval waypoints and the transformer outputs agree with the
     LayerNorm-launch path to fp32 accuracy, the weight gradients of the folded Linears to the accuracy the forward allows, and the
@@ -553,9 +553,9 @@ def test_layernorm_inside_the_qkv_and_mlp_gemms_tracks_the_separate_launches(var
     from mmfn_amd import engine as E
     from oracle import harness
     oracle, net_a, batch, args = _setup(variant)
-    monkeypatch.setattr(E, "LN_FOLD", False)
+    monkeypatch.setattr(E, "LN_FOLD", "0")
     net_a._engine_for()
-    monkeypatch.setattr(E, "LN_FOLD", True)
+    monkeypatch.setattr(E, "LN_FOLD", "1")
     _, net_b, _, _ = _setup(variant)
     ea, eb = net_a._engine_for(), net_b._engine_for()
     assert ea.ln_fold_table is None and eb.ln_fold_table is not None

@@ -4,7 +4,8 @@
 R=${GRAFT_REPO_ROOT:-$(dirname $(dirname $(readlink -f $0)))}
 cd $R
 export MMFN_AUTOTUNE16=1 MMFN_TUNING_FILE16=$R/gpurun_out/gfx950_bf16.json
-rm -f $MMFN_TUNING_FILE16
+# start from the committed table: only shapes it does not hold yet are timed (TUNE16_FRESH=1: time everything again)
+if [ -n "$TUNE16_FRESH" ]; then rm -f $MMFN_TUNING_FILE16; else mkdir -p $R/gpurun_out; cp $R/mmfn_amd/tuning/gfx950_bf16.json $MMFN_TUNING_FILE16; fi
 python - <<'PY'
 import os, sys, torch
 sys.path.insert(0, os.getcwd())
