@@ -301,8 +301,8 @@ def all_ranks_agree(dist, dev, ok):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)   # 100 x ~32 ms: a timed region of seconds, not of a few scheduler quanta
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--variant", default="vec", choices=["vec", "img", "rad"])
     ap.add_argument("--workload", default="train", choices=["train", "image-only"],

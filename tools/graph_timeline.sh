@@ -6,7 +6,7 @@ export EXTRA
 OUT=$R/gpurun_out/timeline
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT -o g -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-oracle-check --profile-steps 1 $EXTRA > $OUT/g.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT -o g -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-oracle-check --no-also --profile-steps 1 $EXTRA > $OUT/g.log 2>&1
 python3 - <<'PY' > $OUT/summary.txt
 import csv, os, collections
 out = os.environ.get('GRAFT_REPO_ROOT', '.') + '/gpurun_out/timeline'

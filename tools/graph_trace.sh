@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/graph_trace
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT -o g -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --profile-steps 1 $EXTRA > $OUT/g.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $OUT -o g -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-also --profile-steps 1 $EXTRA > $OUT/g.log 2>&1
 python3 - <<'PY'
 import csv, os, collections
 out = os.environ.get('GRAFT_REPO_ROOT', '.') + '/gpurun_out/graph_trace'
