@@ -23,6 +23,8 @@ int mmfn_comm_abi_version(void);
 int mmfn_comm_unique_id(void* out_id);
 /* ncclCommInitRank on the calling thread's current HIP device (one process per GPU). */
 int mmfn_comm_init(void** comm, const void* id_bytes, int nranks, int rank);
+/* Destroy the communicator.  Every hipGraph that captured a collective of it must have been destroyed first (RCCL reaches
+ * into the communicator when such a graph dies); mmfn_amd.comm.RcclComm.destroy() enforces the order. */
 int mmfn_comm_destroy(void* comm);
 int mmfn_comm_ranks(void* comm, int* nranks, int* rank);
 /* In-place sum all-reduce of n floats (a gradient bucket: a contiguous range of the flat gradient buffer); the 1/ranks

@@ -9,7 +9,9 @@ The rendezvous id (128 bytes from rank 0) travels over the torch.distributed pro
 (any backend: it is a one-off object broadcast), RCCL itself is driven only through the C ABI.
 """
 import ctypes
+import gc
 import os
+import weakref
 
 import torch
 
@@ -70,6 +72,7 @@ class RcclComm(object):
             unique_id = payload[0]
         assert len(unique_id) == ID_BYTES
         self.rank, self.world = rank, world
+        self._holders = weakref.WeakSet()   # objects owning hipGraphs that captured collectives of this communicator (retain())
         self._comm = ctypes.c_void_p()
         idbuf = ctypes.create_string_buffer(unique_id, ID_BYTES)
         _check(L.mmfn_comm_init(ctypes.byref(self._comm), ctypes.cast(idbuf, ctypes.c_void_p), world, rank), "mmfn_comm_init")
@@ -93,10 +96,26 @@ class RcclComm(object):
         _check(lib().mmfn_comm_ranks(self._comm, ctypes.byref(n), ctypes.byref(r)), "mmfn_comm_ranks")
         return n.value, r.value
 
+    def retain(self, holder):
+        """Register an object that owns hipGraphs with captured collectives of this communicator (graphs.Recorder; weakly held)."""
+        self._holders.add(holder)
+
     def destroy(self):
-        if self._comm:
-            lib().mmfn_comm_destroy(self._comm)
-            self._comm = ctypes.c_void_p()
+        """Destroy the communicator.  A hipGraph that captured its collectives must be gone first: RCCL hooks the graph's
+        destruction and reaches into the communicator from there - freeing the communicator under a live (or merely retired,
+        graphs._graveyard) capture corrupted the heap and crashed a LATER replay (round-4 full-suite segfault).  So the retired
+        captures are destroyed here, and a live one is an error instead of a crash."""
+        if not self._comm:
+            return
+        if torch.cuda.is_available() and torch.cuda.is_initialized() and not torch.cuda.is_current_stream_capturing():
+            from . import graphs
+            gc.collect()
+            graphs.drain_graveyard()
+        if len(self._holders):
+            raise MMFNCommError("%d captured step(s) still hold collectives of this communicator: drop them (GraphedStep / the trainer's "
+                                "captures) before RcclComm.destroy()" % len(self._holders))
+        lib().mmfn_comm_destroy(self._comm)
+        self._comm = ctypes.c_void_p()
 
 
 def all_ranks_agree(dist, dev, ok):

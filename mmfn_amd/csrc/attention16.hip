@@ -394,6 +394,7 @@ int by_tokens16(int which, const AttnArgs& a, hipStream_t s) {
     case 64: return launch16<HS, 2>(which, a, s);
     case 128: return launch16<HS, 4>(which, a, s);
     case 192: return launch16<HS, 6>(which, a, s);
+    case 256: return launch16<HS, 8>(which, a, s);   // the rad variant's deepest fusion / two views: 131 KB of staged K + V at head size 128
   }
   return -1;
 }

@@ -969,6 +969,8 @@ class RadarGAT(object):
         out = bufs.get(nm + ".out", (B, 8, 8, 512))
         ops.log_softmax_fwd(m2d, out, B * 64, 512, True)
         self.saved = (B, N, Fin, H2, x, adj2, y1, y2, m1t, out)
+        if ctx.bf16:   # fp32 inside (81 points x 7 heads: nothing for the bf16 pipe), the radar feature joins the fusion as a bf16 activation
+            return ops.cast_to_bf16(out, bufs.get(nm + ".out16", out.shape, ctx.adt))
         return out
 
     def bwd(self, ctx, g_out):
@@ -977,6 +979,8 @@ class RadarGAT(object):
         R = B * N
         n_cat = B * self.nh * N
         p = self.p if ctx.training else 0.0
+        if g_out.dtype != torch.float32:
+            g_out = ops.cast_to_f32(g_out, bufs.get(nm + ".g.out32", g_out.shape))
         g_m2 = ops.log_softmax_bwd(g_out, out, bufs.get(nm + ".g.m2", (B * 256, 128)), B * 64, 512, True)
         if p > 0.0:
             ops.dropout_apply(g_m2, g_m2, p, ctx.rng_state, self.stream_base + 6)
@@ -1109,9 +1113,6 @@ class Engine(object):
         self.module, self.layout, self.variant, self.cfg = module, layout, variant, cfg
         self.device = layout.device
         self.act_dtype = {"f32": torch.float32, "bf16": torch.bfloat16}[getattr(cfg, "act_dtype", "f32")]
-        if self.act_dtype == torch.bfloat16 and variant == "rad":
-            raise NotImplementedError("the bf16 training mode covers the vec and img variants (the rad variant's T = 256 attention and "
-                                      "radar GAT have no bf16 kernels)")
         S, V = int(cfg.seq_len), int(cfg.n_views)
         if S < 1 or V < 1:
             raise ValueError("seq_len and n_views must be >= 1, got %d and %d" % (S, V))
@@ -1127,8 +1128,8 @@ class Engine(object):
         if tokens > 384:
             raise NotImplementedError("(n_views + 2) * seq_len * 64%s = %d tokens: the attention kernels hold at most 384 keys" % (
                 " + 64" if variant == "rad" else "", tokens))
-        if self.act_dtype == torch.bfloat16 and (S, V) != (1, 1):
-            raise NotImplementedError("the bf16 training mode is built for seq_len = n_views = 1 (its attention kernels take 64 / 128 / 192 tokens)")
+        if self.act_dtype == torch.bfloat16 and tokens > 256:
+            raise NotImplementedError("the bf16 training mode's attention kernels stage K and V of one head in LDS: at most 256 tokens, got %d" % tokens)
         if self.device.type != "cuda":
             raise ops._lib.MMFNLibraryError("the MMFN HIP path needs a GPU device (got %s); there is no CPU fallback" % self.device)
         enc = module.encoder
@@ -1468,7 +1469,7 @@ class Engine(object):
         gin = gpt.bwd(ctx, gtok)
         self._ready(on_ready, st, "gpt")
         if s == 3 and self.rad is not None:
-            dF3 = ops.pool_bcast_add(G[3], gin, bufs.get("dF3.3", G[3].shape), base[3], 1)
+            dF3 = ops.pool_bcast_add(G[3], gin, bufs.get("dF3.3", G[3].shape, G[3].dtype), base[3], 1)
             self.rad.bwd(ctx, dF3)
             self._ready(on_ready, 0, "head")
         if s > 0:

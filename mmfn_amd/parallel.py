@@ -262,6 +262,8 @@ class GraphedStep(object):
         rec = self.recorder = Recorder(eng)
         if dp is not None:
             rec.extra_streams.append(dp.comm_stream)
+            if dp.comm is not None:
+                dp.comm.retain(rec)   # the communicator must outlive the capture (RcclComm.destroy)
         if single_graph is None:
             single_graph = dp is not None and dp.comm is not None
         if single_graph and (dp is None or dp.comm is None):

@@ -23,14 +23,16 @@ sys.path.insert(0, ROOT)
 def _pair(batch, variant="vec", dropout=0.0, seed=42):
     import bench
     from mmfn_amd.config import GlobalConfig
-    from mmfn_amd.model import MMFN, MMFNImg
-    cls = {"vec": MMFN, "img": MMFNImg}[variant]
-    kw = dict(embd_pdrop=dropout, attn_pdrop=dropout, resid_pdrop=dropout)
+    from mmfn_amd.model import MMFN, MMFNImg, MMFNRad
+    n_views = 2 if variant == "img2v" else 1          # img2v: two camera views = 256 tokens per sample, like the rad variant's
+    variant = "img" if variant == "img2v" else variant
+    cls = {"vec": MMFN, "img": MMFNImg, "rad": MMFNRad}[variant]
+    kw = dict(embd_pdrop=dropout, attn_pdrop=dropout, resid_pdrop=dropout, n_views=n_views)
     torch.manual_seed(seed)
     a = cls(GlobalConfig(**kw), DEV)
     b = cls(GlobalConfig(act_dtype="bf16", **kw), DEV)
     b.load_state_dict(a.state_dict())
-    inp, gt = bench.synth_inputs(batch, DEV, seed=seed, variant=variant)
+    inp, gt = bench.synth_inputs(batch, DEV, seed=seed, variant=variant, n_views=n_views)
     return a.train(), b.train(), inp, gt
 
 
@@ -42,8 +44,10 @@ def _stage_cosines(La, Lb):
     return out
 
 
-@pytest.mark.parametrize("variant,batch", [("vec", 32), ("img", 8), ("vec", 2)])
+@pytest.mark.parametrize("variant,batch", [("vec", 32), ("img", 8), ("vec", 2), ("rad", 8), ("img2v", 4)])
 def test_bf16_mode_tracks_the_fp32_path(variant, batch):
+    """(rad: the radar GAT stays an fp32 island, its feature joins the deepest fusion as a bf16 activation; its transformer and
+    img2v's four run the 256-token instantiation of attention16.hip.)"""
     a, b, inp, gt = _pair(batch, variant)
     ea, eb = a._engine_for(), b._engine_for()
     _, la = ea.forward(inp, True, gt)
@@ -61,6 +65,10 @@ def test_bf16_mode_tracks_the_fp32_path(variant, batch):
     assert dt["in.img"] == torch.float32 and dt["fused"] == torch.float32
     if variant == "vec":
         assert dt["vec.gen.pre"] == torch.float32 and dt["vec.out"] == torch.bfloat16
+    if variant == "rad":
+        assert dt["rad.out"] == torch.float32 and dt["rad.out16"] == torch.bfloat16 and eb.gpts[3].T == 256 and eb.gpts[2].T == 192
+    if variant == "img2v":
+        assert all(g.T == 256 for g in eb.gpts)
     assert dt["gpt4.S.gh"] == torch.bfloat16 and dt["img.l3.1.c2.dconv"] == torch.bfloat16
     # ... and the transformers' residual stream and its gradient stay fp32, like torch.autocast's (x + Linear(LN(x)))
     assert dt["gpt4.b0.x1"] == torch.float32 and dt["gpt4.x0"] == torch.float32 and dt["gpt4.S.g"] == torch.float32
@@ -178,7 +186,7 @@ def test_bf16_graph_replay_equals_eager_steps():
 
 def test_bf16_mode_rejects_what_it_does_not_cover():
     from mmfn_amd.config import GlobalConfig
-    from mmfn_amd.model import MMFNRad
-    net = MMFNRad(GlobalConfig(act_dtype="bf16"), DEV)
-    with pytest.raises(NotImplementedError):
+    from mmfn_amd.model import MMFNImg
+    net = MMFNImg(GlobalConfig(act_dtype="bf16", n_views=3), DEV)   # 320 tokens: K and V of a 128-wide head no longer fit LDS
+    with pytest.raises(NotImplementedError, match="256 tokens"):
         net._engine_for()

@@ -238,7 +238,7 @@ def _attn_ref(qkv, C, B, T, NH, hs, mask=None, p=0.0):
     return o, lse
 
 
-@pytest.mark.parametrize("T", [64, 192])
+@pytest.mark.parametrize("T", [64, 192, 256])
 @pytest.mark.parametrize("hs", [16, 32, 64, 128])
 def test_attention_bf16_mfma(hs, T):
     """attention16.hip (bf16 MFMA, fp32 softmax) forward and backward against torch on the same bf16-rounded q, k, v, dO;

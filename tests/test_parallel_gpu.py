@@ -58,16 +58,26 @@ def test_rccl_c_abi_single_rank_communicator():
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     assert torch.equal(x, ref)          # sum over one rank
-    # capturable: the collective is plain stream work
-    g = torch.cuda.CUDAGraph()
+    # capturable: the collective is plain stream work.  (The capture is owned by mmfn_amd.graphs.Graph like every capture of the
+    # package: destroyed at a safe point - parked, then RcclComm.destroy() drains the parked ones before the communicator goes.
+    # A bare torch.cuda.CUDAGraph destroyed right here made a LATER, unrelated replay die inside hipGraphLaunch on ROCm 7.0:
+    # tools/experiments/segv_bisect2.sh.)
+    from mmfn_amd import graphs
     y = torch.ones(4096, device="cuda:0")
     torch.cuda.synchronize()
-    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+    g = graphs.Graph()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        g.capture_begin(capture_error_mode="thread_local")
         y.mul_(2.0)
         c.all_reduce_sum_(y)
+        g.capture_end()
+    torch.cuda.current_stream().wait_stream(cap)
     g.replay(); g.replay()
     torch.cuda.synchronize()
-    assert float(y[0]) in (4.0, 8.0)    # capture itself may or may not execute the work once; replays double twice
+    assert float(y[0]) == 4.0           # (capture does not execute; two replays double twice)
+    del g
     c.destroy()
 
 
@@ -125,6 +135,9 @@ def test_single_graph_data_parallel_step_with_captured_collectives():
         torch.cuda.synchronize()
         outs.append((net._layout.params.clone(), float(step.loss.item())))
         if use_dp:
+            with pytest.raises(Exception, match="still hold collectives"):   # a communicator must outlive the captures that use it
+                comm.destroy()
+            del step
             comm.destroy()
     assert outs[0][1] == outs[1][1]
     assert torch.equal(outs[0][0], outs[1][0])

@@ -230,6 +230,8 @@ def test_data_parallel_epoch_on_the_single_graph_transport_equals_plain_epoch(st
         if use_dp:
             step = next(iter(tr._static_steps.values()))
             assert not isinstance(step, str) and step.seg.single_graph and step.seg.recorder.n_graphs == 1
+            del step
+            tr._static_steps.clear()   # the captures go before the communicator they recorded (RcclComm.destroy)
             dp.comm.destroy()
         out.append((tr.train_loss, net.state_dict()))
     assert out[0][0] == out[1][0]

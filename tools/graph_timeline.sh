@@ -74,3 +74,4 @@ for k, (n, us) in sorted(dur.items(), key=lambda kv: -kv[1][1])[:45]:
 print("sum of kernel durations %.2f ms" % (sum(v[1] for v in dur.values()) / 1e3))
 PY
 cat $OUT/summary.txt
+python3 $R/tools/phase_timeline.py $OUT/g_kernel_trace.csv > $OUT/phases.txt; cat $OUT/phases.txt
