@@ -620,12 +620,23 @@ int launch(int which, const AttnArgs& a, hipStream_t s) {
   return a.io_bf16 ? launch_io<HS, NT, bf16_t>(which, a, s) : launch_io<HS, NT, float>(which, a, s);
 }
 
+template <int HS, int NT>
+constexpr bool fits_lds() {   // the largest of the three kernels: operand area + sm_stat[2][2][4][G] / sm_rows[8][2][G]
+  return (Lds<HS, NT>::AREA + 16 * Shape<HS, NT>::G) * 4 <= 160 * 1024;
+}
+
 template <int HS>
 int by_tokens(int which, const AttnArgs& a, hipStream_t s) {
   switch (a.T) {
     case 64: return launch<HS, 1>(which, a, s);
     case 128: return launch<HS, 2>(which, a, s);
     case 192: return launch<HS, 3>(which, a, s);
+    // several frames / views per sample, the rad variant's 256 tokens: the same kernels where a workgroup's operands
+    // ((T + T/2) rows x (HS + 4) floats) fit the CU's LDS AND the key-owned pass keeps its two T/4 x T/8 accumulator sets in
+    // registers - head sizes 16 and 32 (measured at B = 16 against the tile kernels of attention.hip: T = 256 forward 18 -> 13 /
+    // 20 -> 17 us, backward 48 -> 38 / 58 -> 53 us).  Head size 64 spills in dK/dV and gains nothing; head size 128 does not fit
+    // from T = 256 on (203 KB): both stay with the tile kernels, like every longer sequence.
+    case 256: if constexpr (HS <= 32 && fits_lds<HS, 4>()) return launch<HS, 4>(which, a, s); break;
   }
   return -1;
 }

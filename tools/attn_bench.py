@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mmfn_amd import ops
 dev = "cuda:0"
-B, T, NH = 32, 192, 4
+B, T, NH = int(os.environ.get("ATTN_B", "32")), int(os.environ.get("ATTN_T", "192")), 4
 iters = 20
 DT = torch.bfloat16 if os.environ.get("ATTN_DTYPE") == "bf16" else torch.float32   # bf16: the bf16 mode's kernels (attention16.hip)
 P = float(os.environ.get("ATTN_DROP", "0"))
