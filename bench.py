@@ -358,6 +358,10 @@ def main():
     local_rank = gpu_index
     dist = None
     if world > 1:
+        # a multi-rank run that stops making progress (a collective some rank never joins) says where it stood instead of sitting
+        # there until the launcher is killed from outside: all threads' stacks to stderr, then exit 124
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get("MMFN_BENCH_WATCHDOG_S", "900")), exit=True)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("MMFN_DIST_BACKEND", "gloo" if os.environ.get("MMFN_BENCH_SINGLE_DEVICE") else "nccl")

@@ -1,0 +1,151 @@
+"""Untraced clock of the replayed training step, phase by phase.
+
+rocprofv3's kernel trace serialises concurrent kernels and stretches short ones (tools/phase_timeline.py reads 36 ms for a step
+that replays in 32, and 24 for the bf16 step that replays in 17.7), so it ranks phases but is no clock.  Here the step is captured
+into a hipGraph 20 times, each time with every launch AFTER one more seam of the plan suppressed (the library handle is swapped
+for a proxy whose entry points return 0 without launching once the seam has been passed: forks and joins are still recorded, the
+kernels are not), and each truncated graph is replayed on its own, unprofiled.  The difference between consecutive prefixes is
+what the phase adds to the step with everything before it in place.
+
+    python tools/phase_clock.py [--dtype bf16] [--batch 32] [--variant vec]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from mmfn_amd import _lib, ops  # noqa: E402
+from mmfn_amd.config import GlobalConfig  # noqa: E402
+from mmfn_amd.graphs import Recorder  # noqa: E402
+from mmfn_amd.model import MMFN, MMFNImg, MMFNRad  # noqa: E402
+
+
+class Proxy(object):
+    """Stands in for the ctypes handle: past the cut every entry point that takes a stream (i.e. launches) returns 0 instead;
+    the host-side helpers (workspace sizes, partial-row counts, struct sizes) keep answering."""
+
+    def __init__(self, real):
+        self._real = real
+        self.muted = False
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        sig = _lib._SIGNATURES.get(name)
+        import ctypes
+        if sig is None or not sig[1] or sig[1][-1] is not ctypes.c_void_p:
+            return fn
+
+        def call(*a):
+            return 0 if self.muted else fn(*a)
+        return call
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--variant", default="vec", choices=["vec", "img", "rad"])
+    ap.add_argument("--reps", type=int, default=30)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(42)
+    cls = {"vec": MMFN, "img": MMFNImg, "rad": MMFNRad}[args.variant]
+    net = cls(GlobalConfig(act_dtype="bf16" if args.dtype == "bf16" else "f32"), dev).train()
+    inp, gt = bench.synth_inputs(args.batch, dev, seed=42, variant=args.variant)
+    eng = net._engine_for()
+    for _ in range(2):
+        eng.train_step(inp, gt, lr=1e-4)
+    torch.cuda.synchronize()
+    eng.set_hyper(eng.hyper_rows(lr=1e-4))
+    proxy = Proxy(_lib.lib())
+    _lib._lib = proxy
+
+    # ---- seams: (label, object, attribute, which call of it) - the cut falls AFTER that call returns
+    seams = []
+    state = {"n": 0, "cut": None}
+
+    def seam(label):
+        state["n"] += 1
+        if state["cut"] is not None and state["n"] == state["cut"]:
+            proxy.muted = True
+        if state["cut"] is None:
+            seams.append(label)
+
+    def wrap(obj, attr, label_of):
+        real = getattr(obj, attr)
+        calls = {"k": 0}
+
+        def f(*a, **kw):
+            out = real(*a, **kw)
+            label = label_of(calls["k"])
+            calls["k"] += 1
+            if label:
+                seam(label)
+            return out
+        f._calls = calls
+        setattr(obj, attr, f)
+        return f
+
+    fwd_lane_labels = ["fwd ingest + stems + layer1 (3 lanes)", "fwd layer2 (3 lanes)", "fwd layer3 (3 lanes)", "fwd layer4 (3 lanes)"]
+    bwd_lane_labels = ["bwd layer4 (3 lanes)", "bwd layer3 (3 lanes)", "bwd layer2 (3 lanes)", "bwd layer1 + stems + map branch (3 lanes)"]
+    wrapped = [wrap(eng, "_branches", lambda k: (fwd_lane_labels + bwd_lane_labels)[k] if k < 8 else None)]
+    for s, g in enumerate(eng.gpts):
+        wrapped.append(wrap(g, "fwd", lambda k, s=s: "fwd transformer %d" % (s + 1)))
+        wrapped.append(wrap(g, "bwd", lambda k, s=s: "bwd transformer %d" % (s + 1)))
+    wrapped.append(wrap(eng.head, "fwd", lambda k: "fwd fuse + head + loss"))
+    wrapped.append(wrap(eng, "backward_begin", lambda k: "bwd head"))
+    wrapped.append(wrap(eng, "optimizer_step", lambda k: "AdamW"))
+
+    def body():
+        state["n"] = 0
+        proxy.muted = False
+        for w in wrapped:
+            w._calls["k"] = 0
+        ops.rng_advance(eng.rng_state)
+        eng.forward(inp, True, gt)
+        eng.backward_and_step(None, lr=1e-4)
+        proxy.muted = False
+
+    body()   # eager: collects the seam labels in program order
+    torch.cuda.synchronize()
+    n_seams = len(seams)
+
+    def clock(cut):
+        state["cut"] = cut
+        rec = Recorder(eng)
+        rec.capture(body)
+        for _ in range(3):
+            rec.replay()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                rec.replay()
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t0) / args.reps * 1e3
+            best = t if best is None else min(best, t)
+        del rec
+        return best
+
+    prev = 0.0
+    rows = []
+    for k in range(1, n_seams + 1):
+        t = clock(k)
+        rows.append((seams[k - 1], t - prev, t))
+        prev = t
+    print("# untraced phase clock: %s B=%d %s; prefix graphs replayed alone, best of 3 x %d replays" % (args.variant, args.batch, args.dtype, args.reps))
+    print("%-46s %9s %10s" % ("phase", "adds ms", "prefix ms"))
+    for name, d, t in rows:
+        print("%-46s %9.3f %10.3f" % (name, d, t))
+    tf = sum(d for n, d, _ in rows if n.startswith("fwd transformer") or n.startswith("bwd transformer"))
+    tl = sum(d for n, d, _ in rows if "lanes" in n)
+    print("transformers %.2f ms, trunk lanes %.2f ms, rest %.2f ms, whole step %.2f ms" % (tf, tl, prev - tf - tl, prev))
+
+
+if __name__ == "__main__":
+    main()
