@@ -31,6 +31,7 @@ run img_b32 --variant img
 run image_only_b128 --config img128
 run bf16_b32 --config bf16
 run bf16_img_b32 --dtype bf16 --variant img
+run bf16_rad_b16_65536 --config rad16 --dtype bf16
 run bf16_image_only_b128 --dtype bf16 --config img128
 run bf16_operands_b32 --dtype bf16-operands
 run vec_19x8 --lane-format 19x8
