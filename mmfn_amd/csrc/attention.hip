@@ -585,6 +585,11 @@ extern "C" int mmfn_attention_bwd_bf16(const void* q, const void* k, const void*
   a.scale = scale; a.drop_p = drop_p; a.rng_stream = rng_stream; a.io_bf16 = 1;
   if (drop_p > 0.f && !rng_state) return MMFN_EINVAL;
   if ((ldg & 3) || !lse || !delta) return MMFN_EINVAL;
+  if (a.B > 0 && a.T > 0 && a.NH > 0 && !((uintptr_t)a.q & 15) && !((uintptr_t)a.k & 15) && !((uintptr_t)a.v & 15)) {
+    // both passes in one launch (attention16.hip attn16_bwd_kernel): the key-owned pass forms delta itself
+    const int both = mmfn_attn16_launch(3, HS, a, (hipStream_t)stream);
+    if (both >= 0) return both;
+  }
   int rc = dispatch(1, HS, a, (hipStream_t)stream);
   if (rc) return rc;
   return dispatch(2, HS, a, (hipStream_t)stream);

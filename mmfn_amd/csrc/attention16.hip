@@ -135,10 +135,10 @@ __device__ __forceinline__ void store_rows(const f32x16* acc, bf16_t* dst /* thi
 }
 
 struct Ids { int b, hd, part; };
-__device__ __forceinline__ Ids block_ids(int NH, int parts) {
-  // blockIdx.x -> (part fastest): the halves of a (sample, head) are neighbours; XCD-aware order keeps them on one L2
-  const int nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, r = nb & 7;
-  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+// bx of nb blocks -> (part fastest): the halves of a (sample, head) are neighbours; XCD-aware order keeps them on one L2
+__device__ __forceinline__ Ids block_ids(int NH, int parts, int nb, int bx) {
+  const int xcd = bx & 7, q = nb >> 3, r = nb & 7;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bx >> 3);
   Ids o;
   o.part = id % parts;
   o.hd = (id / parts) % NH;
@@ -149,12 +149,13 @@ __device__ __forceinline__ Ids block_ids(int NH, int parts) {
 // ------------------------------------------------------------------------------------------ forward
 template <int HS, int NKT, int NQT>
 __global__ __launch_bounds__(64 * NQT) void attn16_fwd_kernel(const AttnArgs a) {
+  const int nb = gridDim.x, bx = blockIdx.x;
   constexpr int T = 32 * NKT, NKS = HS / 16, ND = (HS + 31) / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;
   unsigned char* Vs = smem + T * HS * 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
-  const Ids id = block_ids(a.NH, NKT / NQT);
+  const Ids id = block_ids(a.NH, NKT / NQT, nb, bx);
   const size_t rowbase = (size_t)id.b * T;
   const bf16_t* q = reinterpret_cast<const bf16_t*>(a.q) + rowbase * a.ld + id.hd * HS;
   const bf16_t* k = reinterpret_cast<const bf16_t*>(a.k) + rowbase * a.ld + id.hd * HS;
@@ -225,13 +226,12 @@ __global__ __launch_bounds__(64 * NQT) void attn16_fwd_kernel(const AttnArgs a) 
 
 // ------------------------------------------------------------------------------------------ backward, query-owned: dQ (+ delta)
 template <int HS, int NKT, int NQT>
-__global__ __launch_bounds__(64 * NQT) void attn16_dq_kernel(const AttnArgs a) {
+__device__ __forceinline__ void attn16_dq_body(const AttnArgs& a, unsigned char* smem, int nb, int bx) {
   constexpr int T = 32 * NKT, NKS = HS / 16, ND = (HS + 31) / 32;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;
   unsigned char* Vs = smem + T * HS * 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
-  const Ids id = block_ids(a.NH, NKT / NQT);
+  const Ids id = block_ids(a.NH, NKT / NQT, nb, bx);
   const size_t rowbase = (size_t)id.b * T;
   const bf16_t* q = reinterpret_cast<const bf16_t*>(a.q) + rowbase * a.ld + id.hd * HS;
   const bf16_t* k = reinterpret_cast<const bf16_t*>(a.k) + rowbase * a.ld + id.hd * HS;
@@ -292,17 +292,23 @@ __global__ __launch_bounds__(64 * NQT) void attn16_dq_kernel(const AttnArgs a) {
   }
   store_rows<HS>(dq, reinterpret_cast<bf16_t*>(a.dq) + (rowbase + query) * a.ldg + id.hd * HS, h, 1.0f);
 }
+template <int HS, int NKT, int NQT>
+__global__ __launch_bounds__(64 * NQT) void attn16_dq_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  attn16_dq_body<HS, NKT, NQT>(a, smem, gridDim.x, blockIdx.x);
+}
 
 // ------------------------------------------------------------------------------------------ backward, key-owned: dK, dV
-template <int HS, int NKT, int NQT>
-__global__ __launch_bounds__(64 * NQT) void attn16_dkv_kernel(const AttnArgs a) {
+// OWN_DELTA: delta of every query is formed here from dO and O (the sums in the query-owned pass's order: bit-identical to what
+// that pass writes to a.delta) instead of read back - the two passes then have no dependence and share one launch (attn16_bwd_kernel)
+template <int HS, int NKT, int NQT, bool OWN_DELTA>
+__device__ __forceinline__ void attn16_dkv_body(const AttnArgs& a, unsigned char* smem, int nb, int bx) {
   constexpr int T = 32 * NKT, NKS = HS / 16, ND = (HS + 31) / 32;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Qs = smem;
   unsigned char* Gs = smem + T * HS * 2;   // dO
   float* stats = reinterpret_cast<float*>(smem + 2 * T * HS * 2);   // [2][T]: lse, delta of every query (read 16 + 16 times per tile per lane)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
-  const Ids id = block_ids(a.NH, NKT / NQT);
+  const Ids id = block_ids(a.NH, NKT / NQT, nb, bx);
   const size_t rowbase = (size_t)id.b * T;
   const bf16_t* q = reinterpret_cast<const bf16_t*>(a.q) + rowbase * a.ld + id.hd * HS;
   const bf16_t* k = reinterpret_cast<const bf16_t*>(a.k) + rowbase * a.ld + id.hd * HS;
@@ -313,7 +319,22 @@ __global__ __launch_bounds__(64 * NQT) void attn16_dkv_kernel(const AttnArgs a) 
   const size_t stat0 = ((size_t)id.b * a.NH + id.hd) * T;
   for (int t = threadIdx.x; t < T; t += 64 * NQT) {
     stats[t] = a.lse[stat0 + t];
-    stats[T + t] = a.delta[stat0 + t];
+    if (OWN_DELTA) {
+      const bf16_t* o = reinterpret_cast<const bf16_t*>(a.o) + rowbase * a.ldo + id.hd * HS;
+      float dh[2] = {0.f, 0.f};
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const bf16x8 df = *reinterpret_cast<const bf16x8*>(dO + (size_t)t * a.ldo + ks * 16 + hh * 8);
+          const bf16x8 of = *reinterpret_cast<const bf16x8*>(o + (size_t)t * a.ldo + ks * 16 + hh * 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dh[hh] += (float)df[j] * (float)of[j];
+        }
+      stats[T + t] = dh[0] + dh[1];
+    } else {
+      stats[T + t] = a.delta[stat0 + t];
+    }
   }
   const int key = (id.part * NQT + wave) * 32 + l31;
   bf16x8 kf[NKS], vf[NKS];
@@ -367,23 +388,46 @@ __global__ __launch_bounds__(64 * NQT) void attn16_dkv_kernel(const AttnArgs a) 
   store_rows<HS>(dv, reinterpret_cast<bf16_t*>(a.dv) + (rowbase + key) * a.ldg + id.hd * HS, h, 1.0f);
   store_rows<HS>(dk, reinterpret_cast<bf16_t*>(a.dk) + (rowbase + key) * a.ldg + id.hd * HS, h, 1.0f);
 }
+template <int HS, int NKT, int NQT>
+__global__ __launch_bounds__(64 * NQT) void attn16_dkv_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  attn16_dkv_body<HS, NKT, NQT, false>(a, smem, gridDim.x, blockIdx.x);
+}
+
+// Both backward passes in ONE launch of twice the blocks: block role = query-owned (dQ, delta) or key-owned (dK, dV).  The passes
+// are independent once the key-owned one forms delta itself, so at head sizes up to 64 (two or more workgroups per CU) they run side
+// by side instead of one after the other, and every length saves a launch on the transformers' dependent chain.  Blocks 16 j .. 16 j + 7
+// take the query-owned role and 16 j + 8 .. 16 j + 15 the key-owned role of the SAME eight ids: a pair shares its XCD (block b runs on
+// XCD b % 8) and therefore the L2 lines of q / k / v / dO.
+template <int HS, int NKT, int NQT>
+__global__ __launch_bounds__(64 * NQT) void attn16_bwd_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nb = gridDim.x >> 1, gx = blockIdx.x;
+  int role, bx;
+  if ((nb & 7) == 0) { role = (gx >> 3) & 1; bx = (gx & 7) | ((gx >> 4) << 3); }
+  else { role = gx >= nb; bx = gx - role * nb; }
+  if (role == 0) attn16_dq_body<HS, NKT, NQT>(a, smem, nb, bx);
+  else attn16_dkv_body<HS, NKT, NQT, true>(a, smem, nb, bx);
+}
 
 template <int HS, int NKT>
 int launch16(int which, const AttnArgs& a, hipStream_t s) {
   constexpr int NQT = (NKT % 2 == 0) ? NKT / 2 : NKT;
   constexpr int smem = 2 * 32 * NKT * HS * 2 + 2 * 32 * NKT * 4;   // two staged matrices (+ lse / delta in the key-owned pass)
   const dim3 grid(a.B * a.NH * (NKT / NQT)), block(64 * NQT);
-  static bool ready[3] = {false, false, false};
+  static bool ready[4] = {false, false, false, false};
   const void* fn = which == 0 ? reinterpret_cast<const void*>(&attn16_fwd_kernel<HS, NKT, NQT>)
                  : which == 1 ? reinterpret_cast<const void*>(&attn16_dq_kernel<HS, NKT, NQT>)
-                              : reinterpret_cast<const void*>(&attn16_dkv_kernel<HS, NKT, NQT>);
+                 : which == 2 ? reinterpret_cast<const void*>(&attn16_dkv_kernel<HS, NKT, NQT>)
+                              : reinterpret_cast<const void*>(&attn16_bwd_kernel<HS, NKT, NQT>);
   if (!ready[which]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return MMFN_EINVAL;
     ready[which] = true;
   }
   if (which == 0) hipLaunchKernelGGL((attn16_fwd_kernel<HS, NKT, NQT>), grid, block, smem, s, a);
   else if (which == 1) hipLaunchKernelGGL((attn16_dq_kernel<HS, NKT, NQT>), grid, block, smem, s, a);
-  else hipLaunchKernelGGL((attn16_dkv_kernel<HS, NKT, NQT>), grid, block, smem, s, a);
+  else if (which == 2) hipLaunchKernelGGL((attn16_dkv_kernel<HS, NKT, NQT>), grid, block, smem, s, a);
+  else hipLaunchKernelGGL((attn16_bwd_kernel<HS, NKT, NQT>), dim3(2 * grid.x), block, smem, s, a);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
@@ -401,9 +445,13 @@ int by_tokens16(int which, const AttnArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// which: 0 forward, 1 dQ (+ delta), 2 dK / dV.  -1: shape not covered (the caller falls back to the fp32-arithmetic kernels).
+// which: 0 forward, 1 dQ (+ delta), 2 dK / dV (after 1: reads delta), 3 both backward passes in one launch.  -1: shape not covered (the caller falls back to the fp32-arithmetic kernels).
 int mmfn_attn16_launch(int which, int hs, const AttnArgs& a, hipStream_t s) {
   if ((a.ld & 7) || (a.ldo & 7) || (which > 0 && (a.ldg & 7))) return -1;
+  // one launch for both backward passes where two workgroups share a CU (measured in the step's shapes, dQ + dK/dV -> merged:
+  // head size 16: 17.2 + 16.6 -> 21.3 us, 32: 18.6 + 18.1 -> 23.3, 64: 20.8 + 20.9 -> 29.4); at head size 128 one workgroup's K + V
+  // fill the LDS, the roles run in two rounds and the launch is slower than the two it replaces (26.2 + 28.1 -> 59.5)
+  if (which == 3 && hs > 64) return -1;
   switch (hs) {
     case 16: return by_tokens16<16>(which, a, s);
     case 32: return by_tokens16<32>(which, a, s);

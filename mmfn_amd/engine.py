@@ -55,6 +55,8 @@ class Ctx(object):
         self.drop = drop_p if training else (0.0, 0.0, 0.0)  # (embd, attn, resid)
         self.rng_state = rng_state
         self.side = side  # side stream for work that is off the critical path (weight gradients), or None
+        self.side2 = None  # a second one (lane 2's stream): the launch-bound transformers split their side work over both (GPT._offload_side)
+        self.side2_used = False
         self.adt = engine.act_dtype if engine is not None else torch.float32   # dtype of activation / activation-gradient buffers
         self.bf16 = self.adt == torch.bfloat16
         self.folded = False  # eval forward over BatchNorm-folded filters (Engine.fold_batchnorm)
@@ -95,16 +97,19 @@ class Ctx(object):
         ev.record(torch.cuda.current_stream())
         return ev
 
-    def offload_at(self, ev, fn):
+    def offload_at(self, ev, fn, second=False):
         """Like offload(), but ordered after the earlier fork_point() `ev` instead of after everything enqueued so far.
         Used to enqueue side work AFTER the chain's next kernel: when a captured graph is replayed, the first-captured child
         of a node stays on the node's hardware queue and later children move to other queues; capturing the chain's
         continuation first keeps the dependent chain on one queue (a queue hop costs 10-16 us of idle time)."""
         if self.side is None or ev is None:
             return fn()
-        self.side.wait_event(ev)
-        with torch.cuda.stream(self.side), ops.lane(1):
+        st, ln = (self.side2, 2) if (second and self.side2 is not None) else (self.side, 1)
+        st.wait_event(ev)
+        with torch.cuda.stream(st), ops.lane(ln):
             fn()
+        if st is self.side2:
+            self.side2_used = True
 
     def rejoin(self):
         """Current stream waits for all offloaded work (before its input buffers are reused)."""
@@ -113,6 +118,11 @@ class Ctx(object):
         ev = torch.cuda.Event()
         ev.record(self.side)
         torch.cuda.current_stream().wait_event(ev)
+        if self.side2_used:
+            ev2 = torch.cuda.Event()
+            ev2.record(self.side2)
+            torch.cuda.current_stream().wait_event(ev2)
+            self.side2_used = False
 
 
 # ----------------------------------------------------------------------------- conv + BN
@@ -559,6 +569,12 @@ class LayerNorm(object):
 # "1": training too - measured SLOWER there (32.01 vs 31.74 ms per step, DESIGN.md section 5: the folded GEMMs cost what the
 # LayerNorm launches saved, and the recomputation competes with the backward's side work); "0": never.
 LN_FOLD = os.environ.get("MMFN_LN_FOLD", "eval")
+# Side work of the transformers up to this width alternates between TWO side streams (GPT._offload_side): their blocks are
+# launch-bound on the chain AND on the side stream (8 against ~14 launches of 5-8 us per block), so the join at the end of the
+# transformer waited for the side stream.  Measured (3 interleaved runs each): bf16 step 17.55 -> 17.16 ms, fp32 31.62 -> 31.37;
+# C = 512 included: 17.33 / 31.50 (its side work is chip-filling GEMMs); three or four streams: 17.57 / 18.02 and 31.95 (every
+# further fork is a queue hop).
+SIDE_SPLIT_MAX_C = 256
 
 
 class GPT(object):
@@ -662,6 +678,16 @@ class GPT(object):
         y = self.ln_f.fwd(ctx, x, out=bufs.get(nm + ".ln_f.out", (M, C), adt))
         return y.view(B, T, C)
 
+    def _offload_side(self, ctx, pending):
+        """A block's side work (fork point, launch closures).  The narrow transformers are launch-bound on BOTH streams - per block
+        8 kernels on the chain and ~14 on the side stream, 5-8 us each - so there the closures alternate between two side streams."""
+        ev, work = pending
+        if self.C <= SIDE_SPLIT_MAX_C and ctx.side2 is not None and len(work) > 1:
+            ctx.offload_at(ev, lambda: [f() for f in work[0::2]])
+            ctx.offload_at(ev, lambda: [f() for f in work[1::2]], second=True)
+        else:
+            ctx.offload_at(ev, lambda: [f() for f in work])
+
     def bwd(self, ctx, g_y):
         """g_y: [B,T,C] gradient of the GPT output.  Returns the token gradient (masked by the
         embedding dropout) to be spread back over the feature maps; writes all parameter grads."""
@@ -719,7 +745,7 @@ class GPT(object):
             else:
                 ops.linear_dx(gp, Wb(blk["fc2"]), out=gh, aux=h, ldaux=4 * C)
             if pending is not None:   # the previous block's side work, now that this block's first chain kernel is captured
-                ctx.offload_at(pending[0], lambda work=pending[1]: [f() for f in work])
+                self._offload_side(ctx, pending)
                 pending = None
             if ghpart is not None:
                 side.append(lambda gh=gh, blk=blk, a2=a2, p=ghpart, r=ghrows: (ops16.colsum_partials(p, r, 4 * C, blk["fc1"].gb),
@@ -756,7 +782,7 @@ class GPT(object):
             work, side = side, []
             pending = (ctx.fork_point(), work)   # enqueued after the next block's first kernel (Ctx.offload_at)
         if pending is not None:
-            ctx.offload_at(pending[0], lambda work=pending[1]: [f() for f in work])
+            self._offload_side(ctx, pending)
         ctx.rejoin()
         gtok = g.view(B, T, C)
         ops.tokens_bwd(gtok, self.velocity, self.g_pos.view(T, C), self.vel.gw.view(C), self.vel.gb, p_embd, ctx.rng_state,
@@ -1270,7 +1296,9 @@ class Engine(object):
     def _ctx(self, B, training):
         cfg = self.cfg
         side = self.side[0] if (self.multi_stream and self.offload_wgrad and training) else None
-        return Ctx(self._bufs_for(B), training, (cfg.embd_pdrop, cfg.attn_pdrop, cfg.resid_pdrop), self.rng_state, side, engine=self)
+        ctx = Ctx(self._bufs_for(B), training, (cfg.embd_pdrop, cfg.attn_pdrop, cfg.resid_pdrop), self.rng_state, side, engine=self)
+        ctx.side2 = self.side[1] if side is not None else None
+        return ctx
 
     def _ingest(self, ctx, inp):
         """inp: dict of device tensors -> NHWC network inputs."""
