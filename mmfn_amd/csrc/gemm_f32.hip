@@ -63,10 +63,10 @@ __device__ __forceinline__ void epilogue_store(const mmfn_gemm_desc& d, uint64_t
   *c = v;
 }
 
-__device__ __forceinline__ mmfn_gemm_desc batch_view(const mmfn_gemm_desc& in) {
+__device__ __forceinline__ mmfn_gemm_desc batch_view(const mmfn_gemm_desc& in, int zb = -1) {
   mmfn_gemm_desc d = in;
   if (in.batch > 1) {
-    const size_t z = blockIdx.z;
+    const size_t z = zb >= 0 ? (size_t)zb : (size_t)blockIdx.z;
     d.A += z * in.strideA;
     d.B += z * in.strideB;
     d.C += z * in.strideC;
@@ -427,7 +427,31 @@ template <int AM, int BMODE, int BM, int BN, bool LNF = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(LNF && BM == 128 && BN == 128 ? 3 : 1)))
 void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, const int tiles_n,
                                                            const int log2_ow, const int log2_ohw) {
-  const mmfn_gemm_desc d = d_in.dg_parity ? d_in : batch_view(d_in);
+  // Batched launches (the 36 frequency GEMMs of a Winograd convolution): a batch entry's tiles all on ONE XCD.  With the plain order
+  // (x = tile fastest, z = entry) the tiles of an entry are dealt round-robin over the eight XCDs, so every L2 fetches that entry's
+  // filter panel U_f (and, across column tiles, its activation panel) for itself: 58 MB fetched per layer3 launch against 20 MB of
+  // distinct operands (profiles/r04a_pmc.txt).  Here XCD x (= linear block id % 8, the observed dispatch policy) takes the entries
+  // x, x + 8, x + 16, ... whole, and the batch % 8 left-over entries are split over 8 / (batch % 8) XCDs each (36 entries: four whole
+  // entries and half of a fifth per XCD).  bz / by / bxr: the (entry, k-split, tile) this block computes.
+  int bz = blockIdx.z, by = blockIdx.y, bxr = blockIdx.x;
+  bool xcd_batch = false;
+#ifndef MMFN_GEMM_NO_XCD_BATCH
+  if (d_in.batch > 1 && !d_in.dg_parity) {
+    const int U = gridDim.x * gridDim.y, full = d_in.batch >> 3, rem = d_in.batch & 7;
+    const int shares = rem ? 8 / rem : 1;
+    if (rem == 0 || ((8 % rem) == 0 && (U % shares) == 0)) {
+      const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+      const int xcd = lin & 7, s = lin >> 3;
+      int r;
+      if (s < full * U) { bz = xcd + 8 * (s / U); r = s % U; }
+      else { bz = 8 * full + xcd / shares; r = (s - full * U) + (xcd % shares) * (U / shares); }
+      by = r / (int)gridDim.x;
+      bxr = r - by * (int)gridDim.x;
+      xcd_batch = true;
+    }
+  }
+#endif
+  const mmfn_gemm_desc d = d_in.dg_parity ? d_in : batch_view(d_in, bz);
   // Stride-2 transposed convolution, decomposed by output-pixel parity (blockIdx.z = 2*py + px): an input
   // pixel (ih, iw) only receives taps with kh == (ih + pad) mod 2, kw == (iw + pad) mod 2, so each of the
   // four parity classes is a dense GEMM over its own 1/2/2/4 (3x3) taps instead of 9 taps of which 3/4
@@ -470,14 +494,16 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch policy; speed only).  Give each
   // XCD a contiguous run of tiles so the blocks that share an A row-panel / B column-panel hit the same L2.
   int bid;
-  {
+  if (xcd_batch) {
+    bid = bxr;   // the entry's tiles already share an XCD
+  } else {
     const int nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, r = nb & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   }
 #endif
   const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
   const int nkt = Kloc / BK;
-  const int kt_begin = blockIdx.y * kt_per_split;
+  const int kt_begin = by * kt_per_split;
   const int kt_end = min(nkt, kt_begin + kt_per_split);
   const int KHW = d.KH * d.KW;
   const float* zero = g_zero_page;
@@ -745,7 +771,7 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
   uint64_t key = 0;
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
   const bool to_slab = d.splitk > 1;
-  float* slab = to_slab ? d.workspace + ((size_t)blockIdx.y * max(1, d_in.batch) + (d_in.batch > 1 ? blockIdx.z : 0)) * d.M * d.N : nullptr;
+  float* slab = to_slab ? d.workspace + ((size_t)by * max(1, d_in.batch) + (d_in.batch > 1 ? bz : 0)) * d.M * d.N : nullptr;
   // Plain stores of an interior tile (no epilogue operation, or a split slab): one pointer per lane and 16 * TM * TN stores at
   // compile-time row multiples of the leading dimension.  The general loop below tests the tile edge and eight epilogue flags per
   // ELEMENT; tools/experiments/gemm32_pmc.sh counts ~730 non-MFMA instructions per wave around a tile's k-loop, most of them there -

@@ -31,6 +31,8 @@ class Proxy(object):
     def __init__(self, real):
         self._real = real
         self.muted = False
+        self.in_fork = False    # inside Engine._branches (the three trunk lanes)
+        self.lanes = None       # --lanes: the lanes whose launches are kept inside a fork (None: all)
 
     def __getattr__(self, name):
         fn = getattr(self._real, name)
@@ -40,7 +42,9 @@ class Proxy(object):
             return fn
 
         def call(*a):
-            return 0 if self.muted else fn(*a)
+            if self.muted or (self.in_fork and self.lanes is not None and ops.current_lane() not in self.lanes):
+                return 0
+            return fn(*a)
         return call
 
 
@@ -50,6 +54,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--variant", default="vec", choices=["vec", "img", "rad"])
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--lanes", action="store_true", help="instead of the phases: the whole step with only lane 0 / 1 / 2 / none / all "
+                                                         "of the trunk forks launching - what each lane costs alone and what they cost together")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(42)
@@ -131,6 +137,30 @@ def main():
             best = t if best is None else min(best, t)
         del rec
         return best
+
+    if args.lanes:
+        real_branches = wrapped[0]
+
+        def fork(*a, **kw):
+            proxy.in_fork = True
+            try:
+                return real_branches(*a, **kw)
+            finally:
+                proxy.in_fork = False
+        eng._branches = fork
+        names = {0: "lane 0 (camera ResNet-34, main stream)", 1: "lane 1 (LiDAR ResNet-18)", 2: "lane 2 (map branch)"}
+        res = {}
+        for tag, keep in (("none", set()), ("0", {0}), ("1", {1}), ("2", {2}), ("all", None)):
+            proxy.lanes = keep
+            res[tag] = clock(None)
+        base = res["none"]
+        print("# trunk lanes of the replayed step alone and together (%s B=%d %s): whole-step time with only that lane's launches inside the forks" % (args.variant, args.batch, args.dtype))
+        print("no lane launches (transformers, head, AdamW, fork / join only)   %8.3f ms" % base)
+        for k in (0, 1, 2):
+            print("%-64s %8.3f ms  (+%.3f)" % ("only " + names[k], res[str(k)], res[str(k)] - base))
+        print("%-64s %8.3f ms  (+%.3f; the lanes alone add up to +%.3f, the longest is +%.3f)" % (
+            "all three lanes", res["all"], res["all"] - base, sum(res[str(k)] - base for k in (0, 1, 2)), max(res[str(k)] - base for k in (0, 1, 2))))
+        return
 
     prev = 0.0
     rows = []
