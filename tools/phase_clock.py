@@ -33,6 +33,7 @@ class Proxy(object):
         self.muted = False
         self.in_fork = False    # inside Engine._branches (the three trunk lanes)
         self.lanes = None       # --lanes: the lanes whose launches are kept inside a fork (None: all)
+        self.no_side = False    # --side: drop the transformers' side work (weight / bias gradients, reductions: lanes 1, 2 outside forks)
 
     def __getattr__(self, name):
         fn = getattr(self._real, name)
@@ -44,6 +45,8 @@ class Proxy(object):
         def call(*a):
             if self.muted or (self.in_fork and self.lanes is not None and ops.current_lane() not in self.lanes):
                 return 0
+            if self.no_side and not self.in_fork and ops.current_lane() != 0:
+                return 0
             return fn(*a)
         return call
 
@@ -54,6 +57,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--variant", default="vec", choices=["vec", "img", "rad"])
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--side", action="store_true", help="the backward of each transformer with and without its side-stream work")
     ap.add_argument("--lanes", action="store_true", help="instead of the phases: the whole step with only lane 0 / 1 / 2 / none / all "
                                                          "of the trunk forks launching - what each lane costs alone and what they cost together")
     args = ap.parse_args()
@@ -138,6 +142,31 @@ def main():
         del rec
         return best
 
+    if args.side:
+        real_branches = wrapped[0]
+
+        def fork(*a, **kw):
+            proxy.in_fork = True
+            try:
+                return real_branches(*a, **kw)
+            finally:
+                proxy.in_fork = False
+        eng._branches = fork
+        prev = 0.0
+        print("# what the transformers' side work costs (%s B=%d %s): each backward phase with and without the side streams' launches" % (args.variant, args.batch, args.dtype))
+        n_seams = len(seams)
+        for k in range(1, n_seams + 1):
+            if not seams[k - 1].startswith("bwd transformer"):
+                continue
+            proxy.no_side = False
+            t_prev = clock(k - 1)
+            t_full = clock(k)
+            proxy.no_side = True
+            t_chain = clock(k) - (clock(k - 1) - 0.0)
+            proxy.no_side = False
+            # prefix without side work in EARLIER phases differs too, so compare phase additions under both settings
+            print("%-22s with side work +%.3f ms   chain only +%.3f ms" % (seams[k - 1], t_full - t_prev, t_chain))
+        return
     if args.lanes:
         real_branches = wrapped[0]
 
