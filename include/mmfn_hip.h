@@ -299,6 +299,10 @@ int mmfn_layernorm_bwd_partial_f32(const float* g, const float* x, const float* 
                                    float* partials, void* stream);
 int mmfn_layernorm_bwd_finalize_f32(const float* partials, int rows, int C, float* dweight, float* dbias, float* dx_colsum,
                                     void* stream);
+/* mmfn_layernorm_bwd_finalize_f32 for n LayerNorms of one (rows, C) in one launch: table (device memory) holds per entry the four
+ * pointers partials, dweight, dbias, dx_colsum (NULL: the entry's partial rows are [rows][2][C]).  The 17 LayerNorms of a fusion
+ * transformer (model_vec.py:112-133 Block.ln1 / ln2, :172 ln_f) finish their parameter gradients with one launch. */
+int mmfn_layernorm_bwd_finalize_batched_f32(const void* const* table, int n, int rows, int C, void* stream);
 /* out[c] = sum_r in[r*ld + c]   (bias gradients) */
 int64_t mmfn_colsum_workspace_bytes(int64_t M, int C);
 int mmfn_colsum_f32(const float* in, int64_t M, int C, int ld, float* out, void* workspace, void* stream);

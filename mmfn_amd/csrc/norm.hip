@@ -697,6 +697,35 @@ extern "C" int mmfn_layernorm_bwd_partial_bf16(const void* g, const void* x, int
                                       C, act, (bf16_t*)dx_dropped, drop_p, rng_state, rng_stream, want_colsum, partials, stream);
 }
 
+// The same reduction for n LayerNorms of one shape in ONE launch (blockIdx.y = entry): table[4 * e + {0, 1, 2, 3}] = partial rows
+// ([rows][3][C] with a column-sum output, [rows][2][C] without), dweight, dbias, dx_colsum or NULL.  A fusion transformer's 17
+// LayerNorm backward passes leave their row reductions to one such launch at its end instead of 17 on its side streams.
+__global__ void colsum_finalize_batched_kernel(const void* const* __restrict__ table, int nblk, int C) {
+  __shared__ double sh[3][FIN_LANES][FIN_COLS];
+  const void* const* e = table + 4 * blockIdx.y;
+  const float* partials = reinterpret_cast<const float*>(e[0]);
+  float* out0 = reinterpret_cast<float*>(const_cast<void*>(e[1]));
+  float* out1 = reinterpret_cast<float*>(const_cast<void*>(e[2]));
+  float* out2 = reinterpret_cast<float*>(const_cast<void*>(e[3]));
+  const int c = blockIdx.x * FIN_COLS + threadIdx.x % FIN_COLS;
+  const bool valid = c < C;
+  double r[3] = {0, 0, 0};
+  if (out2) reduce_partials<3>(partials, nblk, (size_t)3 * C, C, c, valid, sh, r);
+  else reduce_partials<2>(partials, nblk, (size_t)2 * C, C, c, valid, sh, r);
+  if (!valid || threadIdx.x >= FIN_COLS) return;
+  out0[c] = (float)r[0];
+  out1[c] = (float)r[1];
+  if (out2) out2[c] = (float)r[2];
+}
+
+extern "C" int mmfn_layernorm_bwd_finalize_batched_f32(const void* const* table, int n, int rows, int C, void* stream) {
+  if (!table || n <= 0 || rows <= 0 || C <= 0) return MMFN_EINVAL;
+  hipLaunchKernelGGL(colsum_finalize_batched_kernel, dim3(ceil_div(C, FIN_COLS), n), dim3(FIN_COLS * FIN_LANES), 0, (hipStream_t)stream,
+                     table, rows, C);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmfn_layernorm_bwd_finalize_f32(const float* partials, int rows, int C, float* dweight, float* dbias,
                                                float* dx_colsum, void* stream) {
   if (!partials || rows <= 0 || C <= 0 || !dweight || !dbias) return MMFN_EINVAL;

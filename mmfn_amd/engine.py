@@ -535,7 +535,7 @@ class LayerNorm(object):
         self.saved = (x, mean, rstd, act)
         return y
 
-    def bwd(self, ctx, g, dres=None, out=None, dropped=None, drop_p=0.0, rng_stream=0, colsum=None, defer=False):
+    def bwd(self, ctx, g, dres=None, out=None, dropped=None, drop_p=0.0, rng_stream=0, colsum=None, defer=False, collect=None):
         """defer: the caller rejoins the side stream before the gradients are consumed (GPT.bwd).  dropped: buffer that receives dx with the dropout mask (p, stream) of the branch consuming dx applied.
         colsum: [C] gradient buffer that receives the column sums of that tensor (the consuming Linear's bias gradient)."""
         x, mean, rstd, act = self.saved
@@ -551,7 +551,9 @@ class LayerNorm(object):
             ops.layernorm_bwd_partial(g, x, self.w, self.b, mean, rstd, dx, part, act, dres=dres, dx_dropped=dropped, drop_p=drop_p,
                                       rng_state=rng, rng_stream=rng_stream, want_colsum=colsum is not None)
             fin = lambda: ops.layernorm_bwd_finalize(part, rows, C, self.gw, self.gb, colsum)
-            if isinstance(defer, list):
+            if collect is not None:
+                collect.append((part, self.gw, self.gb, colsum, rows, C))   # GPT.bwd: one batched launch for all of them at its end
+            elif isinstance(defer, list):
                 defer.append(fin)      # the caller decides where the reductions run (GPT.bwd: one fork per block / none)
             else:
                 ctx.offload(fin)
@@ -608,6 +610,7 @@ class GPT(object):
             blk["fold"] = None   # (wqkv * gamma1, c1, c2, fc1.w * gamma2, c1, c2): Engine._build_ln_fold
             self.blocks.append(blk)
         self.ln_f = LayerNorm(name + ".ln_f", layout, prefix + ".ln_f")
+        self._fin_tables = {}   # device pointer tables of the batched LayerNorm finalize, per buffer set
 
     def fwd(self, ctx, feats, velocity):
         B = velocity.shape[0]
@@ -723,10 +726,15 @@ class GPT(object):
         # weight gradient and per LayerNorm reduction (7 per block) that was 0.3 ms per transformer.
         side = []
         pending = None
+        # bf16 mode: the 17 LayerNorm backward passes leave their row reductions (weight / bias gradient, the consuming Linear's bias
+        # gradient) to ONE launch at the end of this transformer (mmfn_layernorm_bwd_finalize_batched_f32) instead of one each on the
+        # side streams.  Bit-identical either way; measured (3 interleaved runs each): bf16 step 17.14 -> 17.09 ms, fp32 31.40 -> 31.49
+        # (there the launch at the tail costs more than the side streams gain) - hence by mode.
+        fins = [] if (ctx.bf16 and ctx.side is not None and DEFER_LN_REDUCTIONS) else None
         refold = getattr(self, "folded_fwd", False)   # the forward ran ln1 / ln2 inside the QKV / mlp.0 GEMMs (LN_FOLD)
         scr_mu, scr_rs = bufs.get(nm + ".ln.scratch.mu", (M,)), bufs.get(nm + ".ln.scratch.rs", (M,))
         g = self.ln_f.bwd(ctx, g_y.view(M, C), out=G[nblk - 1], dropped=GD[nblk - 1] if drop else None, drop_p=p_resid,
-                          rng_stream=sb_of(nblk - 1) + 2, colsum=self.blocks[nblk - 1]["fc2"].gb, defer=side)
+                          rng_stream=sb_of(nblk - 1) + 2, colsum=self.blocks[nblk - 1]["fc2"].gb, defer=side, collect=fins)
         for i in range(nblk - 1, -1, -1):
             blk = self.blocks[i]
             sb = sb_of(i)
@@ -759,7 +767,7 @@ class GPT(object):
             ga2 = bufs.get(nm + ".ga", (M, C), adt)
             ops.linear_dx(gh, Wb(blk["fc1"]), out=ga2)
             g1 = blk["ln2"].bwd(ctx, ga2, dres=g, out=G1[i], dropped=GD2[i] if drop else None, drop_p=p_resid,
-                                rng_stream=sb + 1, colsum=blk["proj"].gb, defer=side)
+                                rng_stream=sb + 1, colsum=blk["proj"].gb, defer=side, collect=fins)
             # ---- attention branch: x1 = x + drop(proj(att(ln1(x))))
             gp = GD2[i] if drop else g1
             side.append(lambda gp=gp, blk=blk, o=o: ops.linear_dw(gp, o, out=blk["proj"].gw))   # proj.gb: from ln2's backward
@@ -778,11 +786,20 @@ class GPT(object):
             ops.linear_dx(dqkv, blk["wqkv16t"] if ctx.bf16 else blk["wqkv"], out=ga)
             g = blk["ln1"].bwd(ctx, ga, dres=g1, out=G[i - 1] if i > 0 else bufs.get(nm + ".g_tok", (M, C), sdt),
                                dropped=GD[i - 1] if (drop and i > 0) else None, drop_p=p_resid,
-                               rng_stream=sb_of(i - 1) + 2, colsum=self.blocks[i - 1]["fc2"].gb if i > 0 else None, defer=side)
+                               rng_stream=sb_of(i - 1) + 2, colsum=self.blocks[i - 1]["fc2"].gb if i > 0 else None, defer=side,
+                               collect=fins)
             work, side = side, []
             pending = (ctx.fork_point(), work)   # enqueued after the next block's first kernel (Ctx.offload_at)
         if pending is not None:
             self._offload_side(ctx, pending)
+        if fins:
+            key = (id(bufs), len(fins))
+            tab = self._fin_tables.get(key)
+            if tab is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("LayerNorm finalize table of %s first built during graph capture; run one eager step first" % nm)
+                tab = self._fin_tables[key] = ops.layernorm_finalize_table([f[:4] for f in fins], g.device)
+            ctx.offload(lambda: ops.layernorm_bwd_finalize_batched(tab, len(fins), fins[0][4], fins[0][5]))
         ctx.rejoin()
         gtok = g.view(B, T, C)
         ops.tokens_bwd(gtok, self.velocity, self.g_pos.view(T, C), self.vel.gw.view(C), self.vel.gb, p_embd, ctx.rng_state,

@@ -842,6 +842,18 @@ def layernorm_bwd_finalize(partials, rows, C, dw, db, dx_colsum=None):
     _call("mmfn_layernorm_bwd_finalize_f32", ptr(partials), rows, C, ptr(dw), ptr(db), ptr(dx_colsum), stream())
 
 
+def layernorm_finalize_table(entries, device):
+    """Device pointer table for layernorm_bwd_finalize_batched: entries = [(partials, dw, db, dx_colsum or None), ...]."""
+    flat = []
+    for part, dw, db, cs in entries:
+        flat += [part.data_ptr(), dw.data_ptr(), db.data_ptr(), 0 if cs is None else cs.data_ptr()]
+    return torch.tensor(flat, dtype=torch.int64).to(device)
+
+
+def layernorm_bwd_finalize_batched(table, n, rows, C):
+    _call("mmfn_layernorm_bwd_finalize_batched_f32", ptr(table), n, rows, C, stream())
+
+
 def colsum(x2d, out, M=None, C=None, ld=None):
     M = x2d.shape[0] if M is None else M
     C = x2d.shape[1] if C is None else C

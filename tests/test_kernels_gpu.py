@@ -106,6 +106,36 @@ def test_layernorm(M, C, act):
     _close(cs, dx.double().sum(0).float().cpu(), 2e-5, "ln dx colsum")
 
 
+def test_layernorm_backward_finalize_batched_equals_one_by_one():
+    """mmfn_layernorm_bwd_finalize_batched_f32: the row reductions of several LayerNorm backward passes of one shape in one launch
+    (a transformer's 17 in the bf16 mode) - bit for bit what the single launches write, with and without the column-sum row."""
+    from mmfn_amd import ops
+    M, C = 768, 128
+    g = _g(11)
+    rows = ops.layernorm_bwd_rows(M)
+    outs_a, outs_b, entries = [], [], []
+    for k in range(5):
+        x = (torch.randn(M, C, generator=g) * 1.5).to(DEV)
+        gy = torch.randn(M, C, generator=g).to(DEV)
+        w, b = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+        mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        ops.layernorm_fwd(x, w, b, torch.empty_like(x), mean, rstd, 0)
+        want = k % 2 == 0
+        part = torch.empty(rows, 3 if want else 2, C, device=DEV)
+        ops.layernorm_bwd_partial(gy, x, w, b, mean, rstd, torch.empty_like(x), part, 0, want_colsum=want)
+        a = [torch.empty(C, device=DEV) for _ in range(3 if want else 2)]
+        bb = [torch.full((C,), float("nan"), device=DEV) for _ in range(3 if want else 2)]
+        ops.layernorm_bwd_finalize(part, rows, C, a[0], a[1], a[2] if want else None)
+        entries.append((part, bb[0], bb[1], bb[2] if want else None))
+        outs_a.append(a); outs_b.append(bb)
+    table = ops.layernorm_finalize_table(entries, DEV)
+    ops.layernorm_bwd_finalize_batched(table, len(entries), rows, C)
+    torch.cuda.synchronize()
+    for a, bb in zip(outs_a, outs_b):
+        for u, v in zip(a, bb):
+            assert torch.equal(u, v)
+
+
 def test_colsum():
     from mmfn_amd import ops
     x = torch.randn(777, 300, generator=_g(1))
