@@ -242,27 +242,54 @@ extern "C" int mmfn_shadow_transpose_bf16(const void* table, int n_entries, int6
 // the weight gradient (which re-reads the same matrix) into plain tuned GEMMs.  KP = K rounded up to the GEMM's k-tile,
 // zero-filled, as are the taps that fall into the padding.
 namespace {
+// One thread per (output pixel, 4 consecutive k): the tap of every k - its offset inside the image and its (kh, kw) for the padding
+// test - comes from a per-block LDS table (K <= 256 entries, built once per block), the pixel from a multiply-high by the host's
+// reciprocal of KP / 4 (plus a correction step) and, where OW and OH * OW are powers of two (every stem here), shifts: the first version decoded both with
+// eight integer divisions per thread and ran at 1-3 TB/s of its 190-360 MB (114-175 us per stem, the longest kernel of the forward).
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_small_kernel(const float* __restrict__ x, T* __restrict__ col, int B, int H, int W, int Cin,
-                                                           int OH, int OW, int KH, int KW, int stride, int pad, int K, int KP) {
+                                                           int OH, int OW, int KH, int KW, int stride, int pad, int K, int KP,
+                                                           unsigned inv_kq, int log2_ow, int log2_ohw) {
+  __shared__ int tap_off[256];
+  __shared__ int tap_hw[256];
+  for (int k = threadIdx.x; k < KP && k < 256; k += 256) {
+    int off = 0, hw = -1;
+    if (k < K) {
+      const int tap = k / Cin, ci = k - tap * Cin;
+      const int kh = tap / KW, kw = tap - kh * KW;
+      off = (kh * W + kw) * Cin + ci;
+      hw = (kh << 16) | kw;
+    }
+    tap_off[k] = off;
+    tap_hw[k] = hw;
+  }
+  __syncthreads();
   const int kq = KP >> 2;
   const int64_t total = (int64_t)B * OH * OW * kq;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int k4 = (int)(i % kq) * 4;
-    int64_t m = i / kq;
-    const int ow = (int)(m % OW); m /= OW;
-    const int oh = (int)(m % OH);
-    const int b = (int)(m / OH);
+    unsigned m = (unsigned)(((uint64_t)(unsigned)i * inv_kq) >> 32);   // floor(2^32 / kq) underestimates i / kq by at most 2 for i < 2^31
+    unsigned rq = (unsigned)i - m * (unsigned)kq;
+    while (rq >= (unsigned)kq) { ++m; rq -= (unsigned)kq; }
+    const int k4 = (int)rq * 4;
+    int b, oh, ow;
+    if (log2_ow >= 0) {
+      ow = m & (OW - 1);
+      oh = (m >> log2_ow) & (OH - 1);
+      b = m >> log2_ohw;
+    } else {
+      ow = m % OW;
+      const unsigned t = m / OW;
+      oh = t % OH;
+      b = t / OH;
+    }
+    const int ih0 = oh * stride - pad, iw0 = ow * stride - pad;
+    const float* base = x + ((size_t)(b * H + ih0) * W + iw0) * Cin;   // (may point outside for padded taps: only dereferenced when inside)
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int k = k4 + e;
-      if (k < K) {
-        const int tap = k / Cin, ci = k - tap * Cin;
-        const int kh = tap / KW, kw = tap - kh * KW;
-        const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
-        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v[e] = x[((size_t)(b * H + ih) * W + iw) * Cin + ci];
-      }
+      const int hw = tap_hw[k4 + e];
+      const int ih = ih0 + (hw >> 16), iw = iw0 + (hw & 0xffff);
+      if (hw >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v[e] = base[tap_off[k4 + e]];
     }
     stx4(col + i * 4, v);
   }
@@ -286,13 +313,19 @@ extern "C" int mmfn_im2col_small(const float* x, void* col, int out_bf16, int B,
   if (!x || !col || KP < K || KP % 4 || Cin <= 0 || Cin > 4) return MMFN_EINVAL;
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
   const int64_t total = (int64_t)B * OH * OW * (KP / 4);
+  if (KP > 256 || total >= ((int64_t)1 << 31) || KH >= 32768 || KW >= 32768) return MMFN_EINVAL;   // tap table / 32-bit element index
   const int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
+  const unsigned kq = (unsigned)(KP / 4);
+  const unsigned inv_kq = kq == 1 ? 0xFFFFFFFFu : (unsigned)(((uint64_t)1 << 32) / kq);   // (i * inv) >> 32 <= i / kq, corrected in the kernel
+  auto lg = [](int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; };
+  const int l_ow = lg(OW), l_oh = lg(OH);
+  const int log2_ow = (l_ow >= 0 && l_oh >= 0) ? l_ow : -1, log2_ohw = log2_ow >= 0 ? l_ow + l_oh : -1;
   if (out_bf16)
     hipLaunchKernelGGL(im2col_small_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)col, B, H, W, Cin, OH, OW,
-                       KH, KW, stride, pad, K, KP);
+                       KH, KW, stride, pad, K, KP, inv_kq, log2_ow, log2_ohw);
   else
     hipLaunchKernelGGL(im2col_small_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (float*)col, B, H, W, Cin, OH, OW, KH,
-                       KW, stride, pad, K, KP);
+                       KW, stride, pad, K, KP, inv_kq, log2_ow, log2_ohw);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

@@ -583,3 +583,24 @@ def test_lane_to_vector_and_polyline_pool():
         assert torch.equal(out.cpu(), out_ref.detach())
         gy = ops.polyline_pool_bwd(gout.to(DEV), arg, torch.empty(R, V, H, device=DEV), R, V, H, last)
         _close(gy, yr.grad, 1e-6, "polyline bwd")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,k,stride,pad,KP", [(2, 64, 64, 3, 7, 2, 3, 160), (3, 36, 52, 2, 7, 2, 3, 128), (1, 20, 20, 4, 3, 1, 1, 36),
+                                                       (2, 16, 24, 1, 1, 1, 0, 4), (2, 64, 64, 3, 7, 2, 3, 192)])
+@pytest.mark.parametrize("out", ["f32", "bf16"])
+def test_im2col_small_matches_unfold(B, H, W, Cin, k, stride, pad, KP, out):
+    """mmfn_im2col_small (the stems' im2col: tap table in LDS, reciprocal pixel decode, shifts where the output sides are powers of
+    two and divisions where they are not) against F.unfold; columns K .. KP zero-filled."""
+    from mmfn_amd import ops
+    g = _g(B * 7 + H + Cin + k)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    col = torch.full((B * OH * OW, KP), float("nan"), device=DEV, dtype=torch.bfloat16 if out == "bf16" else torch.float32)
+    ops.im2col_small(x.to(DEV), col, k, k, stride, pad)
+    u = F.unfold(x.permute(0, 3, 1, 2), k, padding=pad, stride=stride)            # [B, Cin*k*k, OH*OW], rows ordered (ci, kh, kw)
+    u = u.view(B, Cin, k * k, OH * OW).permute(0, 3, 2, 1).reshape(B * OH * OW, k * k * Cin)   # -> (kh, kw, ci) fastest ci
+    ref = torch.zeros(B * OH * OW, KP)
+    ref[:, :k * k * Cin] = u
+    if out == "bf16":
+        ref = ref.bfloat16().float()
+    assert torch.equal(col.float().cpu(), ref)
