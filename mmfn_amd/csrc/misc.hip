@@ -295,6 +295,54 @@ __global__ __launch_bounds__(256) void im2col_small_kernel(const float* __restri
   }
 }
 
+// The same matrix through LDS: a block takes SEG consecutive output pixels of one output row, copies the KH input rows they read
+// (contiguous runs: coalesced loads, padding zero-filled once) into LDS and writes the SEG x KP tile with consecutive 16-byte (8-byte
+// for bf16) stores - the kernel is then bound by writing the matrix (fp32 335 MB, bf16 201 MB per stem) instead of by gather loads.
+constexpr int IM2COL_SEG = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_rows_kernel(const float* __restrict__ x, T* __restrict__ col, int H, int W, int Cin, int OH,
+                                                          int OW, int KH, int KW, int stride, int pad, int K, int KP, int row_len,
+                                                          int segs_per_row) {
+  extern __shared__ float patch[];          // [KH][row_len]: input columns iw0 .. iw0 + (SEG - 1) * stride + KW - 1, Cin channels each
+  __shared__ int tap_off[256];              // k -> kh * row_len + kw * Cin + ci, or -1 (k >= K: zero column)
+  const int seg = blockIdx.x % segs_per_row, oh = (blockIdx.x / segs_per_row) % OH, b = blockIdx.x / (segs_per_row * OH);
+  const int ow0 = seg * IM2COL_SEG, npix = min(IM2COL_SEG, OW - ow0);
+  const int ih0 = oh * stride - pad, iw0 = ow0 * stride - pad;
+  for (int k = threadIdx.x; k < KP; k += 256) {
+    int off = -1;
+    if (k < K) {
+      const int tap = k / Cin, ci = k - tap * Cin;
+      const int kh = tap / KW, kw = tap - kh * KW;
+      off = kh * row_len + kw * Cin + ci;
+    }
+    tap_off[k] = off;
+  }
+  // rows: one contiguous run of row_len floats each, valid where the input column iw0 + r / Cin lies inside the image
+  const int r_lo = max(0, -iw0) * Cin, r_hi = min(row_len, (W - iw0) * Cin);
+  for (int kh = 0; kh < KH; ++kh) {
+    const int ih = ih0 + kh;
+    const bool row_ok = (unsigned)ih < (unsigned)H;
+    const float* src = x + ((size_t)(b * H + (row_ok ? ih : 0)) * W) * Cin + (ptrdiff_t)iw0 * Cin;
+    for (int r = threadIdx.x; r < row_len; r += 256) patch[kh * row_len + r] = (row_ok && r >= r_lo && r < r_hi) ? src[r] : 0.f;
+  }
+  __syncthreads();
+  // tile: 64 lanes per output pixel (lane q < KP / 4 writes that pixel's k = 4q .. 4q+3), four pixels per pass
+  const int q = threadIdx.x & 63, kq = KP >> 2;
+  T* out = col + ((size_t)(b * OH + oh) * OW + ow0) * KP;
+  if (q < kq) {
+    int off[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) off[e] = tap_off[q * 4 + e];
+    for (int p = threadIdx.x >> 6; p < npix; p += 4) {
+      const float* base = patch + p * stride * Cin;
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = off[e] >= 0 ? base[off[e]] : 0.f;
+      stx4(out + (size_t)p * KP + q * 4, v);
+    }
+  }
+}
+
 // dst[r][0..KP) = src[r][0..K) zero-padded (T out), or - unpad - dst[r][0..K) = src[r][0..K) out of rows of KP
 template <typename TI, typename TO>
 __global__ void repitch_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int R, int K, int ps, int pd) {
@@ -312,6 +360,23 @@ extern "C" int mmfn_im2col_small(const float* x, void* col, int out_bf16, int B,
   const int K = KH * KW * Cin;
   if (!x || !col || KP < K || KP % 4 || Cin <= 0 || Cin > 4) return MMFN_EINVAL;
   const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KW) / stride + 1;
+  {
+    // LDS path: KH input rows of the segment's span fit the patch buffer (every stem does: 7 x 399 floats)
+    const int row_len = ((IM2COL_SEG - 1) * stride + KW) * Cin;
+    const size_t lds = (size_t)KH * row_len * sizeof(float);
+    if (KP <= 256 && lds <= 48 * 1024 && (int64_t)B * OH * ceil_div(OW, IM2COL_SEG) < ((int64_t)1 << 30)) {
+      const int segs = ceil_div(OW, IM2COL_SEG);
+      const dim3 grid((unsigned)(B * OH * segs));
+      if (out_bf16)
+        hipLaunchKernelGGL(im2col_rows_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, x, (bf16_t*)col, H, W, Cin, OH, OW, KH, KW,
+                           stride, pad, K, KP, row_len, segs);
+      else
+        hipLaunchKernelGGL(im2col_rows_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, x, (float*)col, H, W, Cin, OH, OW, KH, KW,
+                           stride, pad, K, KP, row_len, segs);
+      MMFN_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   const int64_t total = (int64_t)B * OH * OW * (KP / 4);
   if (KP > 256 || total >= ((int64_t)1 << 31) || KH >= 32768 || KW >= 32768) return MMFN_EINVAL;   // tap table / 32-bit element index
   const int blocks = (int)std::min<int64_t>((total + 255) / 256, 16384);
