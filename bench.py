@@ -106,25 +106,39 @@ class ImageBranchOnly(object):
         return pooled
 
 
-def also_bf16(args):
-    """The bf16 training mode (BASELINE configs[2] arithmetic, one GPU) measured by the SAME driver run: a second bench process
-    started after the fp32 line's timed region (this process keeps its buffers; 288 GB holds both), same steps / warm-up.
-    Returns the fields of its JSON line that matter, or {"error": ...} - the fp32 line never depends on it."""
+def also_config(args, name):
+    """Another BASELINE configuration measured by the SAME driver run: a second bench process started after the fp32 line's
+    timed region (this process keeps its buffers; 288 GB holds both), same steps / warm-up.  `name` is a PRESETS key: "bf16"
+    (configs[2] per-GPU arithmetic), "img128" (configs[3]), "rad16" (configs[4]).  Returns the fields of its JSON line that
+    matter, or {"error": ...} - the fp32 line never depends on it."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--config", "bf16", "--steps", str(args.steps), "--warmup", str(args.warmup),
+    cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--no-cpu-baseline", "--no-also"]
     try:
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
         line = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
         if out.returncode != 0 or not line:
-            return {"error": "bench.py --config bf16 exited %d: %s" % (out.returncode, out.stderr.decode()[-400:])}
+            return {"error": "bench.py --config %s exited %d: %s" % (name, out.returncode, out.stderr.decode()[-400:])}
         rec = json.loads(line[-1])
     except Exception as exc:   # noqa: BLE001 - whatever happens there, the fp32 line is printed
         return {"error": "%s: %s" % (type(exc).__name__, exc)}
-    keep = ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "loss", "roofline", "loss_vs_oracle")
+    keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "loss", "roofline", "loss_vs_oracle")
     rec = {k: rec[k] for k in keep if k in rec}
-    rec["command"] = "python bench.py --config bf16 --steps %d --warmup %d" % (args.steps, args.warmup)
+    rec["config"] = PRESETS[name][0]
+    rec["command"] = "python bench.py --config %s --steps %d --warmup %d" % (name, args.steps, args.warmup)
     return rec
+
+
+def csrc_digest():
+    """sha256 over the kernel sources (mmfn_amd/csrc/*, sorted by name): what a committed PMC profile is valid for.  The GPU box
+    has no .git, so staleness of profiles/*_traffic.json is judged by this digest (tools/summarize_profile.py stamps it)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mmfn_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def default_like_bf16(args, B):
@@ -318,6 +332,9 @@ def main():
                          "saved tensors and weight shadows in HBM, bf16 MFMA with fp32 accumulation, fp32 statistics / master weights "
                          "/ gradients / optimizer.  bf16-operands = round 2's mode: fp32 tensors in HBM, GEMM operands rounded to "
                          "bf16 on their way into LDS")
+    ap.add_argument("--grad-dtype", default="f32", choices=["f32", "bf16"],
+                    help="data-parallel runs: element type of the gradient buckets on the wire.  f32 (default) is what the reference's DDP "
+                         "exchanges, also under autocast; bf16 is an opt-in (210 instead of 419 MB per step, rounding at every hop)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-oracle-check", action="store_true", help="skip the loss_vs_oracle block (one CPU oracle forward)")
@@ -325,8 +342,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps for the roofline block")
     ap.add_argument("--breakdown", action="store_true", help="print the per-operation table of the roofline block's instrumented steps to stderr")
     ap.add_argument("--no-also", action="store_true",
-                    help="default one-GPU run only: do not append the bf16 training mode's record (`also.bf16`, a second bench process "
-                         "after the fp32 line's timed region)")
+                    help="default one-GPU run only: do not append the other BASELINE configurations' records (`also.bf16`, `also.img128`, "
+                         "`also.rad16`: further bench processes after the fp32 line's timed region)")
     ap.add_argument("--config", default=None, choices=sorted(PRESETS),
                     help="BASELINE.json configuration presets (one flag per config): " + "; ".join("%s = %s" % (k, v[0]) for k, v in sorted(PRESETS.items())))
     args = ap.parse_args()
@@ -391,7 +408,7 @@ def main():
         # step is ONE hipGraph) whenever the library loads and its communicator passes a self-test on every rank; otherwise
         # torch's ProcessGroup with the step cut at the bucket boundaries (mmfn_amd.parallel.connect; MMFN_DP_TRANSPORT)
         from mmfn_amd.parallel import connect
-        dp, transport_note = connect(net, dist)
+        dp, transport_note = connect(net, dist, grad_dtype=args.grad_dtype)
         comm_capi = dp.comm
         dp.broadcast_parameters()
     eng = net._engine_for()
@@ -433,7 +450,7 @@ def main():
         if rank == 0:
             sys.stderr.write("C-ABI RCCL transport dropped (%s); continuing on torch.distributed\n" % why)
         comm_capi, transport_note = None, "fallback: " + why
-        dp = DataParallel(net, dist)
+        dp = DataParallel(net, dist, grad_dtype=args.grad_dtype)
         dp.broadcast_parameters()
 
     # two eager steps size every buffer, then (optionally) capture one step into a hipGraph
@@ -574,7 +591,7 @@ def main():
         eng.multi_stream = not args.single_stream
         n_launch, flops, ms = prof.summary()
         executed = prof.executed_flops()
-        traffic, traffic_src = None, None
+        traffic, traffic_src, traffic_commit, traffic_digest = None, None, None, None
         import glob
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
         default_workload = (not image_only and args.variant == "vec" and B == 32 and args.n_lidar == 16384 and args.dtype == "f32"
@@ -582,6 +599,7 @@ def main():
         if tfiles and default_workload:  # PMC-derived HBM bytes per launch of this kernel family (tools/profile_round.sh)
             rec = json.load(open(tfiles[-1]))
             traffic, traffic_src = round(rec["hbm_bytes_per_launch"]), os.path.basename(tfiles[-1])
+            traffic_commit, traffic_digest = rec.get("commit"), rec.get("csrc_digest")
         if args.breakdown:
             rows = sorted(prof.by_tag().items(), key=lambda kv: -kv[1][2])
             for tag, (n, fl, t) in rows[:60]:
@@ -592,6 +610,9 @@ def main():
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_unit": "HBM bytes/launch",
             "traffic_source": traffic_src,
+            # the profile is a constant from the builder's box: which sources it was taken on, and whether they are still these
+            "traffic_commit": traffic_commit, "traffic_csrc_digest": traffic_digest, "csrc_digest": csrc_digest(),
+            "stale": None if traffic is None else (traffic_digest != csrc_digest()),
             "traffic_note": None if traffic is None else "constant read from the committed rocprofv3 PMC profile (separate --pmc passes on the "
                                                          "builder's box, tools/profile_round.sh), NOT measured during this run",
             "algorithmic_bytes_per_launch": round(prof.algo_bytes() / max(n_launch, 1)),
@@ -602,6 +623,8 @@ def main():
             # what the MFMA units execute: less than the algorithmic count where Winograd replaces the direct convolution
             "executed_gflop_per_step": round(executed / steps_p / 1e9, 1),
             "executed_tflops": round(executed / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0,
+            # frac counts algorithmic FLOPs; frac_executed what the MFMA units really execute (the number MFMA-busy counters track)
+            "frac_executed": round(executed / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ms > 0 else 0.0,
             "kernel_ms_per_step": round(ms / steps_p, 3),
             "whole_step_algorithmic_tflops": round(ALGO_GFLOP_PER_SAMPLE.get("image-only" if image_only else args.variant, 0) * B / ms_per_step, 2),
             "accounting": "achieved / frac count ALGORITHMIC FLOPs (SURVEY 8d: output pixels x taps x Cin x Cout of a convolution) over the "
@@ -658,7 +681,7 @@ def main():
                     "traffic_source": os.path.basename(hb[-1]) if (hb and measured is not None) else None}
                 r["mode"] = dict(dtype_detail="bf16 activations / saved tensors / weight shadows in HBM; fp32 accumulation, BatchNorm and "
                                               "LayerNorm statistics, master weights, gradients, AdamW, loss head, VectorNet and the two 7x7 stems")
-            for k in ("executed_gflop_per_step", "executed_tflops", "algorithmic_bytes_per_launch"):
+            for k in ("executed_gflop_per_step", "executed_tflops", "frac_executed", "algorithmic_bytes_per_launch"):
                 r.pop(k, None)
         if not image_only and args.dtype in ("f32", "bf16") and not args.no_oracle_check:
             result["loss_vs_oracle"] = loss_vs_oracle(net, eng, inp, gt, args.variant)
@@ -669,7 +692,8 @@ def main():
         if not args.no_cpu_baseline and not image_only and args.variant == "vec" and world == 1:   # rank 0 at N=1 only
             result["cpu_baseline"] = cpu_baseline()
         if world == 1 and default_workload and not args.no_also and args.config is None:
-            result["also"] = {"bf16": also_bf16(args)}
+            # BASELINE configs[2] (per-GPU arithmetic), configs[3], configs[4]: driver-timed beside the headline
+            result["also"] = {name: also_config(args, name) for name in ("bf16", "img128", "rad16")}
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()

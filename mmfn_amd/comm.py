@@ -125,42 +125,112 @@ def all_ranks_agree(dist, dev, ok):
     return bool(int(t.item()))
 
 
-def open_transport(rank, world, dist, dev, required=False, timeout_s=120.0):
-    """RCCL communicator through the C ABI + a self-test (sum of rank ids over a 1 MiB bucket on a side stream); every rank
-    must pass, else all of them use torch.distributed.  The init runs in a helper thread so that a communicator that never
-    comes up costs `timeout_s`, not the run.  Returns (RcclComm or None, note); required=True raises MMFNCommError instead of
-    falling back."""
+def _real_communicator(rank, world, unique_id, dev):
+    """ncclCommInitRank through the C ABI + the self-test: sum of (rank + 1) over a 1 MiB bucket on a side stream."""
+    torch.cuda.set_device(dev)
+    c = RcclComm(rank, world, unique_id=unique_id)
+    try:
+        x = torch.full((1 << 18,), float(rank + 1), dtype=torch.float32, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        c.all_reduce_sum_(x, stream=side)
+        side.synchronize()
+        expect = world * (world + 1) / 2.0
+        if float(x.min().item()) != expect or float(x.max().item()) != expect or c.ranks() != (world, rank):
+            raise RuntimeError("self-test all-reduce returned %r..%r, expected %r" % (float(x.min()), float(x.max()), expect))
+    except BaseException:
+        c.destroy()
+        raise
+    return c
+
+
+def _local_rendezvous_id(rank):
+    """This rank's part of the rendezvous that needs no other rank: the library loads, rank 0 creates the 128 id bytes."""
+    L = lib()
+    buf = (ctypes.c_char * ID_BYTES)()
+    if rank == 0:
+        _check(L.mmfn_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), "mmfn_comm_unique_id")
+    return bytes(buf.raw)
+
+
+def open_transport(rank, world, dist, dev, required=False, timeout_s=120.0, make_id=None, make_comm=None):
+    """RCCL communicator through the C ABI + a self-test all-reduce; every rank must pass, else all of them use
+    torch.distributed.  Returns (RcclComm or None, note); required=True raises MMFNCommError instead of falling back.
+
+    Collective-safe by construction - every collective on the launcher's process group `dist` is issued from THIS thread, in
+    the same order on every rank, whatever fails where:
+      1. local readiness (library loads, rank 0 has its id) -> all_ranks_agree; a rank without the library never leaves the
+         others blocked in the id broadcast,
+      2. the id broadcast (only when 1. passed everywhere),
+      3. ncclCommInitRank + self-test in a helper thread that touches RCCL only, never `dist`, bounded by `timeout_s`,
+      4. all_ranks_agree on the outcome.
+    An init that is still running at the time limit (asymmetric failure: one rank's init errors at once, the others wait for it
+    in RCCL's bootstrap) is ABANDONED: this rank votes no, and if the helper ever returns, it destroys its communicator itself.
+
+    make_id(rank) -> 128 bytes and make_comm(rank, world, id, dev) -> communicator (with .destroy()) replace the C-ABI calls in
+    the CPU tests of this protocol."""
     import sys
     import threading
-    box = {}
+    make_id = make_id or _local_rendezvous_id
+    make_comm = make_comm or _real_communicator
 
-    def attempt():
-        try:
-            torch.cuda.set_device(dev)
-            c = RcclComm(rank, world, dist=dist)
-            x = torch.full((1 << 18,), float(rank + 1), dtype=torch.float32, device=dev)
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream())
-            c.all_reduce_sum_(x, stream=side)
-            side.synchronize()
-            expect = world * (world + 1) / 2.0
-            if float(x.min().item()) != expect or float(x.max().item()) != expect or c.ranks() != (world, rank):
-                raise RuntimeError("self-test all-reduce returned %r..%r, expected %r" % (float(x.min()), float(x.max()), expect))
-            box["comm"] = c
-        except BaseException as exc:   # a missing library, an RCCL error code, a wrong sum: all mean "use torch.distributed"
-            box["error"] = "%s: %s" % (type(exc).__name__, exc)
-
-    th = threading.Thread(target=attempt, daemon=True)
-    th.start()
-    th.join(timeout_s)
-    if th.is_alive():
-        box.setdefault("error", "communicator did not come up within %.0f s" % timeout_s)
-    ok = "comm" in box
-    if not all_ranks_agree(dist, dev, ok):
-        why = box.get("error", "another rank failed")
+    def give_up(why):
         if required:
             raise MMFNCommError("C-ABI transport required but unavailable on rank %d: %s" % (rank, why))
         if rank == 0:
             sys.stderr.write("C-ABI RCCL transport not used (%s); falling back to torch.distributed\n" % why)
         return None, "fallback: " + why
-    return box["comm"], None
+
+    # 1. what this rank can establish alone
+    local_err, my_id = None, None
+    try:
+        my_id = make_id(rank)
+        assert len(my_id) == ID_BYTES
+    except BaseException as exc:   # noqa: BLE001 - a missing library, an RCCL error code: all mean "use torch.distributed"
+        local_err = "%s: %s" % (type(exc).__name__, exc)
+    if not all_ranks_agree(dist, dev, local_err is None):
+        return give_up(local_err or "another rank cannot load libmmfn_comm.so / create the rendezvous id")
+    # 2. rank 0's id to everybody (main thread, default group)
+    payload = [my_id]
+    if world > 1:
+        dist.broadcast_object_list(payload, src=0)
+    unique_id = payload[0]
+
+    # 3. communicator + self-test, timed
+    box, lock = {}, threading.Lock()
+
+    def attempt():
+        try:
+            c = make_comm(rank, world, unique_id, dev)
+        except BaseException as exc:   # noqa: BLE001
+            with lock:
+                box["error"] = "%s: %s" % (type(exc).__name__, exc)
+            return
+        with lock:
+            if box.get("abandoned"):   # the time limit passed and this rank already voted no: nobody will use this communicator
+                late = c
+            else:
+                box["comm"], late = c, None
+        if late is not None:
+            try:
+                late.destroy()
+            except BaseException:   # noqa: BLE001
+                pass
+
+    th = threading.Thread(target=attempt, daemon=True, name="mmfn-comm-init")
+    th.start()
+    th.join(timeout_s)
+    with lock:
+        if "comm" not in box and "error" not in box:
+            box["abandoned"] = True
+            box["error"] = "communicator did not come up within %.0f s" % timeout_s
+        handle = box.get("comm")
+    # 4. the verdict
+    if not all_ranks_agree(dist, dev, handle is not None):
+        if handle is not None:   # came up here, not elsewhere
+            try:
+                handle.destroy()
+            except BaseException:   # noqa: BLE001
+                pass
+        return give_up(box.get("error", "another rank failed"))
+    return handle, None

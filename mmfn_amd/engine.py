@@ -732,7 +732,10 @@ class GPT(object):
         # (there the launch at the tail costs more than the side streams gain) - hence by mode.
         fins = [] if (ctx.bf16 and ctx.side is not None and DEFER_LN_REDUCTIONS) else None
         refold = getattr(self, "folded_fwd", False)   # the forward ran ln1 / ln2 inside the QKV / mlp.0 GEMMs (LN_FOLD)
-        scr_mu, scr_rs = bufs.get(nm + ".ln.scratch.mu", (M,)), bufs.get(nm + ".ln.scratch.rs", (M,))
+        # (one scratch pair per closure site and block parity: consecutive blocks' side work alternates between TWO side streams for
+        # C <= SIDE_SPLIT_MAX_C, so a shared pair would be written concurrently)
+        scr = [[(bufs.get("%s.ln.scratch.mu%d%d" % (nm, site, par), (M,)), bufs.get("%s.ln.scratch.rs%d%d" % (nm, site, par), (M,)))
+                for par in range(2)] for site in range(2)] if refold else None
         g = self.ln_f.bwd(ctx, g_y.view(M, C), out=G[nblk - 1], dropped=GD[nblk - 1] if drop else None, drop_p=p_resid,
                           rng_stream=sb_of(nblk - 1) + 2, colsum=self.blocks[nblk - 1]["fc2"].gb, defer=side, collect=fins)
         for i in range(nblk - 1, -1, -1):
@@ -760,7 +763,7 @@ class GPT(object):
                                                                                ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
             elif refold:
                 # the forward folded ln2 into mlp.0's GEMM: the normalised tensor the weight gradient contracts with is made here
-                side.append(lambda gh=gh, blk=blk, a2=a2, x1=x1: (ops.layernorm_fwd(x1, blk["ln2"].w, blk["ln2"].b, a2, scr_mu, scr_rs),
+                side.append(lambda gh=gh, blk=blk, a2=a2, x1=x1, sc=scr[0][i & 1]: (ops.layernorm_fwd(x1, blk["ln2"].w, blk["ln2"].b, a2, sc[0], sc[1]),
                                                                   ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
             else:
                 side.append(lambda gh=gh, blk=blk, a2=a2: (ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
@@ -778,7 +781,7 @@ class GPT(object):
             ops.attention_bwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, go, C, lse, delta, dqkv[:, C:], dqkv, dqkv[:, 2 * C:],
                               3 * C, B, T, nh, hs, scale, drop_p=p_attn, rng_state=ctx.rng_state, rng_stream=sb)
             if refold:
-                side.append(lambda dqkv=dqkv, blk=blk, a=a, x=x: (ops.layernorm_fwd(x, blk["ln1"].w, blk["ln1"].b, a, scr_mu, scr_rs),
+                side.append(lambda dqkv=dqkv, blk=blk, a=a, x=x, sc=scr[1][i & 1]: (ops.layernorm_fwd(x, blk["ln1"].w, blk["ln1"].b, a, sc[0], sc[1]),
                                                                   ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
             else:
                 side.append(lambda dqkv=dqkv, blk=blk, a=a: (ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
@@ -793,7 +796,9 @@ class GPT(object):
         if pending is not None:
             self._offload_side(ctx, pending)
         if fins:
-            key = (id(bufs), len(fins))
+            # keyed by the addresses the table holds (not by id(bufs): a dropped Buffers object's id can be reused, and a
+            # reallocated gradient buffer moves the targets) - a stale table would write through dangling pointers
+            key = tuple(0 if t is None else t.data_ptr() for f in fins for t in f[:4])
             tab = self._fin_tables.get(key)
             if tab is None:
                 if torch.cuda.is_current_stream_capturing():

@@ -18,10 +18,12 @@ import torch
 
 class DataParallel(object):
     def __init__(self, module, dist, max_bucket_bytes=64 << 20, comm=None, grad_dtype=None):
-        """grad_dtype: "f32", or "bf16" = the buckets cross the links as bf16 (the default of the bf16 training mode, BASELINE
-        configs[2]: 210 MB instead of 419 MB per step): each bucket is cast into a bf16 staging range, summed
-        there, and the sum cast back into the fp32 gradient buffer - on the communication stream, behind the event that marks
-        the bucket complete - so AdamW, the master weights and the moments stay fp32.
+        """grad_dtype: "f32" (default in every mode: what the reference's DDP exchanges, also under torch.autocast -
+        phase2_train_net.py:227,265-269) or "bf16" = an explicit opt-in (bench.py --grad-dtype bf16): the buckets cross the
+        links as bf16, 210 MB instead of 419 MB per step: each bucket is cast into a bf16 staging range, summed there (rounding
+        at every hop of the ring), and the sum cast back into the fp32 gradient buffer - on the communication stream, behind the
+        event that marks the bucket complete - so AdamW, the master weights and the moments stay fp32.  Its error against
+        the fp32 exchange is bounded in tests/test_parallel_cpu.py.
 
         dist: torch.distributed (process group already initialised).  comm: optional mmfn_amd.comm.RcclComm - the
         gradient buckets then go through the C ABI (mmfn_allreduce_sum_f32) on a side HIP stream owned by this object
@@ -39,7 +41,7 @@ class DataParallel(object):
         self.world = dist.get_world_size()
         self.layout = module._layout
         if grad_dtype is None:
-            grad_dtype = "bf16" if getattr(getattr(module, "config", None), "act_dtype", "f32") == "bf16" else "f32"
+            grad_dtype = "f32"
         if grad_dtype not in ("f32", "bf16"):
             raise ValueError("grad_dtype must be f32 or bf16, got %r" % (grad_dtype,))
         self.grad_dtype = grad_dtype
@@ -213,13 +215,15 @@ class DataParallel(object):
         return sum(ms) / len(ms)
 
 
-def connect(module, dist, transport=None, max_bucket_bytes=64 << 20, grad_dtype=None):
+def connect(module, dist, transport=None, max_bucket_bytes=64 << 20, grad_dtype=None, transport_opts=None):
     """DataParallel on the best transport that comes up on EVERY rank - what trainer.fit / bench.py --gpus N use.
 
     transport: "auto" (default; or the MMFN_DP_TRANSPORT environment variable): the C-ABI RCCL communicator (mmfn_amd.comm) when
     the library loads, the communicator initialises and a self-test all-reduce returns the right sum on every rank - the step
     is then ONE hipGraph with the collectives captured inside (GraphedStep) - otherwise torch.distributed (the step cut at the
-    bucket boundaries); "capi": the C ABI or an error; "torch": torch.distributed.  Returns (DataParallel, note or None)."""
+    bucket boundaries); "capi": the C ABI or an error; "torch": torch.distributed.  Returns (DataParallel, note or None).
+    transport_opts: keyword arguments for comm.open_transport (timeout_s; make_id / make_comm stand-ins in the CPU tests of the
+    fallback protocol, which also lift the "device must be a GPU" condition)."""
     import os
     from . import comm as C
     want = transport or os.environ.get("MMFN_DP_TRANSPORT", "auto")
@@ -227,11 +231,12 @@ def connect(module, dist, transport=None, max_bucket_bytes=64 << 20, grad_dtype=
         raise ValueError("transport must be auto / capi / torch, got %r" % (want,))
     dev = module._layout.device
     handle, note = None, None
-    if want != "torch" and dist.get_world_size() >= 1 and dev.type == "cuda":
+    opts = dict(transport_opts or {})
+    if want != "torch" and dist.get_world_size() >= 1 and (dev.type == "cuda" or "make_comm" in opts):
         if want == "auto" and os.environ.get("MMFN_BENCH_SINGLE_DEVICE"):
             note = "single-device CI run: RCCL refuses two ranks on one GPU, torch.distributed (gloo) instead"
         else:
-            handle, note = C.open_transport(dist.get_rank(), dist.get_world_size(), dist, dev, required=(want == "capi"))
+            handle, note = C.open_transport(dist.get_rank(), dist.get_world_size(), dist, dev, required=(want == "capi"), **opts)
     return DataParallel(module, dist, max_bucket_bytes=max_bucket_bytes, comm=handle, grad_dtype=grad_dtype), note
 
 

@@ -214,7 +214,7 @@ class Trainer(object):
         if not all(os.path.isfile(os.path.join(logdir, n)) for n in names):
             # no validation set / no improvement yet: save() never wrote the best_* pair - continue from the recent one
             names = ("model.pth", "recent_optim.pth")
-        stale = [n for n in names if n in table.get("files", {}) and table["files"][n] != _stamp(os.path.join(logdir, n))]
+        stale = [n for n in names if n in table.get("files", {}) and not _same_save(table["files"][n], _stamp(os.path.join(logdir, n)))]
         if stale:
             import warnings
             warnings.warn("checkpoint file(s) %s differ in size or content from what recent.log recorded (a save interrupted between "
@@ -248,6 +248,14 @@ def _stamp(path):
             f.seek(size - (1 << 20))
             h.update(f.read(1 << 20))
     return [size, h.hexdigest()]
+
+
+def _same_save(logged, now):
+    """A recent.log written before the stamps became content hashes holds [size, mtime_ns]: compare the size only for those
+    (an int second element), so healthy older log directories resume without a spurious "files from different saves" warning."""
+    if len(logged) == 2 and isinstance(logged[1], int):
+        return logged[0] == now[0]
+    return list(logged) == list(now)
 
 
 def _atomic_save(obj, path):

@@ -166,3 +166,13 @@ def test_comm_library_exports_every_declared_symbol():
     assert handle.mmfn_comm_abi_version() == 1
     assert handle.mmfn_allreduce_sum_f32(None, None, 0, None) == -1     # argument checking happens before any RCCL call
     assert handle.mmfn_allreduce_sum_bf16(None, None, 0, None) == -1
+
+
+def test_checkpoint_stamps_written_before_the_content_hash_still_compare_equal():
+    """ADVICE r4 (trainer.py:239): a recent.log from before the stamps became [size, sha256] holds [size, mtime_ns]; such a
+    healthy directory must not look like an interrupted save."""
+    from mmfn_amd.trainer import _same_save
+    assert _same_save([1234, 1727500000000000000], [1234, "ab" * 32])          # legacy stamp: size decides
+    assert not _same_save([1234, 1727500000000000000], [1235, "ab" * 32])
+    assert _same_save([1234, "ab" * 32], [1234, "ab" * 32])
+    assert not _same_save([1234, "ab" * 32], [1234, "cd" * 32])                # same size, other content

@@ -165,9 +165,10 @@ def test_bf16_gradient_buckets_through_the_c_abi_and_inside_one_graph():
     torch.manual_seed(5)
     net = MMFN(GlobalConfig(act_dtype="bf16"), dev)
     net.train()
-    dp = DataParallel(net, _OneRank, comm=comm, max_bucket_bytes=16 << 20)
+    assert DataParallel(net, _OneRank, max_bucket_bytes=16 << 20).grad_dtype == "f32"   # the default in every mode: what the reference's DDP exchanges
+    dp = DataParallel(net, _OneRank, comm=comm, max_bucket_bytes=16 << 20, grad_dtype="bf16")   # the opt-in
     eng, L = net._engine_for(), net._layout
-    assert dp.grad_dtype == "bf16" and dp.bytes_per_step() == 2 * L.tail and dp.n_buckets() >= 17   # the mode's default
+    assert dp.grad_dtype == "bf16" and dp.bytes_per_step() == 2 * L.tail and dp.n_buckets() >= 17
     init = {k: v.detach().clone() for k, v in net.state_dict().items()}
     rng0, step0 = eng.rng_state.clone(), eng.step_count.clone()
 

@@ -68,6 +68,8 @@ print("\n".join(lines))
 
 # 3. HBM traffic of the dominant (GEMM) kernel family, per launch, for bench.py's roofline.traffic
 import json
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import csrc_digest  # noqa: E402
 fetch = glob.glob(os.path.join(out, "pmc_fetch*counter_collection.csv"))
 write = glob.glob(os.path.join(out, "pmc_write*counter_collection.csv"))
 if fetch and write:
@@ -94,6 +96,9 @@ if fetch and write:
         "fetch_bytes_per_launch_corrected": 2.0 * f * 1024.0 / max(nf, 1),
         "write_bytes_per_launch": w * 1024.0 / max(nw, 1),
         "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0 / max(nf, 1),
+        # which kernel sources the profile is valid for (bench.py marks the constant `stale` when its own digest differs); the
+        # commit is stamped by tools/stamp_profiles.py when the file is copied into profiles/ (the GPU box has no .git)
+        "csrc_digest": csrc_digest(), "commit": os.environ.get("MMFN_COMMIT"),
         "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
                   "`bench.py --no-graph --steps 1 --warmup 0 --profile-steps 1`; counters are KiB; FETCH_SIZE doubled per "
                   "MI355X_MICROARCH.md (gfx950 reports half the bytes of 16-B/lane streaming reads); WRITE_SIZE matches "
