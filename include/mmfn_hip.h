@@ -142,7 +142,8 @@ typedef struct mmfn_gemm_desc {
   int32_t H, W, Cin, OH, OW, Cout, KH, KW, stride, pad;
   int32_t flags;
   int32_t splitk;       /* 0 auto, 1 none, >1 forced number of k slices                   */
-  int32_t tile;         /* 0 auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128          */
+  int32_t tile;         /* 0 auto, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128 (2x2 waves of 32x32 MFMA tiles); on request only:
+                         * 5 = 192x64, 6 = 64x192 (wave tile 96x32 / 32x96), 7 = 64x64 as two waves of 32x64 */
   uint32_t rng_stream;  /* distinguishes dropout sites                                    */
   float drop_p;
   /* batched GEMM (radar GAT, model_rad.py:816-824): problem z uses A + z*strideA, ... (floats);

@@ -395,6 +395,22 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d_in,
 // Eligibility is checked on the host (fast_ok); everything else runs the generic kernel above.
 __device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
 
+// MMFN_GEMM_TIMELINE (experiment builds only, tools/experiments/gemm64_timeline.sh): every wave of the first g_tl_blocks blocks
+// stamps s_memtime at its start, after the prologue's loads are issued, after each k-tile's barrier (operands of that tile
+// landed everywhere), after the k-loop and after its last store - the per-k-tile issue timeline the thread trace would give,
+// where no trace decoder is installed.  Slots: 0 start, 1 HW_ID, 2 prologue issued, 3 + kt tile kt ready (kt < 36), 40 loop
+// done, 41 stores issued, 42 XCC_ID, 43 s_memrealtime at start, 44 at end.
+#ifdef MMFN_GEMM_TIMELINE
+constexpr int TL_SLOTS = 48;
+__device__ unsigned long long* g_tl_buf = nullptr;
+__device__ int g_tl_blocks = 0;
+#define TL_MARK(slot) do { if (tl && lane == 0) tl[(slot)] = __builtin_readcyclecounter(); } while (0)
+#define TL_END() do { MMFN_WAIT_VMCNT(0); if (tl && lane == 0) { tl[41] = __builtin_readcyclecounter(); tl[44] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define TL_MARK(slot) do { } while (0)
+#define TL_END() do { } while (0)
+#endif
+
 #ifdef MMFN_GEMM_NO_GLDS
 constexpr bool USE_GLDS = false;  // register-staged fallback (A/B experiment switch)
 #else
@@ -423,8 +439,12 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
 // floats of LDS to the lanes that hold that row's accumulators, and the interior-tile epilogue starts from
 // rstd * (acc - mean * c1[n]) + c2[n] instead of acc + bias[n].
 // (amdgpu_waves_per_eu: the LNF 128x128 instantiation took 192 registers = two blocks per CU; held to three like the plain form)
-template <int AM, int BMODE, int BM, int BN, bool LNF = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(LNF && BM == 128 && BN == 128 ? 3 : 1)))
+// WM_ x WN_: the block's waves as a grid over the tile; each wave owns (BM / WM_) x (BN / WN_) outputs as TM x TN MFMA tiles of
+// 32 x 32.  2 x 2 waves everywhere but: 192 x 64 / 64 x 192 (wave tile 96 x 32 / 32 x 96: the M = 6144 transformer GEMMs divide
+// into exactly 256 / 768 / 1024 blocks - whole rounds of the 256 CUs - where 128 x 128 leaves 192 or 576), and the two-wave
+// 64 x 64 block (wave tile 32 x 64: three fragment reads per eight MFMAs instead of four).
+template <int AM, int BMODE, int BM, int BN, bool LNF = false, int WM_ = 2, int WN_ = 2>
+__global__ __launch_bounds__(64 * WM_ * WN_) __attribute__((amdgpu_waves_per_eu(LNF && BM == 128 && BN == 128 ? 3 : 1)))
 void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, const int tiles_n,
                                                            const int log2_ow, const int log2_ohw) {
   // Batched launches (the 36 frequency GEMMs of a Winograd convolution): a batch entry's tiles all on ONE XCD.  With the plain order
@@ -470,11 +490,14 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
   }
   constexpr bool A_KC = (AM != MMFN_A_COLMAJOR);
   constexpr bool B_KC = (BMODE == MMFN_B_NK);
-  constexpr int WAVES_N = 2;
-  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int WAVES_N = WN_;
+  constexpr int NTH = 64 * WM_ * WN_;
+  constexpr int TM = BM / (32 * WM_), TN = BN / (32 * WN_);
+  static_assert(TM * 32 * WM_ == BM && TN * 32 * WN_ == BN, "tile must divide into 32 x 32 MFMA tiles per wave");
+  static_assert((BM * BK / 4) % NTH == 0 && (BN * BK / 4) % NTH == 0, "whole 16-byte staging units per thread");
   constexpr int LDK = BK;
   constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK;
-  constexpr int UA = BM * BK / 4 / NT, UB = BN * BK / 4 / NT;
+  constexpr int UA = BM * BK / 4 / NTH, UB = BN * BK / 4 / NTH;
   // LDS stages of the operand pipeline (global_load_lds path).  NS >= 3: tiles kt+1 .. kt+NS-2 are in flight while tile kt is
   // multiplied, retired with COUNTED vmcnt waits, one raw s_barrier per k-tile - the step's GEMMs are a few hundred 64x64
   // tiles each (1-3 blocks per CU) with 36-288 k-tiles, so it is the depth of each block's operand stream, not occupancy,
@@ -488,6 +511,23 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+#ifdef MMFN_GEMM_TIMELINE
+  unsigned long long* tl = nullptr;
+  {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (g_tl_buf && (int)lin < g_tl_blocks) {
+      tl = g_tl_buf + ((size_t)lin * (NTH / 64) + wave) * TL_SLOTS;
+      if (lane == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tl[0] = __builtin_readcyclecounter();
+        tl[1] = hwid; tl[42] = xcc;
+        tl[43] = __builtin_amdgcn_s_memrealtime();
+      }
+    }
+  }
+#endif
 #ifdef MMFN_GEMM_NO_XCD_SWIZZLE
   const int bid = blockIdx.x;
 #else
@@ -513,7 +553,7 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
   int ay0[UA], ax0[UA];
 #pragma unroll
   for (int i = 0; i < UA; ++i) {
-    const int u = tid + i * NT;
+    const int u = tid + i * NTH;
     ay0[i] = ax0[i] = 0;
     if (AM == MMFN_A_ROWMAJOR) {
       pa[i] = d.A + (size_t)min(m0 + u / KQ, d.M - 1) * d.lda + SRCQ(u) * 4;
@@ -553,7 +593,7 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
   int bkh[UB], bkw[UB];
 #pragma unroll
   for (int i = 0; i < UB; ++i) {
-    const int u = tid + i * NT;
+    const int u = tid + i * NTH;
     bkh[i] = bkw[i] = 0;
     if (BMODE == MMFN_B_NK) {
       pb[i] = d.B + (size_t)min(n0 + u / KQ, d.N - 1) * d.ldb + SRCQ(u) * 4;
@@ -607,7 +647,7 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
     if (BMODE == MMFN_B_KN) return pb[i] + (size_t)kt * BK * d.ldb;
     if (BMODE == MMFN_B_DGRADW)
       return pb[i] + ((size_t)t_c0 * KHW + (dgp ? (kh0 + 2 * t_kh) * d.KW + (kw0 + 2 * t_kw) : t_kh * d.KW + t_kw)) * d.Cin;
-    const int kk = kt * BK + (tid + i * NT) / (BN / 4);
+    const int kk = kt * BK + (tid + i * NTH) / (BN / 4);
     const int b = kk >> log2_ohw, rem = kk & ((1 << log2_ohw) - 1);
     const int oh = rem >> log2_ow, ow = rem & ((1 << log2_ow) - 1);
     const int ih = oh * d.stride - d.pad + bkh[i], iw = ow * d.stride - d.pad + bkw[i];
@@ -615,13 +655,13 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
     return ok ? pb[i] + ((size_t)(b * d.H + ih) * d.W + iw) * d.Cin : zero;
   };
   auto store_a = [&](float* As, int i, f32x4 v) {
-    const int u = tid + i * NT;
+    const int u = tid + i * NTH;
     if (USE_GLDS) *reinterpret_cast<f32x4*>(&As[u * 4]) = v;
     else if (A_KC) *reinterpret_cast<f32x4*>(&As[(u / KQ) * LDK + kc_slot(u / KQ, u % KQ) * 4]) = v;
     else *reinterpret_cast<f32x4*>(&As[(u / (BM / 4)) * BM + (u % (BM / 4)) * 4]) = v;
   };
   auto store_b = [&](float* Bs, int i, f32x4 v) {
-    const int u = tid + i * NT;
+    const int u = tid + i * NTH;
     if (USE_GLDS) *reinterpret_cast<f32x4*>(&Bs[u * 4]) = v;
     else if (B_KC) *reinterpret_cast<f32x4*>(&Bs[(u / KQ) * LDK + kc_slot(u / KQ, u % KQ) * 4]) = v;
     else *reinterpret_cast<f32x4*>(&Bs[(u / (BN / 4)) * BN + (u % (BN / 4)) * 4]) = v;
@@ -648,9 +688,9 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
   auto stage_issue = [&](int kt, float* dst) {
     if (USE_GLDS) {
 #pragma unroll
-      for (int i = 0; i < UA; ++i) glds16(src_a(i, kt), dst + (i * NT + wave * 64) * 4);
+      for (int i = 0; i < UA; ++i) glds16(src_a(i, kt), dst + (i * NTH + wave * 64) * 4);
 #pragma unroll
-      for (int i = 0; i < UB; ++i) glds16(src_b(i, kt), dst + A_ELEMS + (i * NT + wave * 64) * 4);
+      for (int i = 0; i < UB; ++i) glds16(src_b(i, kt), dst + A_ELEMS + (i * NTH + wave * 64) * 4);
     } else {
 #pragma unroll
       for (int i = 0; i < UA; ++i) ra[i] = ld4(src_a(i, kt));
@@ -680,6 +720,7 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
     __syncthreads();
   }
 
+  TL_MARK(2);
   int cur = 0, nxt = D;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const bool more = (kt + 1 < kt_end);
@@ -691,6 +732,9 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
       else if (D > 1 && ahead == 1) MMFN_WAIT_VMCNT(UA + UB);
       else MMFN_WAIT_VMCNT(0);
       __builtin_amdgcn_s_barrier();                 // ... and everybody else's
+#ifdef MMFN_GEMM_TIMELINE
+      if (kt - kt_begin < 36) TL_MARK(3 + kt - kt_begin);
+#endif
     } else if (more) {
       stage_issue(kt + 1, smem + (cur ^ 1) * STG);
     }
@@ -750,6 +794,7 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
     }
   }
 
+  TL_MARK(40);
   __shared__ float ln_stat[LNF ? 2 * BM : 1];
   if (LNF) {
 #pragma unroll
@@ -772,12 +817,12 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
   const bool to_slab = d.splitk > 1;
   float* slab = to_slab ? d.workspace + ((size_t)by * max(1, d_in.batch) + (d_in.batch > 1 ? bz : 0)) * d.M * d.N : nullptr;
+  constexpr int EPI_OPS = MMFN_EPI_BIAS | MMFN_EPI_RELU | MMFN_EPI_GELU | MMFN_EPI_MASK_AUX | MMFN_EPI_DROPOUT | MMFN_EPI_RESIDUAL |
+                          MMFN_EPI_ACCUM | MMFN_EPI_RELU_LAST;
   // Plain stores of an interior tile (no epilogue operation, or a split slab): one pointer per lane and 16 * TM * TN stores at
   // compile-time row multiples of the leading dimension.  The general loop below tests the tile edge and eight epilogue flags per
   // ELEMENT; tools/experiments/gemm32_pmc.sh counts ~730 non-MFMA instructions per wave around a tile's k-loop, most of them there -
   // more than the k-loop itself issues for the K = 64 ... 256 Winograd-domain GEMMs that are two thirds of the step's launches.
-  constexpr int EPI_OPS = MMFN_EPI_BIAS | MMFN_EPI_RELU | MMFN_EPI_GELU | MMFN_EPI_MASK_AUX | MMFN_EPI_DROPOUT | MMFN_EPI_RESIDUAL |
-                          MMFN_EPI_ACCUM | MMFN_EPI_RELU_LAST;
   if (!dgp && m0 + BM <= d.M && n0 + BN <= d.N && (to_slab || !(d.flags & EPI_OPS))) {
     const int ld = to_slab ? d.N : d.ldc;
     float* p0 = (to_slab ? slab : d.C) + (size_t)(m0 + wm * TM * 32 + 4 * h) * ld + n0 + wn * TN * 32 + l31;
@@ -787,6 +832,7 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
       for (int q = 0; q < TN; ++q)
 #pragma unroll
         for (int r = 0; r < 16; ++r) p0[(size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * ld + q * 32] = acc[i][q][r];
+    TL_END();
     return;
   }
   // Interior tile with the common epilogue operations (bias, ReLU, ReLU-backward mask, dropout, residual, final ReLU): the same
@@ -828,6 +874,7 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
           p0[(size_t)dr * d.ldc + q * 32] = v;
         }
       }
+    TL_END();
     return;
   }
 #pragma unroll
@@ -849,6 +896,7 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
         else epilogue_store(d, key, row, col, acc[i][q][r]);
       }
     }
+  TL_END();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1190,9 +1238,16 @@ void launch_splitk_reduce(const mmfn_gemm_desc& dd_in, hipStream_t s) {
 }
 
 struct TileCand { int id, bm, bn; float eff; int target; };
-// id: 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128.  eff = measured relative MFMA efficiency of the
-// tile shape; target = resident blocks that saturate the chip (256 CUs x blocks/CU that fit).
-const TileCand kTiles[4] = {{1, 128, 128, 1.00f, 512}, {3, 128, 64, 1.00f, 512}, {4, 64, 128, 1.00f, 512}, {2, 64, 64, 0.98f, 768}};
+// id: 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128 (2x2 waves each); 5 = 192x64, 6 = 64x192 (2x2 waves, wave tile 96x32 /
+// 32x96), 7 = 64x64 as two waves of 32x64.  eff = measured relative MFMA efficiency of the tile shape; target = resident blocks
+// that saturate the chip (256 CUs x blocks/CU that fit).  5-7 are only taken on request (mmfn_gemm_desc.tile, i.e. from the
+// measured table tuning/gfx950.json), never by the time model below.
+const TileCand kTiles[7] = {{1, 128, 128, 1.00f, 512}, {3, 128, 64, 1.00f, 512}, {4, 64, 128, 1.00f, 512}, {2, 64, 64, 0.98f, 768},
+                            {5, 192, 64, 1.00f, 512}, {6, 64, 192, 1.00f, 512}, {7, 64, 64, 0.98f, 1536}};
+constexpr int kMaxTile = 7;
+// X(id, BM, BN, waves along M, waves along N)
+#define MMFN_F32_TILES(X) X(1, 128, 128, 2, 2) X(3, 128, 64, 2, 2) X(4, 64, 128, 2, 2) X(5, 192, 64, 2, 2) X(6, 64, 192, 2, 2) \
+  X(7, 64, 64, 2, 1) X(2, 64, 64, 2, 2)
 
 int ilog2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;
@@ -1221,7 +1276,12 @@ bool fast_ok(const mmfn_gemm_desc& d) {
   return true;
 }
 
-constexpr int dyn_lds_bytes() { return 0; }   // (round-2 experiment: extra dynamic LDS per block to cap the blocks per CU)
+// experiment knob: extra dynamic LDS per block caps the blocks per CU (MMFN_GEMM_DYN_LDS, bytes; read once)
+int dyn_lds_bytes() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MMFN_GEMM_DYN_LDS"); v = e ? atoi(e) : 0; }
+  return v;
+}
 
 template <int AM, int BMODE>
 int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
@@ -1236,6 +1296,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
       // four output-parity classes in one launch (grid.z), no split-K: each class already has M/4 rows
       dd.dg_parity = 1;
       dd.splitk = 1;
+      if (tile > 4) tile = 2;   // (the parity form is instantiated for the four 2x2-wave tiles)
       const int mloc = d.M / 4;
       const int bm = (tile == 1 || tile == 3) ? 128 : 64, bn = (tile == 1 || tile == 4) ? 128 : 64;
       const int tn = ceil_div(d.N, bn);
@@ -1249,6 +1310,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
     }
     if (d.flags & MMFN_EPI_LN_FOLD) {
       if (AM != MMFN_A_ROWMAJOR || BMODE != MMFN_B_NK) return MMFN_EINVAL;
+      if (tile > 4) tile = 2;
       int bm = (tile == 1 || tile == 3) ? 128 : 64, bn = (tile == 1 || tile == 4) ? 128 : 64;
       if (d.M % bm || d.N % bn) { tile = 2; bm = bn = 64; }   // the epilogue of this form only exists for interior tiles
       if (d.M % bm || d.N % bn || d.batch > 1) return MMFN_EINVAL;
@@ -1266,16 +1328,17 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
     }
     const int l_ow = (BMODE == MMFN_B_IM2COL) ? ilog2_exact(d.OW) : 0;
     const int l_ohw = (BMODE == MMFN_B_IM2COL) ? ilog2_exact(d.OH * d.OW) : 0;
-#define MMFN_LAUNCH_FAST(BM_, BN_)                                                                                   \
-  {                                                                                                                  \
+#define MMFN_LAUNCH_FAST(ID_, BM_, BN_, WM_, WN_)                                                                     \
+  if (tile == ID_ && !launched) {                                                                                    \
+    launched = true;                                                                                                 \
     const int tn = ceil_div(d.N, BN_);                                                                               \
     dim3 grid(ceil_div(d.M, BM_) * tn, zdim, d.batch > 1 ? d.batch : 1);                                             \
-    hipLaunchKernelGGL((gemm_f32_fast_kernel<AM, BMODE, BM_, BN_>), grid, dim3(NT), dyn_lds_bytes(), s, dd, kps, tn, l_ow, l_ohw); \
+    hipLaunchKernelGGL((gemm_f32_fast_kernel<AM, BMODE, BM_, BN_, false, WM_, WN_>), grid, dim3(64 * WM_ * WN_), dyn_lds_bytes(), s, \
+                       dd, kps, tn, l_ow, l_ohw);                                                                    \
   }
-    if (tile == 1) MMFN_LAUNCH_FAST(128, 128)
-    else if (tile == 3) MMFN_LAUNCH_FAST(128, 64)
-    else if (tile == 4) MMFN_LAUNCH_FAST(64, 128)
-    else MMFN_LAUNCH_FAST(64, 64)
+    bool launched = false;
+    if (tile < 1 || tile > kMaxTile) tile = 2;
+    MMFN_F32_TILES(MMFN_LAUNCH_FAST)
 #undef MMFN_LAUNCH_FAST
     MMFN_LAUNCH_CHECK();
     if (zdim > 1) {
@@ -1286,6 +1349,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
   }
 #endif
   if (d.flags & MMFN_EPI_LN_FOLD) return MMFN_EINVAL;   // (needs the fast kernel: 16-byte aligned operands, K a multiple of 16)
+  if (tile > 4) tile = 2;
 #define MMFN_LAUNCH_TILE(BM_, BN_)                                                                              \
   {                                                                                                             \
     const int tn = ceil_div(d.N, BN_);                                                                          \
@@ -1410,9 +1474,10 @@ void pick_config(const mmfn_gemm_desc& d, int* tile, int* splitk) {
   const bool can_split = d.workspace != nullptr && d.splitk != 1 && (d.batch <= 1 || batch_can_split(d));
   int best = -1, best_sk = 1;
   double best_t = 0.0;
-  for (int i = 0; i < 4; ++i) {
+  const bool asked = d.tile >= 1 && d.tile <= kMaxTile;
+  for (int i = 0; i < kMaxTile; ++i) {
     const TileCand& c = kTiles[i];
-    if (d.tile >= 1 && d.tile <= 4 && d.tile != c.id) continue;
+    if (asked ? d.tile != c.id : c.id > 4) continue;
     const int64_t tm = ceil_div(d.M, c.bm), tn = ceil_div(d.N, c.bn);
     const int64_t blocks = tm * tn * std::max(1, d.batch);
     // outputs of only a handful of tiles (first-layer weight gradients, K = B*H*W ~ 1e5..1e6) may split deeper
@@ -1433,6 +1498,16 @@ void pick_config(const mmfn_gemm_desc& d, int* tile, int* splitk) {
 }
 
 }  // namespace
+
+#ifdef MMFN_GEMM_TIMELINE
+// experiment builds only: buf = device memory for blocks * waves * 48 uint64 (zeroed by the caller)
+extern "C" int mmfn_debug_gemm_timeline(void* buf, int blocks) {
+  unsigned long long* p = (unsigned long long*)buf;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_tl_buf), &p, sizeof(p)) != hipSuccess) return 1;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_tl_blocks), &blocks, sizeof(blocks)) != hipSuccess) return 1;
+  return 0;
+}
+#endif
 
 extern "C" int64_t mmfn_gemm_workspace_bytes(const mmfn_gemm_desc* d) {
   if (!d) return 0;

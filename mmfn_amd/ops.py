@@ -157,6 +157,9 @@ AUTOTUNE = os.environ.get("MMFN_AUTOTUNE", "0") == "1"
 F32X3 = os.environ.get("MMFN_F32X3", "0") == "1"  # let fp32 GEMMs use the bf16x3 emulation kernel where the table says so
 USE_TABLE = os.environ.get("MMFN_TUNING_TABLE", "1") != "0"
 _SK_GRID = (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96)
+# mmfn_gemm_desc.tile -> (rows, columns) of the fp32 kernel's block tile (include/mmfn_hip.h); 7 = 64 x 64 as two waves of 32 x 64
+TILE_DIMS = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128), 5: (192, 64), 6: (64, 192), 7: (64, 64)}
+TILE_IDS = tuple(int(t) for t in os.environ.get("MMFN_TUNE_TILES", "1,2,3,4,5,6,7").split(","))
 
 
 def _tune_key(a_mode, b_mode, M, N, K, batch, conv):
@@ -230,8 +233,8 @@ def _autotune(d, C, key, reps=3):
             d.flags = (saved[1] & ~EPI_ACCUM) | mode
             emu = bool(d.flags & (EPI_BF16_OPERANDS | EPI_BF16X3))
             kt = max(1, K // (32 if emu else 16))
-            for tile in ((1, 2) if emu else (1, 2, 3, 4)):
-                bm, bn = {1: (128, 128), 2: (64, 64), 3: (128, 64), 4: (64, 128)}[tile]
+            for tile in ((1, 2) if emu else TILE_IDS):
+                bm, bn = TILE_DIMS[tile]
                 blocks = -(-M // bm) * -(-N // bn)
                 for sk in _SK_GRID:
                     if sk > 1 and (not batch_split or sk > kt // 4):

@@ -21,7 +21,7 @@ def _close(got, ref, tol=2e-4):
 
 @pytest.mark.parametrize("M,N,K", [(64, 64, 16), (128, 128, 64), (100, 70, 36), (6144, 192, 64),
                                    (333, 257, 129), (32, 256, 512), (2048, 512, 4608), (37, 64, 7), (8, 3, 1)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_linear_forms(M, N, K, tile):
     from mmfn_amd import ops
     dev = _dev()
@@ -137,7 +137,7 @@ CONVS = [  # B, H, W, Cin, Cout, k, stride, pad
 
 
 @pytest.mark.parametrize("cfg", CONVS)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_conv_forms(cfg, tile):
     from mmfn_amd import ops
     dev = _dev()

@@ -16,11 +16,11 @@ def timeit(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 
-for (T, C) in ((2048, 128), (512, 256), (128, 512)):
+for (T, C) in ((8192, 64), (2048, 128), (512, 256), (128, 512)):
     V = torch.randn(36, T, C, device=dev); U = torch.randn(36, C, C, device=dev); M = torch.empty(36, T, C, device=dev)
     dU = torch.empty(36, C, C, device=dev)
     fl = 2.0 * 36 * T * C * C
-    for tile in (1, 2, 3, 4):
+    for tile in (1, 2, 3, 4, 7):
         for sk in ((1,) if T > 128 else (1, 2, 4)):
             try:
                 us = timeit(lambda: ops.gemm(V, U, M, T, C, C, C, C, C, ops.A_ROWMAJOR, ops.B_NK, batch=36, strideA=T * C, strideB=C * C, strideC=T * C, tile=tile, splitk=sk))
