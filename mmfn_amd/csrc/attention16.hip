@@ -81,30 +81,6 @@ __device__ __forceinline__ bf16x8 trfrag(const unsigned char* m, int col0, int k
   return out;
 }
 
-__device__ __forceinline__ uint32_t hash32(uint32_t x) {   // lowbias32
-  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-  return x;
-}
-struct Drop {
-  uint32_t salt, thresh;
-  float inv_keep;
-  bool on;
-  __device__ __forceinline__ void init(const AttnArgs& a, int b, int hd) {
-    on = a.drop_p > 0.f;
-    salt = 0; thresh = 0; inv_keep = 1.f;
-    if (on) {
-      const uint64_t k = mmfn_rng_key(a.rng_state, a.rng_stream) + (uint64_t)(b * a.NH + hd) * 0x9E3779B97F4A7C15ull;
-      salt = hash32((uint32_t)k ^ hash32((uint32_t)(k >> 32)));
-      thresh = (uint32_t)fminf(a.drop_p * 4294967296.0f, 4294967040.0f);
-      inv_keep = 1.0f / (1.0f - a.drop_p);
-    }
-  }
-  // keep-scale of element (query, key): 0 or 1 / (1 - p)
-  __device__ __forceinline__ float scale(int query, int key, int T) const {
-    return hash32((uint32_t)(query * T + key) ^ salt) >= thresh ? inv_keep : 0.f;
-  }
-};
-
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s) {
   bf16x8 o;
 #pragma unroll

@@ -353,10 +353,9 @@ __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
   }
   __syncthreads();   // statistics visible; K / Q no longer read
   stV.commit(sm, tid);
-  const bool drop = a.drop_p > 0.f;
-  uint64_t key64 = 0;
-  float inv_keep = 1.f;
-  if (drop) { key64 = mmfn_rng_key(a.rng_state, a.rng_stream); inv_keep = 1.0f / (1.0f - a.drop_p); }
+  Drop dr;
+  dr.init(a, b, hd);
+  const bool drop = dr.on;
 #pragma unroll
   for (int y = 0; y < NT; ++y) {
     const int qi = 16 * y + l15;
@@ -371,13 +370,12 @@ __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
     const int q = q0 + qi;
     if (ks == 0 && l4 == 0 && a.lse) a.lse[((size_t)b * a.NH + hd) * T + q] = m + logf(l);
     const float fac = mmfn_exp(mx[y] - m) / l;
-    const uint64_t pbase = (((uint64_t)b * a.NH + hd) * T + q) * (uint64_t)T;
 #pragma unroll
     for (int x = 0; x < NT; ++x)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float p = s[x][y][r] * fac;
-        if (drop) p *= mmfn_dropout_scale(key64, pbase + (uint64_t)(k0 + 16 * x + 4 * l4 + r), a.drop_p, inv_keep);
+        if (drop) p *= dr.scale(q, k0 + 16 * x + 4 * l4 + r, T);
         s[x][y][r] = p;
       }
   }
@@ -449,15 +447,13 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
       [&]() { stK.issue(io_k + rowbase * ld + hd * HS, ld, tid); });
   __syncthreads();
   stK.commit(sA, tid);
-  const bool drop = a.drop_p > 0.f;
-  uint64_t key64 = 0;
-  float inv_keep = 1.f;
-  if (drop) { key64 = mmfn_rng_key(a.rng_state, a.rng_stream); inv_keep = 1.0f / (1.0f - a.drop_p); }
+  Drop dr;
+  dr.init(a, b, hd);
+  const bool drop = dr.on;
 #pragma unroll
   for (int y = 0; y < NT; ++y) {
     const int q = q0 + 16 * y + l15;
     const float lse = lse_y[y];
-    const uint64_t pbase = (statbase + q) * (uint64_t)T;
     float dl = 0.f, ps = 0.f;
 #pragma unroll
     for (int x = 0; x < NT; ++x)
@@ -467,7 +463,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
         const float ex = mmfn_exp((nokeys ? 0.f : acc[0][x][y][r] * a.scale) - lse);
         const float p = (nokeys || key < kvlen) ? ex : 0.f;
         float dpv = acc[1][x][y][r];
-        if (drop) dpv *= mmfn_dropout_scale(key64, pbase + (uint64_t)key, a.drop_p, inv_keep);
+        if (drop) dpv *= dr.scale(q, key, T);
         acc[0][x][y][r] = p;
         acc[1][x][y][r] = dpv;
         dl += p * dpv;
@@ -557,10 +553,9 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
       },
       [&](int i, int col0) { product_phase<HS, NT, Groups<HS>::COLS>(sA + q0 * P, sB + kg * G * P, col0, l15, l4, acc[i]); },
       [&]() {});
-  const bool drop = a.drop_p > 0.f;
-  uint64_t key64 = 0;
-  float inv_keep = 1.f;
-  if (drop) { key64 = mmfn_rng_key(a.rng_state, a.rng_stream); inv_keep = 1.0f / (1.0f - a.drop_p); }
+  Drop dr;
+  dr.init(a, b, hd);
+  const bool drop = dr.on;
 #pragma unroll
   for (int x = 0; x < NT; ++x)
 #pragma unroll
@@ -575,7 +570,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
         const float ex = mmfn_exp((nokeys ? 0.f : acc[0][x][y][r] * a.scale) - lse);
         const float p = kin ? ex : 0.f;
         float msc = 1.f;
-        if (drop) msc = mmfn_dropout_scale(key64, (statbase + q) * (uint64_t)T + (uint64_t)key, a.drop_p, inv_keep);
+        if (drop) msc = dr.scale(q, key, T);
         acc[0][x][y][r] = p * msc;                                                           // dV = (P o mask)^T dO
         acc[1][x][y][r] = nokeys ? 0.f : p * (acc[1][x][y][r] * msc - dlt) * a.scale;         // dK = dS^T Q
       }
@@ -601,7 +596,15 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
   merge_store<HS, NT, TIO>(g, sm, kg, qs, lane, l15, l4, io_dk + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
 }
 
+#ifdef MMFN_ATTN_STAMPS   // experiment builds (tools/experiments/attn_phases.sh): phase time stamps of the forward kernel
+__device__ long long g_attn_dbg[32];
+long long* debug_buffer() {
+  void* p = nullptr;
+  return hipGetSymbolAddress(&p, HIP_SYMBOL(g_attn_dbg)) == hipSuccess ? (long long*)p : nullptr;
+}
+#else
 long long* debug_buffer() { return nullptr; }   // (phase time stamps of the forward kernel: a development build option, off)
+#endif
 
 template <int HS, int NT, typename TIO>
 int launch_io(int which, const AttnArgs& a_in, hipStream_t s) {

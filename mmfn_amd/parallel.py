@@ -218,15 +218,17 @@ class DataParallel(object):
 def connect(module, dist, transport=None, max_bucket_bytes=64 << 20, grad_dtype=None, transport_opts=None):
     """DataParallel on the best transport that comes up on EVERY rank - what trainer.fit / bench.py --gpus N use.
 
-    transport: "auto" (default; or the MMFN_DP_TRANSPORT environment variable): the C-ABI RCCL communicator (mmfn_amd.comm) when
-    the library loads, the communicator initialises and a self-test all-reduce returns the right sum on every rank - the step
-    is then ONE hipGraph with the collectives captured inside (GraphedStep) - otherwise torch.distributed (the step cut at the
-    bucket boundaries); "capi": the C ABI or an error; "torch": torch.distributed.  Returns (DataParallel, note or None).
+    transport (or the MMFN_DP_TRANSPORT environment variable): "torch" (default): torch.distributed (backend "nccl" = RCCL), the step
+    cut at the bucket boundaries - the conservative choice for a first run on real multi-GPU hardware: RCCL has never seen more than
+    one rank under the C-ABI transport, and a collective captured into a hipGraph that deadlocks on replay cannot be recovered from
+    inside the process; "auto": the C-ABI RCCL communicator (mmfn_amd.comm) when the library loads, the communicator initialises and a
+    self-test all-reduce returns the right sum on every rank - the step is then ONE hipGraph with the collectives captured inside
+    (GraphedStep) - otherwise torch.distributed; "capi": the C ABI or an error.  Returns (DataParallel, note or None).
     transport_opts: keyword arguments for comm.open_transport (timeout_s; make_id / make_comm stand-ins in the CPU tests of the
     fallback protocol, which also lift the "device must be a GPU" condition)."""
     import os
     from . import comm as C
-    want = transport or os.environ.get("MMFN_DP_TRANSPORT", "auto")
+    want = transport or os.environ.get("MMFN_DP_TRANSPORT", "torch")
     if want not in ("auto", "capi", "torch"):
         raise ValueError("transport must be auto / capi / torch, got %r" % (want,))
     dev = module._layout.device
