@@ -21,15 +21,9 @@ struct AttnArgs {
 
 // Dropout of the attention probabilities (attn_pdrop) in attention_wg.hip and attention16.hip: the keep mask of element (b, h, query,
 // key) is a 32-bit hash (lowbias32) of query * T + key, salted per (rng state, stream, b, h) - the same function in the three
-// kernels of a family.  The engine's 64-bit splitmix counter RNG (common.h, used by every other dropout site and by the tile
-// kernels of attention.hip) costs ~25 integer instructions per element, a dozen of them quarter-rate multiplies: with 36-96
-// probabilities per lane the mask alone was 9-10 k of the forward kernel's 26-70 k cycles at every head size
-// (tools/experiments/attn_phases.py); two 32-bit multiplies are enough for a dropout mask.
+// kernels of a family, with the salt, the threshold compare on the raw 32 bits and 1 / (1 - p) hoisted into a struct (the same
+// mixer as common.h's mmfn_rng_u32, which every other dropout site and the tile kernels of attention.hip use per flat index).
 #ifdef __HIPCC__
-__device__ __forceinline__ uint32_t hash32(uint32_t x) {   // lowbias32
-  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-  return x;
-}
 struct Drop {
   uint32_t salt, thresh;
   float inv_keep;
@@ -39,14 +33,14 @@ struct Drop {
     salt = 0; thresh = 0; inv_keep = 1.f;
     if (on) {
       const uint64_t k = mmfn_rng_key(a.rng_state, a.rng_stream) + (uint64_t)(b * a.NH + hd) * 0x9E3779B97F4A7C15ull;
-      salt = hash32((uint32_t)k ^ hash32((uint32_t)(k >> 32)));
+      salt = mmfn_rng_salt(k);
       thresh = (uint32_t)fminf(a.drop_p * 4294967296.0f, 4294967040.0f);
       inv_keep = 1.0f / (1.0f - a.drop_p);
     }
   }
   // keep-scale of element (query, key): 0 or 1 / (1 - p)
   __device__ __forceinline__ float scale(int query, int key, int T) const {
-    return hash32((uint32_t)(query * T + key) ^ salt) >= thresh ? inv_keep : 0.f;
+    return mmfn_hash32((uint32_t)(query * T + key) ^ salt) >= thresh ? inv_keep : 0.f;
   }
 };
 #endif

@@ -83,14 +83,19 @@ __device__ __forceinline__ float mmfn_bn_affine(float x, float alpha, float beta
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Counter-based RNG (splitmix64 finaliser).  One 32-bit draw per (seed, step, stream, index);
-// the backward pass regenerates the same mask instead of storing it.
+// Counter-based RNG: one 32-bit draw per (seed, step, stream, index); the backward pass regenerates the same mask instead of
+// storing it.  The draw is a 32-bit mixer (lowbias32: two 32-bit multiplies) of the index, salted with a hash of the 64-bit
+// (seed, step, stream) key - the salt is uniform over a launch, so it costs scalar instructions once.  Rounds 1-4 ran the 64-bit
+// splitmix finaliser per element (three 64-bit multiplies = a dozen quarter-rate v_mul_lo/hi_u32 + ~15 more instructions): with
+// 36-96 elements per lane that was 9-10 k cycles of every attention kernel and the longest part of a dropout epilogue.
+__device__ __forceinline__ uint32_t mmfn_hash32(uint32_t x) {   // lowbias32
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t mmfn_rng_salt(uint64_t key) { return mmfn_hash32((uint32_t)key ^ mmfn_hash32((uint32_t)(key >> 32))); }
 __device__ __forceinline__ uint32_t mmfn_rng_u32(uint64_t key, uint64_t idx) {
-  uint64_t z = key + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (uint32_t)(z >> 32);
+  // (the high index word only matters for tensors of more than 2^32 elements; it is folded in rather than ignored)
+  return mmfn_hash32(((uint32_t)idx ^ mmfn_rng_salt(key)) + (uint32_t)(idx >> 32) * 0x9E3779B1u);
 }
 __device__ __forceinline__ uint64_t mmfn_rng_key(const uint64_t* state, uint32_t stream) {
   // state[0] = seed, state[1] = step counter

@@ -604,3 +604,32 @@ def test_im2col_small_matches_unfold(B, H, W, Cin, k, stride, pad, KP, out):
     if out == "bf16":
         ref = ref.bfloat16().float()
     assert torch.equal(col.float().cpu(), ref)
+
+
+def test_counter_rng_masks_are_bernoulli_and_independent():
+    """The dropout mask is a 32-bit mixer of (flat index ^ salt(seed, step, stream)) (csrc/common.h): keep rate 1 - p to sampling
+    error, no structure along rows / columns, and masks of different streams, steps and seeds agree only as often as independent
+    Bernoulli draws do (p^2 + (1 - p)^2) - a salt that failed to separate them would show as agreement 1."""
+    from mmfn_amd import ops
+    n, p = 1 << 22, 0.1
+    ones = torch.ones(n, device=DEV)
+
+    def mask(seed, step, stream):
+        st = torch.tensor([seed, step], dtype=torch.int64, device=DEV)
+        return ops.dropout_apply(ones, torch.empty_like(ones), p, st, stream) > 0
+
+    m = mask(42, 7, 3)
+    sd = math.sqrt(p * (1 - p) / n)
+    assert abs(float(m.float().mean()) - (1 - p)) < 5 * sd
+    assert torch.equal(m, mask(42, 7, 3))                                   # a pure function of (seed, step, stream, index)
+    # rows / columns of a [2048, 2048] view: every row and column mean within 6 sigma of 1 - p, neighbours uncorrelated
+    g = m.view(2048, 2048).float()
+    sd_row = math.sqrt(p * (1 - p) / 2048)
+    assert float((g.mean(0) - (1 - p)).abs().max()) < 6 * sd_row and float((g.mean(1) - (1 - p)).abs().max()) < 6 * sd_row
+    for a, b in ((g[:, 1:], g[:, :-1]), (g[1:], g[:-1])):
+        corr = float(((a - (1 - p)) * (b - (1 - p))).mean()) / (p * (1 - p))
+        assert abs(corr) < 5 / math.sqrt(a.numel()), corr
+    indep = p * p + (1 - p) * (1 - p)
+    for other in (mask(42, 7, 4), mask(42, 8, 3), mask(43, 7, 3), mask(42, 7, 3 + (1 << 20))):
+        agree = float((m == other).float().mean())
+        assert abs(agree - indep) < 6 * math.sqrt(indep * (1 - indep) / n), agree
