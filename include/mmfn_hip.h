@@ -122,6 +122,7 @@ enum {
   MMFN_EPI_BF16X3 = 256    /* fp32 arithmetic on the bf16 MFMA pipe (plain GEMM forms): each operand element split exactly
                               into three bf16 terms, six cross products accumulated in fp32: product error < 2^-22 relative */,
   MMFN_EPI_LN_FOLD = 4096, /* see mmfn_gemm_desc.ln_c1 */
+  MMFN_EPI_COLSUM_A = 8192, /* see mmfn_gemm_desc.colsum */
   MMFN_EPI_RELU_LAST = 512 /* max(v, 0) as the LAST step, after residual / accumulate: conv + folded BatchNorm + skip + ReLU in one
                               launch (eval mode, mmfn_bn_fold_f32) */
 };
@@ -164,6 +165,12 @@ typedef struct mmfn_gemm_desc {
   float* ln_rstd;
   float ln_eps;
   int32_t reserved0;
+  /* MMFN_EPI_COLSUM_A (TN form A_COLMAJOR x B_KN, single problem, 16-byte aligned operands, K a multiple of 16): colsum[m] =
+   * sum_k A[k, m], the column sums of the A operand, from the fragments the kernel feeds its MFMAs anyway.  For a Linear's weight
+   * gradient dW = dY^T X that is the BIAS gradient (aten sum(dY, 0) beside addmm's backward, model_vec.py:82-89,121-123) without
+   * the two column-sum launches.  With split-K the per-slice sums go to the tail of the workspace (mmfn_gemm_workspace_bytes
+   * accounts for it) and the combine launch adds them in slice order. */
+  float* colsum;
 } mmfn_gemm_desc;
 
 /* ---- bf16 training mode (BASELINE configs[2]): GEMM / implicit-GEMM convolution with bf16 operands in HBM ------------- */

@@ -16,6 +16,7 @@ B_NK, B_KN, B_IM2COL, B_DGRADW = 0, 1, 2, 3
 EPI_BIAS, EPI_RELU, EPI_GELU, EPI_MASK_AUX, EPI_DROPOUT, EPI_RESIDUAL, EPI_ACCUM, EPI_BF16_OPERANDS, EPI_BF16X3 = 1, 2, 4, 8, 16, 32, 64, 128, 256
 EPI_RELU_LAST = 512
 EPI_LN_FOLD = 4096
+EPI_COLSUM_A = 8192
 
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32
@@ -36,6 +37,7 @@ class GemmDesc(ctypes.Structure):
         ("rng_stream", ctypes.c_uint32), ("drop_p", _f32),
         ("batch", _i32), ("dg_parity", _i32), ("strideA", _i64), ("strideB", _i64), ("strideC", _i64),
         ("ln_c1", _vp), ("ln_mean", _vp), ("ln_rstd", _vp), ("ln_eps", _f32), ("reserved0", _i32),
+        ("colsum", _vp),
     ]
 
 

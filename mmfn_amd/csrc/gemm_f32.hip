@@ -682,6 +682,11 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
   double ln_s1[TM], ln_s2[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) { ln_s1[i] = 0.0; ln_s2[i] = 0.0; }
+  // MMFN_EPI_COLSUM_A: this lane's partial column sums of A (rows wm*TM*32 + i*32 + l31, its half of every k-chunk): a k-tile's
+  // eight values in fp32, the running sum over the k-tiles in fp64 (thousands of sequential fp32 additions would cost 2e-6 relative)
+  double csa[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) csa[i] = 0.0;
   // stage(kt, dst): global -> LDS for one k-tile.  With USE_GLDS the 16-byte pieces go straight to LDS
   // (global_load_lds: wave-uniform LDS base + lane*16, so the image is lane-linear and the slot swizzle
   // is applied to the SOURCE address); otherwise through registers (issue now, ds_write after the MFMAs).
@@ -740,9 +745,9 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
     }
     const float* As = smem + cur * STG;
     const float* Bs = As + A_ELEMS;
-    float ln_p1[TM], ln_p2[TM];
+    float ln_p1[TM], ln_p2[TM], cs_p[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) { ln_p1[i] = 0.f; ln_p2[i] = 0.f; }
+    for (int i = 0; i < TM; ++i) { ln_p1[i] = 0.f; ln_p2[i] = 0.f; cs_p[i] = 0.f; }
 #pragma unroll
     for (int c = 0; c < BK / 8; ++c) {
       float a[TM][4], b[TN][4];
@@ -760,6 +765,7 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
 #pragma unroll
           for (int j = 0; j < 4; ++j) { ln_p1[i] += a[i][j]; ln_p2[i] = fmaf(a[i][j], a[i][j], ln_p2[i]); }
         }
+        if (AM == MMFN_A_COLMAJOR) cs_p[i] += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
@@ -783,6 +789,10 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
     if (LNF) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) { ln_s1[i] += (double)ln_p1[i]; ln_s2[i] += (double)ln_p2[i]; }
+    }
+    if (AM == MMFN_A_COLMAJOR) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) csa[i] += (double)cs_p[i];
     }
     if (NS > 2) {
       cur = cur + 1 == NS ? 0 : cur + 1;
@@ -817,6 +827,18 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
   const bool to_slab = d.splitk > 1;
   float* slab = to_slab ? d.workspace + ((size_t)by * max(1, d_in.batch) + (d_in.batch > 1 ? bz : 0)) * d.M * d.N : nullptr;
+  if (AM == MMFN_A_COLMAJOR && (d.flags & MMFN_EPI_COLSUM_A) && wn == 0 && n0 == 0) {
+    // the two lane halves saw complementary k's of the same rows; one block column (n0 == 0) of every row tile and k-slice writes:
+    // without split-K straight into colsum, else into its slice's row of the partials behind the slabs (combined in slice order by
+    // the split-K combine launch)
+    float* dst = to_slab ? d.workspace + (size_t)d.splitk * d.M * d.N + (size_t)by * d.M : d.colsum;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float v = (float)(csa[i] + __shfl_xor(csa[i], 32, 64));
+      const int row = m0 + wm * TM * 32 + i * 32 + l31;
+      if (h == 0 && row < d.M) dst[row] = v;
+    }
+  }
   constexpr int EPI_OPS = MMFN_EPI_BIAS | MMFN_EPI_RELU | MMFN_EPI_GELU | MMFN_EPI_MASK_AUX | MMFN_EPI_DROPOUT | MMFN_EPI_RESIDUAL |
                           MMFN_EPI_ACCUM | MMFN_EPI_RELU_LAST;
   // Plain stores of an interior tile (no epilogue operation, or a split slab): one pointer per lane and 16 * TM * TN stores at
@@ -1122,6 +1144,17 @@ __global__ __launch_bounds__(NT) void gemm_bf16_kernel(const mmfn_gemm_desc d_in
 
 // Deterministic split-K combine: slabs [splitk][M][N] -> epilogue(C).  One thread per 4 consecutive
 // columns (16-byte loads), 4 independent partial sums so the slab loads pipeline.
+// MMFN_EPI_COLSUM_A with split-K: colsum[m] = sum over the slices (in slice order) of the partial rows behind the slabs
+__device__ __forceinline__ void combine_colsum(const mmfn_gemm_desc& d) {
+  if (!(d.flags & MMFN_EPI_COLSUM_A)) return;
+  const float* part = d.workspace + (size_t)d.splitk * d.M * d.N;
+  for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < d.M; m += gridDim.x * blockDim.x) {
+    float v = 0.f;
+    for (int z = 0; z < d.splitk; ++z) v += part[(size_t)z * d.M + m];
+    d.colsum[m] = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const mmfn_gemm_desc d_in) {
   // batch > 1 here: outputs of the batch entries are NOT packed (strideC != M*N, e.g. the same weight of eight transformer
   // blocks in the flat gradient buffer): blockIdx.y is the batch entry, slabs are [split][batch][M][N]
@@ -1133,6 +1166,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const mmfn_gemm_desc
     d.workspace += (size_t)blockIdx.y * per;
   }
   const size_t total4 = per >> 2;
+  if (d_in.batch <= 1 && blockIdx.y == 0) combine_colsum(d);
   uint64_t key = 0;
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
   const bool vec = (d.N & 3) == 0;
@@ -1172,6 +1206,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const mmfn_gemm_desc
 // (The flat kernel above walks all slabs serially per thread: 600 us for the 2-channel LiDAR stem.)
 __global__ __launch_bounds__(1024) void splitk_reduce_deep_kernel(const mmfn_gemm_desc d) {
   __shared__ float part[16][64];
+  combine_colsum(d);
   const size_t total = (size_t)d.M * d.N;
   const int e = threadIdx.x & 63, zc = threadIdx.x >> 6;
   const size_t idx = (size_t)blockIdx.x * 64 + e;
@@ -1517,7 +1552,8 @@ extern "C" int64_t mmfn_gemm_workspace_bytes(const mmfn_gemm_desc* d) {
   int tile, sk;
   if (bf16_ok(dd)) bf16_config(dd, &tile, &sk);
   else pick_config(dd, &tile, &sk);
-  return sk > 1 ? (int64_t)sk * std::max(1, d->batch) * d->M * d->N * (int64_t)sizeof(float) : 0;
+  const int64_t cs = (d->flags & MMFN_EPI_COLSUM_A) ? (int64_t)d->M : 0;   // one partial row per k-slice behind the slabs
+  return sk > 1 ? (int64_t)sk * (std::max(1, d->batch) * (int64_t)d->M * d->N + cs) * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int mmfn_gemm_f32(const mmfn_gemm_desc* dp, void* stream) {
@@ -1531,6 +1567,11 @@ extern "C" int mmfn_gemm_f32(const mmfn_gemm_desc* dp, void* stream) {
   if (d.flags & MMFN_EPI_LN_FOLD) {
     if (!(d.flags & MMFN_EPI_BIAS) || !d.ln_c1 || (d.flags & (MMFN_EPI_BF16_OPERANDS | MMFN_EPI_BF16X3 | MMFN_EPI_GELU | MMFN_EPI_ACCUM)) ||
         d.a_mode != MMFN_A_ROWMAJOR || d.b_mode != MMFN_B_NK || (d.ln_mean && !d.ln_rstd) || d.ln_eps <= 0.f)
+      return MMFN_EINVAL;
+  }
+  if (d.flags & MMFN_EPI_COLSUM_A) {   // only the fast TN kernel forms the sums
+    if (!d.colsum || d.a_mode != MMFN_A_COLMAJOR || d.b_mode != MMFN_B_KN || d.batch > 1 || !fast_ok(d) ||
+        (d.flags & (MMFN_EPI_BF16_OPERANDS | MMFN_EPI_BF16X3)))
       return MMFN_EINVAL;
   }
   hipStream_t s = (hipStream_t)stream;

@@ -579,6 +579,15 @@ LN_FOLD = os.environ.get("MMFN_LN_FOLD", "eval")
 SIDE_SPLIT_MAX_C = 256
 
 
+def _dw_db(dy, x, gw, gb):
+    """A Linear's weight AND bias gradient: one GEMM in fp32 (the bias gradient = the column sums of dy, formed from the operand
+    fragments of dW = dy^T x: MMFN_EPI_COLSUM_A), column sums + GEMM in the bf16 mode."""
+    if dy.dtype == torch.bfloat16:
+        ops.colsum(dy, gb)
+        return ops.linear_dw(dy, x, out=gw)
+    return ops.linear_dw(dy, x, out=gw, db=gb)
+
+
 class GPT(object):
     """model_vec.py:136-246 (GPT), :112-133 (Block), :73-109 (SelfAttention)."""
 
@@ -764,9 +773,9 @@ class GPT(object):
             elif refold:
                 # the forward folded ln2 into mlp.0's GEMM: the normalised tensor the weight gradient contracts with is made here
                 side.append(lambda gh=gh, blk=blk, a2=a2, x1=x1, sc=scr[0][i & 1]: (ops.layernorm_fwd(x1, blk["ln2"].w, blk["ln2"].b, a2, sc[0], sc[1]),
-                                                                  ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
+                                                                  _dw_db(gh, a2, blk["fc1"].gw, blk["fc1"].gb)))
             else:
-                side.append(lambda gh=gh, blk=blk, a2=a2: (ops.colsum(gh, blk["fc1"].gb), ops.linear_dw(gh, a2, out=blk["fc1"].gw)))
+                side.append(lambda gh=gh, blk=blk, a2=a2: (_dw_db(gh, a2, blk["fc1"].gw, blk["fc1"].gb)))
             ga2 = bufs.get(nm + ".ga", (M, C), adt)
             ops.linear_dx(gh, Wb(blk["fc1"]), out=ga2)
             g1 = blk["ln2"].bwd(ctx, ga2, dres=g, out=G1[i], dropped=GD2[i] if drop else None, drop_p=p_resid,
@@ -782,9 +791,9 @@ class GPT(object):
                               3 * C, B, T, nh, hs, scale, drop_p=p_attn, rng_state=ctx.rng_state, rng_stream=sb)
             if refold:
                 side.append(lambda dqkv=dqkv, blk=blk, a=a, x=x, sc=scr[1][i & 1]: (ops.layernorm_fwd(x, blk["ln1"].w, blk["ln1"].b, a, sc[0], sc[1]),
-                                                                  ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
+                                                                  _dw_db(dqkv, a, blk["g_wqkv"], blk["g_bqkv"])))
             else:
-                side.append(lambda dqkv=dqkv, blk=blk, a=a: (ops.colsum(dqkv, blk["g_bqkv"]), ops.linear_dw(dqkv, a, out=blk["g_wqkv"])))
+                side.append(lambda dqkv=dqkv, blk=blk, a=a: (_dw_db(dqkv, a, blk["g_wqkv"], blk["g_bqkv"])))
             ga = bufs.get(nm + ".ga2", (M, C), adt)
             ops.linear_dx(dqkv, blk["wqkv16t"] if ctx.bf16 else blk["wqkv"], out=ga)
             g = blk["ln1"].bwd(ctx, ga, dres=g1, out=G[i - 1] if i > 0 else bufs.get(nm + ".g_tok", (M, C), sdt),

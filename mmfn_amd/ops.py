@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import (A_COLMAJOR, A_DGRAD, A_IM2COL, A_ROWMAJOR, B_DGRADW, B_IM2COL, B_KN, B_NK,
-                   EPI_ACCUM, EPI_BF16_OPERANDS, EPI_BF16X3, EPI_BIAS, EPI_DROPOUT, EPI_GELU, EPI_LN_FOLD, EPI_MASK_AUX, EPI_RELU, EPI_RELU_LAST,
+                   EPI_ACCUM, EPI_BF16_OPERANDS, EPI_BF16X3, EPI_BIAS, EPI_COLSUM_A, EPI_DROPOUT, EPI_GELU, EPI_LN_FOLD, EPI_MASK_AUX, EPI_RELU, EPI_RELU_LAST,
                    EPI_RESIDUAL,
                    GemmDesc, check, lib, ptr, stream)
 
@@ -276,8 +276,10 @@ def _f32c(t, name):
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=None, res=None, ldr=0,
          aux=None, ldaux=0, relu=False, gelu=False, accum=False, relu_last=False, drop_p=0.0, rng_state=None, rng_stream=0,
-         conv=None, splitk=0, tile=0, batch=1, strideA=0, strideB=0, strideC=0, ln_fold=None):
-    """ln_fold = (c1 [N], mean [M] or None, rstd [M] or None, eps): C = LayerNorm(A) . B^T + bias with B / bias the folded operands
+         conv=None, splitk=0, tile=0, batch=1, strideA=0, strideB=0, strideC=0, ln_fold=None, colsum=None):
+    """colsum ([M] fp32, TN form): also the column sums of the A operand (MMFN_EPI_COLSUM_A: a Linear's bias gradient from its
+    weight-gradient GEMM).
+    ln_fold = (c1 [N], mean [M] or None, rstd [M] or None, eps): C = LayerNorm(A) . B^T + bias with B / bias the folded operands
     of ln_fold_weights (MMFN_EPI_LN_FOLD, include/mmfn_hip.h); mean / rstd receive the row statistics."""
     d = GemmDesc()
     d.batch, d.strideA, d.strideB, d.strideC = batch, strideA, strideB, strideC
@@ -320,6 +322,10 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=N
         (a_mode, b_mode) == (A_IM2COL, B_NK) or (BF16_WGRAD and (a_mode, b_mode) == (A_COLMAJOR, B_IM2COL)))))
     if bf16:
         flags |= EPI_BF16X3 if _gemm_dtype == "f32x3" else EPI_BF16_OPERANDS
+    if colsum is not None:
+        assert (a_mode, b_mode) == (A_COLMAJOR, B_KN) and batch <= 1 and not bf16
+        flags |= EPI_COLSUM_A
+        d.colsum = ptr(colsum)
     d.flags = flags
     d.splitk = splitk
     d.tile = tile
@@ -394,16 +400,27 @@ def linear_dx(dy, w, out=None, **epi):
     return gemm(dy, w, out, M, K, N, dy.stride(0), w.stride(0), out.stride(0), A_ROWMAJOR, B_KN, **epi)
 
 
-def linear_dw(dy, x, out=None, **epi):
-    """dw[N,K] = dy[M,N]^T @ x[M,K]."""
+FUSE_COLSUM = os.environ.get("MMFN_FUSE_COLSUM", "1") != "0"   # bias gradients from the weight-gradient GEMM (MMFN_EPI_COLSUM_A)
+
+
+def linear_dw(dy, x, out=None, db=None, **epi):
+    """dw[N,K] = dy[M,N]^T @ x[M,K];  db ([N], optional) = the column sums of dy = the bias gradient: formed inside the same GEMM
+    where the fast TN kernel runs (fp32, 16-byte aligned operands, M a multiple of 16, N and K multiples of 4), else by colsum()."""
     if dy.dtype == BF16:
         from . import ops16
+        assert db is None
         return ops16.linear_dw(dy, x, out, **epi)
     M, N = dy.shape
     K = x.shape[1]
     if out is None:
         out = torch.empty(N, K, dtype=torch.float32, device=dy.device)
-    return gemm(dy, x, out, N, K, M, dy.stride(0), x.stride(0), out.stride(0), A_COLMAJOR, B_KN, **epi)
+    if db is not None:
+        fusable = (FUSE_COLSUM and _gemm_dtype == "f32" and M % 16 == 0 and N % 4 == 0 and K % 4 == 0 and N >= 4 and K >= 4
+                   and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+        if not fusable:
+            colsum(dy, db)
+            db = None
+    return gemm(dy, x, out, N, K, M, dy.stride(0), x.stride(0), out.stride(0), A_COLMAJOR, B_KN, colsum=db, **epi)
 
 
 # ---------------------------------------------------------------- Convolution (NHWC)

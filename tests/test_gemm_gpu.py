@@ -421,3 +421,25 @@ def test_batched_gemm_split_k():
         ops.gemm(dM.to(dev), V.to(dev), out, 128, 64, 512, 128, 64, 64, ops.A_COLMAJOR, ops.B_KN, batch=36,
                  strideA=512 * 128, strideB=512 * 64, strideC=128 * 64, tile=2, splitk=sk)
         assert (out.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item(), sk
+
+
+@pytest.mark.parametrize("M,N,K", [(6144, 192, 64), (6144, 2048, 512), (6144, 64, 64), (2048, 384, 128), (256, 100, 36), (250, 64, 64)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 5, 7])
+@pytest.mark.parametrize("splitk", [0, 1, 3])
+def test_bias_gradient_from_the_weight_gradient_gemm(M, N, K, tile, splitk):
+    """MMFN_EPI_COLSUM_A: linear_dw(dy, x, db=...) returns dW = dy^T x AND db = sum over rows of dy from ONE launch (+ the split-K
+    combine) where the fast TN kernel runs, and through colsum() elsewhere (M not a multiple of 16): both against fp64, the
+    weight gradient bit-identical to the launch without the flag."""
+    from mmfn_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    dy = torch.randn(M, N, generator=g)
+    x = torch.randn(M, K, generator=g)
+    dyd, xd = dy.to(dev), x.to(dev)
+    db = torch.full((N,), float("nan"), device=dev)
+    dw = ops.linear_dw(dyd, xd, db=db, tile=tile, splitk=splitk)
+    _close(dw, dy.double().t() @ x.double())
+    ref = dy.double().sum(0)
+    err = (db.cpu().double() - ref).abs().max().item()
+    assert err <= 1e-5 * (dy.abs().double().sum(0).max().item() + 1e-6), err
+    assert torch.equal(dw, ops.linear_dw(dyd, xd, tile=tile, splitk=splitk))
