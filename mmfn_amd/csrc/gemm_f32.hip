@@ -1311,12 +1311,16 @@ bool fast_ok(const mmfn_gemm_desc& d) {
   return true;
 }
 
-// experiment knob: extra dynamic LDS per block caps the blocks per CU (MMFN_GEMM_DYN_LDS, bytes; read once)
+// experiment builds (-DMMFN_GEMM_EXPERIMENTS, tools/experiments/cap_sweep.py): extra dynamic LDS per block caps the blocks per CU
+#ifdef MMFN_GEMM_EXPERIMENTS
 int dyn_lds_bytes() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("MMFN_GEMM_DYN_LDS"); v = e ? atoi(e) : 0; }
   return v;
 }
+#else
+constexpr int dyn_lds_bytes() { return 0; }
+#endif
 
 template <int AM, int BMODE>
 int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {

@@ -1,4 +1,6 @@
-"""Blocks per CU capped by extra dynamic LDS (MMFN_GEMM_DYN_LDS): the big transformer GEMMs with 128x128 / 128x64 / 64x64 tiles."""
+"""Blocks per CU capped by extra dynamic LDS (MMFN_GEMM_DYN_LDS): the big transformer GEMMs with 128x128 / 128x64 / 64x64 tiles.
+Needs a build of gemm_f32.hip with -DMMFN_GEMM_EXPERIMENTS (MMFN_EXTRA_FLAGS=-DMMFN_GEMM_EXPERIMENTS python -m mmfn_amd.build --force
+into a scratch copy, or MMFN_HIP_LIB); result of round 5: profiles/r05_gemm_cap_sweep.txt (slower at every cap)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
