@@ -74,7 +74,13 @@ def _worker(rank, world, port, out):
         dp16.on_stage(stage)
     dp16.finish()
     want = sum((vals * (r + 1) + 0.001953125 * r).bfloat16().float() for r in range(world)).bfloat16().float()
-    ok_sum16 = torch.equal(L.grads[:L.tail], want[:L.tail]) and torch.equal(L.grads[L.tail:], tail_before) \
+    if world == 2:   # one addition: exactly bf16(a + b)
+        ok16 = torch.equal(L.grads[:L.tail], want[:L.tail])
+    else:            # more ranks: the ring rounds to bf16 at every hop, in an order that is the backend's - bounded, not bit-defined
+        mag = sum((vals * (r + 1) + 0.001953125 * r).abs() for r in range(world))
+        exact = sum((vals * (r + 1) + 0.001953125 * r).double() for r in range(world))
+        ok16 = bool(((L.grads[:L.tail].double() - exact[:L.tail]).abs() <= world * 2.0 ** -8 * mag[:L.tail].double() + 1e-30).all())   # one rounding per addend + one per hop
+    ok_sum16 = ok16 and torch.equal(L.grads[L.tail:], tail_before) \
         and dp16.bytes_per_step() * 2 == dp.bytes_per_step() and L.grads.dtype == torch.float32
     if rank == 0:
         out.put((same_params, covered, ok_sum, ok_tail, ok_view, dp.world, ok_sum16))
@@ -82,19 +88,20 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_two_ranks_gloo():
+@pytest.mark.parametrize("world_size", [2, 8])   # 8 = the ranks of BASELINE configs[2] (one node of 8 GPUs)
+def test_bucketed_allreduce_two_ranks_gloo(world_size):
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world_size, port, out)) for r in range(world_size)]
     for p in procs:
         p.start()
-    res = out.get(timeout=120)
+    res = out.get(timeout=240)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     same_params, covered, ok_sum, ok_tail, ok_view, world, ok_sum16 = res
-    assert world == 2
+    assert world == world_size
     assert same_params, "rank-0 broadcast did not equalise the parameters"
     assert covered, "gradient buckets must tile the trained range exactly"
     assert ok_sum, "all-reduce (sum) over the trained range"
