@@ -323,19 +323,31 @@ __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
   // ---- softmax over keys, flash-style across the four key slices: every slice normalises by its OWN row maximum, the
   // (max, sum) pairs meet in LDS once, then each slice rescales by exp(m_slice - m) / l
   float mx[NT];
+  const bool masked = a.kv_len != nullptr;   // the fusion transformers pass no key mask: no per-element key test there (block-uniform)
 #pragma unroll
   for (int y = 0; y < NT; ++y) {
     float m = -INFINITY;
+    if (!masked) {
 #pragma unroll
-    for (int x = 0; x < NT; ++x)
+      for (int x = 0; x < NT; ++x)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = k0 + 16 * x + 4 * l4 + r;
-        // kv_len == 0: the reference's masked_fill(-1e9) + softmax is uniform attention over all keys (model_vec.py:315-317)
-        const float v = nokeys ? 0.f : (key < kvlen ? s[x][y][r] * a.scale : -INFINITY);
-        s[x][y][r] = v;
-        m = fmaxf(m, v);
-      }
+        for (int r = 0; r < 4; ++r) {
+          const float v = s[x][y][r] * a.scale;
+          s[x][y][r] = v;
+          m = fmaxf(m, v);
+        }
+    } else {
+#pragma unroll
+      for (int x = 0; x < NT; ++x)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = k0 + 16 * x + 4 * l4 + r;
+          // kv_len == 0: the reference's masked_fill(-1e9) + softmax is uniform attention over all keys (model_vec.py:315-317)
+          const float v = nokeys ? 0.f : (key < kvlen ? s[x][y][r] * a.scale : -INFINITY);
+          s[x][y][r] = v;
+          m = fmaxf(m, v);
+        }
+    }
     m = quad_max(m);
     const float msafe = m > -INFINITY ? m : 0.f;   // a fully masked slice: every exponent is exp(-inf - 0) = 0
     float t = 0.f;
@@ -450,6 +462,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
   Drop dr;
   dr.init(a, b, hd);
   const bool drop = dr.on;
+  const bool masked = a.kv_len != nullptr;
 #pragma unroll
   for (int y = 0; y < NT; ++y) {
     const int q = q0 + 16 * y + l15;
@@ -460,8 +473,12 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = k0 + 16 * x + 4 * l4 + r;
-        const float ex = mmfn_exp((nokeys ? 0.f : acc[0][x][y][r] * a.scale) - lse);
-        const float p = (nokeys || key < kvlen) ? ex : 0.f;
+        float p;
+        if (!masked) p = mmfn_exp(acc[0][x][y][r] * a.scale - lse);   // (block-uniform: no key mask was passed)
+        else {
+          const float ex = mmfn_exp((nokeys ? 0.f : acc[0][x][y][r] * a.scale) - lse);
+          p = (nokeys || key < kvlen) ? ex : 0.f;
+        }
         float dpv = acc[1][x][y][r];
         if (drop) dpv *= dr.scale(q, key, T);
         acc[0][x][y][r] = p;
@@ -556,6 +573,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
   Drop dr;
   dr.init(a, b, hd);
   const bool drop = dr.on;
+  const bool masked = a.kv_len != nullptr;
 #pragma unroll
   for (int x = 0; x < NT; ++x)
 #pragma unroll
@@ -566,9 +584,13 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
 #pragma unroll
       for (int y = 0; y < NT; ++y) {
         const int key = k0 + 16 * y + l15;
-        const bool kin = nokeys || key < kvlen;
-        const float ex = mmfn_exp((nokeys ? 0.f : acc[0][x][y][r] * a.scale) - lse);
-        const float p = kin ? ex : 0.f;
+        float p;
+        if (!masked) p = mmfn_exp(acc[0][x][y][r] * a.scale - lse);
+        else {
+          const bool kin = nokeys || key < kvlen;
+          const float ex = mmfn_exp((nokeys ? 0.f : acc[0][x][y][r] * a.scale) - lse);
+          p = kin ? ex : 0.f;
+        }
         float msc = 1.f;
         if (drop) msc = dr.scale(q, key, T);
         acc[0][x][y][r] = p * msc;                                                           // dV = (P o mask)^T dO
