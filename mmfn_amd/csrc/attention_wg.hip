@@ -18,8 +18,15 @@
 //     lane>>4, step r), so probabilities never leave registers;
 //   * the four slices meet through LDS three times: row max, row sum (delta in the backward), and the partial output
 //     tiles - each wave finishes the quarter of the head dimension it owns, so the merge is balanced as well and the
-//     result leaves as 64..128-byte contiguous runs per row.
+//     result leaves as 64..128-byte contiguous runs per row;
+//   * the key-owned pass at head size 128 keeps BOTH accumulator sets (P o mask for dV, dS for dK: 72 registers) across
+//     its two second products, so it runs them one 16-key row at a time (8 output tiles = 32 registers instead of 96) and
+//     merges each row in the half-operand area, which leaves dO / Q in place: 0 bytes of scratch where the whole-tile
+//     form spilled 77 registers (312 bytes per lane), 62.6 -> 54 us.  build.check_scratch() fails the build on scratch in
+//     any kernel not named in scratch_allowlist.txt.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "attention_args.h"
 
@@ -177,6 +184,31 @@ __device__ __forceinline__ void second_phase(const f32x4 (*Pm)[NT], const float*
   }
 }
 
+// One key-tile row (y) of second_phase: out[j] += sum_r P[r][row 16y + ..] * R[r][dcol(.., j)].  Used where the full
+// [NT][NDT] output set does not fit the register file beside both accumulator sets (dK/dV pass at head size 128).
+template <int HS, int NT>
+__device__ __forceinline__ void second_phase_row(const f32x4 (*Pm)[NT], int y, const float* rows, int l15, int l4, f32x4* out) {
+  using S = Shape<HS, NT>;
+  constexpr int NDT = S::NDT, W = S::W, NGR = NDT / W, P = Pitch<HS>::P;
+#pragma unroll
+  for (int step = 0; step < 4 * NT; ++step) {
+    const int x = step >> 2, e = step & 3;
+    const float* p = rows + (16 * x + 4 * l4 + e) * P + l15 * W;
+    float rv[NDT];
+#pragma unroll
+    for (int g = 0; g < NGR; ++g) {
+      if (W == 2) {
+        const f32x2 t = *reinterpret_cast<const f32x2*>(p + 32 * g);
+        rv[2 * g] = t[0]; rv[2 * g + 1] = t[1];
+      } else {
+        rv[g] = p[16 * g];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NDT; ++j) out[j] = mfma16(Pm[x][y][e], rv[j], out[j]);
+  }
+}
+
 // Partial output tiles of the four slices of a group -> their sum, written to dst (row stride ldd, rows of this group).
 // Slice s owns tiles [s*W, s*W+W) (the first NOWN slices when the head has fewer than four tiles); everybody parks the
 // tiles it does not own in LDS, one barrier, owners add the three foreign copies in slice order (deterministic).
@@ -202,38 +234,37 @@ __device__ __forceinline__ void merge_store(const f32x4 (*acc)[HS / 16], float* 
     }
   }
   __syncthreads();
-  if (owner) {
+  // the owner's part, with the slice as a compile-time constant (slice is wave-uniform: one scalar branch, static registers)
+  auto own = [&](auto SL) {
+    constexpr int sl = decltype(SL)::value;
 #pragma unroll
     for (int y = 0; y < NT; ++y) {
       f32x4 t[W];
 #pragma unroll
       for (int jj = 0; jj < W; ++jj) {
-        const int j = slice * W + jj;   // NDT < 4: W == 1 and slice < NDT, so j = slice
+        const int j = sl * W + jj;   // NDT < 4: W == 1 and slice < NDT, so j = slice
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        bool first = true;
 #pragma unroll
         for (int src = 0; src < 4; ++src) {   // slice order, own copy taken from registers at its place in the order
-          f32x4 part;
-          if (src == slice) {
-            // j depends on slice (wave-uniform): select acc[y][j] with an unrolled compare so register indices stay static
-            part = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int jc = 0; jc < NDT; ++jc)
-              if (jc == j) part = acc[y][jc];
-          } else {
-            part = *slab(src, slot_of(src, j), y);
-          }
-          v = first ? part : v + part;
-          first = false;
+          const f32x4 part = src == sl ? acc[y][j < NDT ? j : 0] : *slab(src, slot_of(src, j), y);
+          v = src == 0 ? part : v + part;
         }
         t[jj] = v;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        TIO* p = dst + (size_t)(16 * y + 4 * l4 + r) * ldd + slice * 16 * W + l15 * W;
-        if (W == 2) VecIO<2, TIO>::st(p, f32x2{t[0][r], t[1][r]});
+        TIO* p = dst + (size_t)(16 * y + 4 * l4 + r) * ldd + sl * 16 * W + l15 * W;
+        if (W == 2) VecIO<2, TIO>::st(p, f32x2{t[0][r], t[W - 1][r]});
         else stx1(p, t[0][r]);
       }
+    }
+  };
+  if (owner) {
+    switch (slice) {
+      case 0: own(std::integral_constant<int, 0>{}); break;
+      case 1: if constexpr (NOWN > 1) own(std::integral_constant<int, 1>{}); break;
+      case 2: if constexpr (NOWN > 2) own(std::integral_constant<int, 2>{}); break;
+      default: if constexpr (NOWN > 3) own(std::integral_constant<int, 3>{}); break;
     }
   }
 }
@@ -597,6 +628,27 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
         acc[1][x][y][r] = nokeys ? 0.f : p * (acc[1][x][y][r] * msc - dlt) * a.scale;         // dK = dS^T Q
       }
     }
+  if constexpr ((HS == 128 && NT == 3) || NT == 4) {
+    // one key-tile row at a time: 8 output tiles (32 registers) instead of 24 beside the two accumulator sets, and a
+    // merge of a third of the size, which fits the half-operand area (sB) - so the full-operand area keeps dO / Q
+    stA.issue(io_q + rowbase * ld + hd * HS, ld, tid);
+#pragma unroll
+    for (int prod = 0; prod < 2; ++prod) {
+#pragma unroll
+      for (int y = 0; y < NT; ++y) {
+        __builtin_amdgcn_sched_barrier(0);   // keeps one row's MFMAs from being interleaved with the next (register pressure)
+        f32x4 g1[1][NDT];
+#pragma unroll
+        for (int j = 0; j < NDT; ++j) g1[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        second_phase_row<HS, NT>(acc[prod], y, sA + q0 * P, l15, l4, g1[0]);
+        __syncthreads();   // sB free: V (first pass) / the previous merge's copies have been read
+        if (prod == 0 && y == NT - 1) stA.commit(sA, tid);   // dO is no longer read
+        TIO* dst = (prod == 0 ? io_dv : io_dk) + (rowbase + k0 + 16 * y) * a.ldg + hd * HS;
+        merge_store<HS, 1, TIO>(g1, sB, kg, qs, lane, l15, l4, dst, a.ldg);
+      }
+    }
+    return;
+  }
   f32x4 g[NT][NDT];
 #pragma unroll
   for (int y = 0; y < NT; ++y)

@@ -114,6 +114,21 @@ def test_abi_library_exports_every_declared_symbol():
     assert set(_lib._SIGNATURES) == set(declared)
 
 
+def test_no_hot_kernel_uses_scratch_memory():
+    """The build gate (mmfn_amd/build.check_scratch): every kernel hipcc compiled reports 0 bytes of scratch per lane unless
+    csrc/scratch_allowlist.txt names it; the fusion transformers' attention kernels (head size 128, T = 192) are never listed."""
+    from mmfn_amd import build
+    res = build.kernel_resources()
+    if not res:
+        pytest.skip("no compiler resource remarks beside the objects (library built by an older build.py)")
+    assert len(res) >= 400
+    build.check_scratch(verbose=False)   # raises on an unlisted kernel with scratch
+    hot = [k for k in res if "attn_wg_" in k and "ILi128ELi3E" in k]
+    assert len(hot) == 6 and all(res[k]["scratch"] == 0 for k in hot)
+    allow = open(build.SCRATCH_ALLOW).read()
+    assert "ILi128E" not in allow and "gemm" not in allow
+
+
 def test_decay_groups_follow_the_reference_rule():
     """configure_optimizers == GPT.configure_optimizers (model_vec.py:179-209) on the GPT sub-modules, extended to the whole
     model: Linear / Conv2d weights decay; biases, LayerNorm / BatchNorm weights and pos_emb do not."""
