@@ -226,7 +226,8 @@ def _autotune(d, C, key, reps=3):
     results = []
     plain = d.a_mode in (A_ROWMAJOR, A_COLMAJOR) and d.b_mode in (B_NK, B_KN)
     modes = [0]
-    if F32X3 and plain and not d.flags & (EPI_BF16_OPERANDS | EPI_BF16X3) and K % 32 == 0:
+    # (not with MMFN_EPI_COLSUM_A: the column sums are formed from the fp32 operand fragments of the native kernel only)
+    if F32X3 and plain and not d.flags & (EPI_BF16_OPERANDS | EPI_BF16X3 | EPI_COLSUM_A) and K % 32 == 0:
         modes.append(EPI_BF16X3)  # fp32 on the bf16 pipe (three-term split) competes with the native fp32 MFMA kernel
     if base is not None:
         for mode in modes:
@@ -335,6 +336,11 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=N
         cfg = _tuned.get(key)
         if cfg is None and AUTOTUNE and _profiler is None and not torch.cuda.is_current_stream_capturing() and ln_fold is None:
             cfg = _autotune(d, C, key)
+        if cfg is not None and len(cfg) == 3 and colsum is not None:
+            # a table entry that moves this shape to the three-term bf16 emulation kernel (MMFN_F32X3=1): that kernel cannot also
+            # return the A operand's column sums (mmfn_gemm_f32 answers MMFN_EINVAL to COLSUM_A + BF16X3), and the entry's
+            # (tile, split) were measured for it - the fused bias gradient keeps the native kernel at the library's default
+            cfg = None
         if cfg is not None and (len(cfg) == 2 or F32X3):
             d.tile, d.splitk = cfg[0], cfg[1]
             if len(cfg) == 3 and ln_fold is None:

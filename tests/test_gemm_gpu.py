@@ -443,3 +443,31 @@ def test_bias_gradient_from_the_weight_gradient_gemm(M, N, K, tile, splitk):
     err = (db.cpu().double() - ref).abs().max().item()
     assert err <= 1e-5 * (dy.abs().double().sum(0).max().item() + 1e-6), err
     assert torch.equal(dw, ops.linear_dw(dyd, xd, tile=tile, splitk=splitk))
+
+
+def test_bias_gradient_from_the_weight_gradient_gemm_under_the_f32x3_table():
+    """MMFN_F32X3=1 loads tuning/gfx950_f32x3.json, whose entries move the transformers' weight-gradient shapes to the three-term
+    bf16 emulation kernel - which cannot return column sums (mmfn_gemm_f32: COLSUM_A + BF16X3 = MMFN_EINVAL; round 5 crashed the
+    training step here).  linear_dw(db=...) must then stay on the native kernel for those shapes and still return both."""
+    import os
+    from mmfn_amd import ops
+    dev = _dev()
+    saved_flag, saved_table = ops.F32X3, dict(ops._tuned)
+    try:
+        ops.F32X3 = True
+        ops.load_tuning(os.path.join(os.path.dirname(ops._TUNE_FILE), "gfx950_f32x3.json"))
+        emulated = [k for k, v in ops._tuned.items() if len(v) == 3 and k.startswith("1,1,")]
+        assert emulated, "the f32x3 table no longer holds a TN entry: pick another shape for this test"
+        for key in emulated[:3]:
+            N, K, M = (int(v) for v in key.split("|")[0].split(",")[2:5])
+            g = torch.Generator().manual_seed(N + K)
+            dy, x = torch.randn(M, N, generator=g), torch.randn(M, K, generator=g)
+            db = torch.full((N,), float("nan"), device=dev)
+            dw = ops.linear_dw(dy.to(dev), x.to(dev), db=db)
+            _close(dw, dy.double().t() @ x.double())
+            err = (db.cpu().double() - dy.double().sum(0)).abs().max().item()
+            assert err <= 1e-5 * (dy.abs().double().sum(0).max().item() + 1e-6), (key, err)
+    finally:
+        ops.F32X3 = saved_flag
+        ops._tuned.clear()
+        ops._tuned.update(saved_table)
