@@ -368,6 +368,60 @@ int mmfn_attention_bwd_f32(const float* q, const float* k, const float* v, int l
  * last workgroup-form forward launch) to HOST memory; MMFN_EINVAL when the instrumentation is off. */
 int mmfn_attn_debug_read(int64_t* out32);
 
+/* ---- fused GPT block (narrow fusion transformers: n_embd 64 / 128, 4 heads, T = 192) ------------------------------
+ * One transformer block of model_vec.py:112-133 in TWO forward launches and THREE backward launches (the separate kernels: 8 and
+ * 9 on the dependent chain, each at the 9-18 us launch floor where the whole block holds < 2 GFLOP):
+ *   mmfn_gpt_block_attn_fwd_f32   ln1 -> key / query / value of ONE head -> softmax(q k^T) (dropout) v, one workgroup per (sample,
+ *                                 head, query half): replaces native_layer_norm + 3 addmm + the bmm / softmax / dropout / bmm of
+ *                                 :96-105, :126 (the existing fused attention with the projections as its prologue);
+ *   mmfn_gpt_block_mlp_fwd_f32    x1 = x + drop(proj(o)); a2 = ln2(x1); h = relu(mlp.0(a2)); x2 = x1 + drop(mlp.2(h)) for a block of
+ *                                 32 token rows per workgroup, the hidden activations never leaving LDS between the GEMMs:
+ *                                 replaces 3 addmm + native_layer_norm + relu + 2 dropout + 2 add of :107-108,:126-131;
+ *   mmfn_gpt_block_bwd_rows_f32   the row-local part of the backward between two attention backward passes, 32 token rows per
+ *                                 workgroup: (upper block) dqkv . Wqkv -> ln1 backward (+ residual) -> dropout mask of the block
+ *                                 below; (lower block) mlp.2 dgrad (ReLU mask from h) -> mlp.0 dgrad -> ln2 backward (+ residual)
+ *                                 -> dropout mask -> proj dgrad.  Either half may be absent (NULL): first / last launch of a GPT.
+ * Everything a weight gradient contracts with (a, a2, o, h; gd, gh, gd2, dqkv) is still written to HBM: the weight-gradient GEMMs
+ * stay separate launches off the dependent chain.  Dropout masks: the counter RNG at the indices of the unfused kernels (attention:
+ * stream rng_stream, proj: rng_stream + 1, mlp.2: rng_stream + 2; element (row, col) of an [M, C] tensor = row * C + col), so fused
+ * and unfused forward / backward kernels can be mixed.  LayerNorm partial rows: [n_workgroups][2 or 3][C] as mmfn_layernorm_bwd_partial
+ * writes them (dweight, dbias, column sums of the dropped gradient), n_workgroups = M / 32, for mmfn_layernorm_bwd_finalize_f32. */
+typedef struct mmfn_gpt_block_desc {
+  /* parameters, fp32, reference layouts: Linear weights [out][in]; wqkv = key | query | value stacked [3C][C] (model_vec.py:82-84) */
+  const float* ln1_w; const float* ln1_b; const float* wqkv; const float* bqkv; const float* wproj; const float* bproj;
+  const float* ln2_w; const float* ln2_b; const float* w1; const float* b1; const float* w2; const float* b2;
+  /* forward activations, M = B * T rows */
+  const float* x;                     /* [M][C] block input (residual stream) */
+  float* a; float* mu1; float* rs1;   /* ln1(x) [M][C], its row mean / 1 / std [M] */
+  float* qkv;                         /* [M][3C] key | query | value */
+  float* o; float* lse;               /* attention output [M][C], log-sum-exp [B][NH][T] */
+  float* x1; float* a2; float* mu2; float* rs2; float* h; float* x2;   /* [M][C], [M][C], [M], [M], [M][4C], [M][C] */
+  /* backward tensors */
+  const float* g;       /* [M][C] gradient arriving at x2 (lower block, read when no upper block produces it in the same launch) */
+  const float* gd;      /* its copy under mlp.2's dropout mask; NULL = g (resid_pdrop == 0) */
+  float* gh;            /* [M][4C] gradient of the hidden activations (after the ReLU mask) */
+  float* g1;            /* [M][C] gradient of x1 */
+  float* gd2;           /* its copy under proj's dropout mask; NULL when resid_pdrop == 0 */
+  float* go;            /* [M][C] gradient of the attention output */
+  const float* dqkv;    /* [M][3C] gradient of key | query | value (upper block) */
+  float* g_below;       /* [M][C] gradient of x = the block input (upper block writes it) */
+  float* gd_below;      /* its copy under the mask of the block below (stream rng_stream_below + 2); NULL = not wanted */
+  float* part_ln1;      /* [M/32][2 or 3][C] partial rows of ln1's backward (3 with below_colsum) */
+  float* part_ln2;      /* [M/32][3][C] partial rows of ln2's backward (third: column sums of gd2 = proj's bias gradient) */
+  const uint64_t* rng_state;
+  int32_t B, T, C, NH;
+  float attn_pdrop, resid_pdrop, eps;
+  uint32_t rng_stream, rng_stream_below;
+  int32_t below_colsum;  /* part_ln1 carries a third row: the column sums of what leaves in gd_below (or g_below) */
+  int32_t reserved;
+} mmfn_gpt_block_desc;
+/* MMFN_EINVAL unless C in {64, 128}, NH == 4, T == 192 */
+int mmfn_gpt_block_supported(int C, int NH, int T);
+int mmfn_sizeof_gpt_block_desc(void);
+int mmfn_gpt_block_attn_fwd_f32(const mmfn_gpt_block_desc* d, void* stream);
+int mmfn_gpt_block_mlp_fwd_f32(const mmfn_gpt_block_desc* d, void* stream);
+int mmfn_gpt_block_bwd_rows_f32(const mmfn_gpt_block_desc* upper, const mmfn_gpt_block_desc* lower, void* stream);
+
 /* ---- waypoint head: GRUCell x steps + Linear(64,2) + L1 loss (model_vec.py:666-680, phase2:104) ---- */
 int64_t mmfn_gru_head_part_floats(void);
 int mmfn_gru_head_fwd_f32(const float* z0, const float* target, const float* w_ih, const float* w_hh, const float* b_ih,

@@ -56,6 +56,18 @@ class Gemm16Desc(ctypes.Structure):
     ]
 
 
+class GptBlockDesc(ctypes.Structure):
+    """mmfn_gpt_block_desc (include/mmfn_hip.h): one transformer block of the narrow fusion transformers for the fused kernels."""
+    _PTRS = ("ln1_w", "ln1_b", "wqkv", "bqkv", "wproj", "bproj", "ln2_w", "ln2_b", "w1", "b1", "w2", "b2",
+             "x", "a", "mu1", "rs1", "qkv", "o", "lse", "x1", "a2", "mu2", "rs2", "h", "x2",
+             "g", "gd", "gh", "g1", "gd2", "go", "dqkv", "g_below", "gd_below", "part_ln1", "part_ln2", "rng_state")
+    _fields_ = [(n, _vp) for n in _PTRS] + [
+        ("B", _i32), ("T", _i32), ("C", _i32), ("NH", _i32),
+        ("attn_pdrop", _f32), ("resid_pdrop", _f32), ("eps", _f32),
+        ("rng_stream", ctypes.c_uint32), ("rng_stream_below", ctypes.c_uint32), ("below_colsum", _i32), ("reserved", _i32),
+    ]
+
+
 G16_NT, G16_CONV_FWD, G16_CONV_DGRAD, G16_TN, G16_CONV_WGRAD = 0, 1, 2, 3, 4
 EPI16_OUT_F32 = 1024
 EPI16_RES_F32 = 2048
@@ -115,6 +127,8 @@ def lib():
             raise MMFNLibraryError("mmfn_gemm_desc layout mismatch between C and ctypes")
         if handle.mmfn_sizeof_gemm16_desc() != ctypes.sizeof(Gemm16Desc):
             raise MMFNLibraryError("mmfn_gemm16_desc layout mismatch between C and ctypes")
+        if handle.mmfn_sizeof_gpt_block_desc() != ctypes.sizeof(GptBlockDesc):
+            raise MMFNLibraryError("mmfn_gpt_block_desc layout mismatch between C and ctypes")
         _lib = handle
     return _lib
 

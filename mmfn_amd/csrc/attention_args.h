@@ -28,14 +28,15 @@ struct Drop {
   uint32_t salt, thresh;
   float inv_keep;
   bool on;
-  __device__ __forceinline__ void init(const AttnArgs& a, int b, int hd) {
-    on = a.drop_p > 0.f;
+  __device__ __forceinline__ void init(const AttnArgs& a, int b, int hd) { init(a.drop_p, a.rng_state, a.rng_stream, a.NH, b, hd); }
+  __device__ __forceinline__ void init(float drop_p, const uint64_t* rng_state, uint32_t rng_stream, int NH, int b, int hd) {
+    on = drop_p > 0.f;
     salt = 0; thresh = 0; inv_keep = 1.f;
     if (on) {
-      const uint64_t k = mmfn_rng_key(a.rng_state, a.rng_stream) + (uint64_t)(b * a.NH + hd) * 0x9E3779B97F4A7C15ull;
+      const uint64_t k = mmfn_rng_key(rng_state, rng_stream) + (uint64_t)(b * NH + hd) * 0x9E3779B97F4A7C15ull;
       salt = mmfn_rng_salt(k);
-      thresh = (uint32_t)fminf(a.drop_p * 4294967296.0f, 4294967040.0f);
-      inv_keep = 1.0f / (1.0f - a.drop_p);
+      thresh = (uint32_t)fminf(drop_p * 4294967296.0f, 4294967040.0f);
+      inv_keep = 1.0f / (1.0f - drop_p);
     }
   }
   // keep-scale of element (query, key): 0 or 1 / (1 - p)

@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "attention_args.h"
+#include "gpt_block.h"
 
 namespace {
 
@@ -293,14 +294,15 @@ struct Lds {
 // XCD-aware block order.  Workgroup L runs on XCD L % 8 (each XCD has its own L2).  The two halves of a (sample, head)
 // pair read the same K / V (forward, dQ pass) or Q / dO (dK/dV pass): they get ids that agree mod 8 and are adjacent in that
 // XCD's dispatch order, so the pair's shared operands come from HBM once and the second half hits L2.
-__device__ __forceinline__ bool decode_block(const AttnArgs& a, int& half, int& hd, int& b) {
+__device__ __forceinline__ bool decode_block(int NH, int B, int& half, int& hd, int& b) {
   const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
   const int pair = (slot >> 1) * 8 + xcd;
   half = slot & 1;
-  hd = pair % a.NH;
-  b = pair / a.NH;
-  return pair < a.NH * a.B;
+  hd = pair % NH;
+  b = pair / NH;
+  return pair < NH * B;
 }
+__device__ __forceinline__ bool decode_block(const AttnArgs& a, int& half, int& hd, int& b) { return decode_block(a.NH, a.B, half, hd, b); }
 
 // dev instrumentation: s_memtime stamps of waves 0 and 7 of workgroup (0,0,0) at the phase boundaries
 __device__ __forceinline__ void stamp(const AttnArgs& a, int idx) {
@@ -435,6 +437,194 @@ __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
   __syncthreads();   // V no longer read: the area becomes the merge parking space
   merge_store<HS, NT, TIO>(o, sm, qg, ks, lane, l15, l4, io_o + (rowbase + q0) * a.ldo + hd * HS, a.ldo);
   stamp(a, 5);
+}
+
+// ------------------------------------------------------------------------ forward with the projections as its prologue
+// The narrow fusion transformers (n_embd 64 / 128, head size 16 / 32): ln1 -> key / query / value of this head -> attention in
+// ONE launch (gpt_block.h; include/mmfn_hip.h mmfn_gpt_block_attn_fwd_f32).  A sample's 192 x C token rows fit LDS, so the
+// workgroup of (sample, head, query half) normalises them itself (8 workgroups per sample repeat that: 24 rows per wave),
+// projects K and V of its head for all T tokens and Q for its half on the matrix pipes - weights as the MFMA A operand, so a
+// lane holds 4 consecutive head columns of a token: 16-byte stores into the staged operand layout and into the packed qkv tensor
+// the backward reads - and continues exactly as attn_wg_fwd_kernel.  Waves 0-2: K (4 token tiles each), 3-5: V, 6-7: Q (3 each).
+// Saved tensors: this workgroup writes its (query half) x (head columns) piece of a = ln1(x) and of key | query | value.
+template <int C, int HS>
+__global__ __launch_bounds__(NTHR) void gpt_attn_fwd_kernel(const GptArgs g) {
+  constexpr int NT = 3, T = 64 * NT, NH = C / HS, PX = C + 4, NHT = HS / 16, NCHX = C / 64;
+  using S = Shape<HS, NT>;
+  using L = Lds<HS, NT>;
+  constexpr int NDT = S::NDT, G = S::G, P = L::P;
+  constexpr int XF = T * PX, KQV = (2 * T + T / 2) * P;
+  constexpr int AREA = XF > KQV ? (XF > L::MERGE ? XF : L::MERGE) : (KQV > L::MERGE ? KQV : L::MERGE);
+  __shared__ __attribute__((aligned(16))) float sm[AREA];
+  __shared__ float sm_stat[2][2][4][G];
+  int half, hd, b;
+  if (!decode_block(NH, g.B, half, hd, b)) return;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const size_t rowbase = (size_t)b * T;
+  // ---- x rows of the sample -> LDS
+  {
+    constexpr int Q = C / 4, UNITS = T * Q;
+    const float* src = g.x + rowbase * C;
+#pragma unroll
+    for (int u0 = 0; u0 < UNITS; u0 += NTHR) {
+      const int u = u0 + tid;
+      *reinterpret_cast<f32x4*>(sm + (u / Q) * PX + 4 * (u % Q)) = ld4(src + (size_t)(u / Q) * C + 4 * (u % Q));
+    }
+  }
+  __syncthreads();
+  // ---- a = ln1(x) in place: 4 rows per wave pass (16 lanes per row), 6 passes
+  {
+    f32x4 wv[NCHX], bv[NCHX];
+#pragma unroll
+    for (int i = 0; i < NCHX; ++i) { wv[i] = ld4(g.ln1_w + 64 * i + 4 * l15); bv[i] = ld4(g.ln1_b + 64 * i + 4 * l15); }
+#pragma unroll
+    for (int it = 0; it < T / 32; ++it) {
+      const int t = 32 * it + 4 * w + l4;
+      f32x4 v[NCHX];
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCHX; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(sm + t * PX + 64 * i + 4 * l15);
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+      }
+      const float mu = gpt_row16_sum(s) / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCHX; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = v[i][r] - mu; q += d * d; }
+      const float rs = 1.0f / sqrtf(gpt_row16_sum(q) / (float)C + g.eps);
+      const bool mine = (t / (T / 2)) == half;
+#pragma unroll
+      for (int i = 0; i < NCHX; ++i) {
+        const int n = 64 * i + 4 * l15;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (v[i][r] - mu) * rs * wv[i][r] + bv[i][r];
+        *reinterpret_cast<f32x4*>(sm + t * PX + n) = o;
+        if (mine && n / HS == hd) *reinterpret_cast<f32x4*>(g.a + (rowbase + t) * C + n) = o;
+      }
+      if (mine && hd == 0 && l15 == 0) { g.mu1[rowbase + t] = mu; g.rs1[rowbase + t] = rs; }
+    }
+  }
+  __syncthreads();
+  // ---- key / value (all T tokens) and query (this half) of head hd: [HS] x [token tile] accumulators, in registers until
+  // every wave has finished reading a (their destination overlays it)
+  const int sel = w < 3 ? 0 : (w < 6 ? 2 : 1);               // packed order: key | query | value
+  const int tile0 = w < 6 ? 4 * (w % 3) : (T / 32) * half + 3 * (w - 6);   // first 16-token tile of this wave
+  f32x4 pacc[NHT][4];
+#pragma unroll
+  for (int i = 0; i < NHT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    const float* W = g.wqkv + (size_t)(sel * C + hd * HS) * C;
+    if (w < 6) {
+      gpt_rows_gemm_nt<C, NHT, 4, 4>(W, C, sm + 16 * tile0 * PX, l15, l4, pacc);
+    } else {
+      f32x4 q3[NHT][3];
+#pragma unroll
+      for (int i = 0; i < NHT; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) q3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      gpt_rows_gemm_nt<C, NHT, 3, 4>(W, C, sm + 16 * tile0 * PX, l15, l4, q3);
+#pragma unroll
+      for (int i = 0; i < NHT; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) pacc[i][j] = q3[i][j];
+    }
+  }
+  __syncthreads();   // a is no longer read
+  float* sK = sm;                    // [T][P]
+  float* sQ = sm + T * P;            // [T/2][P]
+  float* sV = sm + (T + T / 2) * P;  // [T][P]
+  {
+    float* dstbase = sel == 0 ? sK : (sel == 2 ? sV : sQ - (T / 2) * half * P);   // (query rows are stored relative to the half)
+    const int ntile = w < 6 ? 4 : 3;
+#pragma unroll
+    for (int i = 0; i < NHT; ++i) {
+      const f32x4 bias = ld4(g.bqkv + sel * C + hd * HS + 16 * i + 4 * l4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < ntile) {
+          const int t = 16 * (tile0 + j) + l15, n = 16 * i + 4 * l4;
+          const f32x4 v = pacc[i][j] + bias;
+          *reinterpret_cast<f32x4*>(dstbase + t * P + n) = v;
+          if ((t / (T / 2)) == half) *reinterpret_cast<f32x4*>(g.qkv + (rowbase + t) * 3 * C + sel * C + hd * HS + n) = v;
+        }
+    }
+  }
+  __syncthreads();
+  // ---- attention (attn_wg_fwd_kernel without a key mask; K, Q, V are staged already)
+  const int qg = w >> 2, ks = w & 3;
+  const int q0 = half * 2 * G + qg * G;
+  const int k0 = ks * G;
+  const float scale = 1.0f / sqrtf((float)HS);
+  f32x4 s[NT][NT];
+#pragma unroll
+  for (int x = 0; x < NT; ++x)
+#pragma unroll
+    for (int y = 0; y < NT; ++y) s[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+  product_phase<HS, NT, HS>(sK + k0 * P, sQ + qg * G * P, 0, l15, l4, s);
+  float mx[NT];
+#pragma unroll
+  for (int y = 0; y < NT; ++y) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int x = 0; x < NT; ++x)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = s[x][y][r] * scale;
+        s[x][y][r] = v;
+        m = fmaxf(m, v);
+      }
+    m = quad_max(m);
+    float t = 0.f;
+#pragma unroll
+    for (int x = 0; x < NT; ++x)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = mmfn_exp(s[x][y][r] - m);
+        s[x][y][r] = e;
+        t += e;
+      }
+    mx[y] = m;
+    t = quad_sum(t);
+    if (l4 == 0) { sm_stat[0][qg][ks][16 * y + l15] = m; sm_stat[1][qg][ks][16 * y + l15] = t; }
+  }
+  __syncthreads();
+  Drop dr;
+  dr.init(g.attn_pdrop, g.rng_state, g.rng_stream, NH, b, hd);
+  const bool drop = dr.on;
+#pragma unroll
+  for (int y = 0; y < NT; ++y) {
+    const int qi = 16 * y + l15;
+    float m = sm_stat[0][qg][0][qi];
+#pragma unroll
+    for (int o = 1; o < 4; ++o) m = fmaxf(m, sm_stat[0][qg][o][qi]);
+    float l = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) l += sm_stat[1][qg][o][qi] * mmfn_exp(sm_stat[0][qg][o][qi] - m);
+    const int q = q0 + qi;
+    if (ks == 0 && l4 == 0) g.lse[((size_t)b * NH + hd) * T + q] = m + logf(l);
+    const float fac = mmfn_exp(mx[y] - m) / l;
+#pragma unroll
+    for (int x = 0; x < NT; ++x)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = s[x][y][r] * fac;
+        if (drop) p *= dr.scale(q, k0 + 16 * x + 4 * l4 + r, T);
+        s[x][y][r] = p;
+      }
+  }
+  f32x4 o[NT][NDT];
+#pragma unroll
+  for (int y = 0; y < NT; ++y)
+#pragma unroll
+    for (int j = 0; j < NDT; ++j) o[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  second_phase<HS, NT>(s, sV + k0 * P, l15, l4, o);
+  __syncthreads();   // K, Q, V no longer read: the area becomes the merge parking space
+  merge_store<HS, NT, float>(o, sm, qg, ks, lane, l15, l4, g.o + (rowbase + q0) * C + hd * HS, C);
 }
 
 // ---------------------------------------------------------------------------------------- backward, query-owned: dQ, delta
@@ -719,6 +909,16 @@ int by_tokens(int which, const AttnArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int mmfn_gpt_block_attn_fwd_f32(const mmfn_gpt_block_desc* d, void* stream) {
+  if (!d || mmfn_gpt_block_supported(d->C, d->NH, d->T) != 0 || d->B <= 0) return MMFN_EINVAL;
+  if (d->attn_pdrop < 0.f || d->attn_pdrop >= 1.f || (d->attn_pdrop > 0.f && !d->rng_state)) return MMFN_EINVAL;
+  const dim3 grid(2 * 8 * ceil_div(d->NH * d->B, 8));
+  if (d->C == 64) hipLaunchKernelGGL((gpt_attn_fwd_kernel<64, 16>), grid, dim3(NTHR), 0, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL((gpt_attn_fwd_kernel<128, 32>), grid, dim3(NTHR), 0, (hipStream_t)stream, *d);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int mmfn_attn_debug_read(int64_t* out64) {   // dev only: copies the 32 stamps to host memory
   long long* p = debug_buffer();

@@ -577,6 +577,10 @@ LN_FOLD = os.environ.get("MMFN_LN_FOLD", "eval")
 # C = 512 included: 17.33 / 31.50 (its side work is chip-filling GEMMs); three or four streams: 17.57 / 18.02 and 31.95 (every
 # further fork is a queue hop).
 SIDE_SPLIT_MAX_C = 256
+# The narrow transformers (n_embd 64 / 128, fp32): a block is 2 forward launches (ln1 + q/k/v + attention per (sample, head, half);
+# proj + ln2 + mlp per 32-row block) and 3 backward launches (dQ, dK/dV, the row-local rest) instead of 8 and 9 on the dependent
+# chain (ops.gpt_block_*, csrc/gpt_block.hip).  MMFN_GPT_FUSED: "1" (default) both passes, "fwd" forward only, "0" off.
+GPT_FUSED = os.environ.get("MMFN_GPT_FUSED", "1")
 
 
 def _dw_db(dy, x, gw, gb):
@@ -649,9 +653,28 @@ class GPT(object):
         fold = (not ctx.bf16) and ops.current_precision() == "f32" and self.blocks[0]["fold"] is not None and M % 64 == 0 \
             and ctx.engine.ln_fold_now(ctx.training)
         self.folded_fwd = fold
+        fused = self.fused_now(ctx) and not fold
+        self.fused_fwd = fused
         for i, blk in enumerate(self.blocks):
             sb = self.stream_base + 1 + 3 * i
             qkv = bufs.get("%s.b%d.qkv" % (nm, i), (M, 3 * C), adt)
+            if fused:
+                ln1, ln2 = blk["ln1"], blk["ln2"]
+                mu1, rs1 = bufs.get(ln1.name + ".mu", (M,)), bufs.get(ln1.name + ".rs", (M,))
+                mu2, rs2 = bufs.get(ln2.name + ".mu", (M,)), bufs.get(ln2.name + ".rs", (M,))
+                lse = bufs.get("%s.b%d.lse" % (nm, i), (B, nh, T))
+                x1 = bufs.get("%s.b%d.x1" % (nm, i), (M, C), sdt)
+                x2 = bufs.get("%s.b%d.x2" % (nm, i), (M, C), sdt)
+                a, o, a2, h = S_a[i], S_o[i], S_a2[i], S_h[i]
+                d = self._desc(blk, B, ctx, sb, x=x, a=a, mu1=mu1, rs1=rs1, qkv=qkv, o=o, lse=lse, x1=x1, a2=a2, mu2=mu2, rs2=rs2,
+                               h=h, x2=x2)
+                ops.gpt_block_attn_fwd(d)
+                ops.gpt_block_mlp_fwd(d)
+                ln1.saved = (x, mu1, rs1, ACT_NONE)
+                ln2.saved = (x1, mu2, rs2, ACT_NONE)
+                self.acts.append((x, a, qkv, o, lse, x1, a2, h))
+                x = x2
+                continue
             if fold:
                 # LN(x) . Wqkv^T + b in one launch; a = LN(x) is (re)computed by the backward's side work, where it is needed
                 ln = blk["ln1"]
@@ -690,6 +713,88 @@ class GPT(object):
         y = self.ln_f.fwd(ctx, x, out=bufs.get(nm + ".ln_f.out", (M, C), adt))
         return y.view(B, T, C)
 
+    def fused_now(self, ctx):
+        """The fused block kernels serve this transformer in this pass: fp32 mode and arithmetic, n_embd 64 / 128, 4 heads, T = 192."""
+        return (GPT_FUSED != "0" and not ctx.bf16 and ops.current_precision() == "f32"
+                and ops.gpt_block_supported(self.C, self.nh, self.T))
+
+    def _desc(self, blk, B, ctx, sb, sb_below=0, below_colsum=False, **tensors):
+        p_embd, p_attn, p_resid = ctx.drop
+        return ops.gpt_block_desc(
+            B, self.T, self.C, self.nh, eps=1e-5, attn_pdrop=p_attn, resid_pdrop=p_resid, rng_state=ctx.rng_state, rng_stream=sb,
+            rng_stream_below=sb_below, below_colsum=below_colsum,
+            ln1_w=blk["ln1"].w, ln1_b=blk["ln1"].b, wqkv=blk["wqkv"], bqkv=blk["bqkv"], wproj=blk["proj"].w, bproj=blk["proj"].b,
+            ln2_w=blk["ln2"].w, ln2_b=blk["ln2"].b, w1=blk["fc1"].w, b1=blk["fc1"].b, w2=blk["fc2"].w, b2=blk["fc2"].b, **tensors)
+
+    def _bwd_fused(self, ctx, g_y):
+        """GPT.bwd with the row-local chain of every block in one launch (csrc/gpt_block.hip gpt_bwd_rows_kernel): per block the chain is
+        dQ -> dK/dV -> rows(this block's qkv dgrad + ln1 backward | the block below's mlp / ln2 / proj dgrads)."""
+        B = g_y.shape[0]
+        T, C, nh, hs = self.T, self.C, self.nh, self.hs
+        M = B * T
+        bufs, nm = ctx.bufs, self.name
+        p_embd, p_attn, p_resid = ctx.drop
+        scale = 1.0 / math.sqrt(hs)
+        nblk = len(self.blocks)
+        drop = p_resid > 0.0
+        sb_of = lambda i: self.stream_base + 1 + 3 * i
+        f32 = torch.float32
+        G = bufs.get(nm + ".S.g", (nblk, M, C), f32)
+        GD = bufs.get(nm + ".S.gdrop", (nblk, M, C), f32) if drop else None
+        G1 = bufs.get(nm + ".S.g1", (nblk, M, C), f32)
+        GD2 = bufs.get(nm + ".S.gdrop2", (nblk, M, C), f32) if drop else None
+        GH = bufs.get(nm + ".S.gh", (nblk, M, 4 * C), f32)
+        DQKV = bufs.get(nm + ".S.dqkv", (nblk, M, 3 * C), f32)
+        nrow = M // ops.GPT_ROWS
+        P1 = bufs.get(nm + ".S.part1", (nblk, nrow, 3, C), f32)
+        P2 = bufs.get(nm + ".S.part2", (nblk, nrow, 3, C), f32)
+        go = bufs.get(nm + ".go", (M, C), f32)
+        g_tok = bufs.get(nm + ".g_tok", (M, C), f32)
+        delta = bufs.get(nm + ".delta", (B, nh, T))
+        side = []
+        self.ln_f.bwd(ctx, g_y.view(M, C), out=G[nblk - 1], dropped=GD[nblk - 1] if drop else None, drop_p=p_resid,
+                      rng_stream=sb_of(nblk - 1) + 2, colsum=self.blocks[nblk - 1]["fc2"].gb, defer=side)
+        descs = []
+        for i, blk in enumerate(self.blocks):
+            x, a, qkv, o, lse, x1, a2, h = self.acts[i]
+            descs.append(self._desc(
+                blk, B, ctx, sb_of(i), sb_below=sb_of(i - 1) if i > 0 else 0, below_colsum=i > 0,
+                x=x, mu1=blk["ln1"].saved[1], rs1=blk["ln1"].saved[2], x1=x1, mu2=blk["ln2"].saved[1], rs2=blk["ln2"].saved[2], h=h,
+                g=G[i], gd=GD[i] if drop else None, gh=GH[i], g1=G1[i], gd2=GD2[i] if drop else None, go=go, dqkv=DQKV[i],
+                g_below=G[i - 1] if i > 0 else g_tok, gd_below=GD[i - 1] if (drop and i > 0) else None, part_ln1=P1[i], part_ln2=P2[i]))
+        ops.gpt_block_bwd_rows(None, descs[nblk - 1])
+        pending = None
+        for i in range(nblk - 1, -1, -1):
+            blk = self.blocks[i]
+            x, a, qkv, o, lse, x1, a2, h = self.acts[i]
+            dqkv = DQKV[i]
+            ops.attention_bwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, go, C, lse, delta, dqkv[:, C:], dqkv, dqkv[:, 2 * C:],
+                              3 * C, B, T, nh, hs, scale, drop_p=p_attn, rng_state=ctx.rng_state, rng_stream=sb_of(i))
+            if pending is not None:   # the block above's side work, now that this block's first chain kernel is captured
+                self._offload_side(ctx, pending)
+                pending = None
+            ops.gpt_block_bwd_rows(descs[i], descs[i - 1] if i > 0 else None)
+            gp, gp2 = (GD[i] if drop else G[i]), (GD2[i] if drop else G1[i])
+            below_gb = self.blocks[i - 1]["fc2"].gb if i > 0 else None
+            side += [
+                lambda gp=gp, blk=blk, h=h: ops.linear_dw(gp, h, out=blk["fc2"].gw),
+                lambda gh=GH[i], blk=blk, a2=a2: _dw_db(gh, a2, blk["fc1"].gw, blk["fc1"].gb),
+                lambda p=P2[i], blk=blk: ops.layernorm_bwd_finalize(p, nrow, C, blk["ln2"].gw, blk["ln2"].gb, blk["proj"].gb),
+                lambda gp2=gp2, blk=blk, o=o: ops.linear_dw(gp2, o, out=blk["proj"].gw),
+                lambda dqkv=dqkv, blk=blk, a=a: _dw_db(dqkv, a, blk["g_wqkv"], blk["g_bqkv"]),
+                lambda p=(P1[i] if i > 0 else P1[i].view(-1)[:nrow * 2 * C].view(nrow, 2, C)), blk=blk, cs=below_gb:
+                    ops.layernorm_bwd_finalize(p, nrow, C, blk["ln1"].gw, blk["ln1"].gb, cs),
+            ]
+            work, side = side, []
+            pending = (ctx.fork_point(), work)
+        if pending is not None:
+            self._offload_side(ctx, pending)
+        ctx.rejoin()
+        gtok = g_tok.view(B, T, C)
+        ops.tokens_bwd(gtok, self.velocity, self.g_pos.view(T, C), self.vel.gw.view(C), self.vel.gb, p_embd, ctx.rng_state,
+                       self.stream_base)
+        return gtok
+
     def _offload_side(self, ctx, pending):
         """A block's side work (fork point, launch closures).  The narrow transformers are launch-bound on BOTH streams - per block
         8 kernels on the chain and ~14 on the side stream, 5-8 us each - so there the closures alternate between two side streams."""
@@ -703,6 +808,8 @@ class GPT(object):
     def bwd(self, ctx, g_y):
         """g_y: [B,T,C] gradient of the GPT output.  Returns the token gradient (masked by the
         embedding dropout) to be spread back over the feature maps; writes all parameter grads."""
+        if GPT_FUSED == "1" and self.fused_now(ctx):
+            return self._bwd_fused(ctx, g_y)
         B = g_y.shape[0]
         T, C, nh, hs = self.T, self.C, self.nh, self.hs
         M = B * T

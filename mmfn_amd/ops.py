@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import (A_COLMAJOR, A_DGRAD, A_IM2COL, A_ROWMAJOR, B_DGRADW, B_IM2COL, B_KN, B_NK,
                    EPI_ACCUM, EPI_BF16_OPERANDS, EPI_BF16X3, EPI_BIAS, EPI_COLSUM_A, EPI_DROPOUT, EPI_GELU, EPI_LN_FOLD, EPI_MASK_AUX, EPI_RELU, EPI_RELU_LAST,
                    EPI_RESIDUAL,
-                   GemmDesc, check, lib, ptr, stream)
+                   GemmDesc, GptBlockDesc, check, lib, ptr, stream)
 
 BF16 = torch.bfloat16   # activations of the bf16 training mode: the wrappers below dispatch on the tensors' dtype
 _workspace = {}
@@ -1003,6 +1003,50 @@ def attention_bwd(q, k, v, ld, o, dO, ldo, lse, delta, dq, dk, dv, ldg, B, T, NH
                   rng_state=None, rng_stream=0):
     _call("mmfn_attention_bwd_bf16" if q.dtype == BF16 else "mmfn_attention_bwd_f32", ptr(q), ptr(k), ptr(v), ld, ptr(o), ptr(dO), ldo, ptr(lse), ptr(delta), ptr(dq),
           ptr(dk), ptr(dv), ldg, B, T, NH, HS, float(scale), ptr(kv_len), float(drop_p), ptr(rng_state), rng_stream, stream())
+
+
+# ---------------------------------------------------------------- fused GPT block (narrow fusion transformers)
+GPT_ROWS = 32   # token rows per workgroup of the row-block kernels = rows per LayerNorm partial row
+
+
+def gpt_block_supported(C, NH, T):
+    return lib().mmfn_gpt_block_supported(C, NH, T) == 0
+
+
+def gpt_block_desc(B, T, C, NH, eps=1e-5, attn_pdrop=0.0, resid_pdrop=0.0, rng_state=None, rng_stream=0, rng_stream_below=0,
+                   below_colsum=False, **tensors):
+    """mmfn_gpt_block_desc (include/mmfn_hip.h): tensors by field name (fp32, contiguous); missing fields stay NULL.  The returned
+    structure keeps its tensors alive."""
+    d = GptBlockDesc()
+    for name, t in tensors.items():
+        if name not in GptBlockDesc._PTRS:
+            raise KeyError(name)
+        if t is not None:
+            assert t.dtype == torch.float32 and t.is_contiguous(), name
+        setattr(d, name, ptr(t))
+    d.rng_state = ptr(rng_state)
+    d.B, d.T, d.C, d.NH = B, T, C, NH
+    d.attn_pdrop, d.resid_pdrop, d.eps = float(attn_pdrop), float(resid_pdrop), float(eps)
+    d.rng_stream, d.rng_stream_below, d.below_colsum = rng_stream, rng_stream_below, 1 if below_colsum else 0
+    d._keep = (tensors, rng_state)
+    return d
+
+
+def gpt_block_attn_fwd(d):
+    """ln1 -> key / query / value -> attention of one transformer block, one launch (model_vec.py:96-105,126)."""
+    _call("mmfn_gpt_block_attn_fwd_f32", ctypes.addressof(d), stream())
+
+
+def gpt_block_mlp_fwd(d):
+    """proj (+ residual) -> ln2 -> mlp.0 -> ReLU -> mlp.2 (+ residual) of one transformer block, one launch (model_vec.py:107-108,126-131)."""
+    _call("mmfn_gpt_block_mlp_fwd_f32", ctypes.addressof(d), stream())
+
+
+def gpt_block_bwd_rows(upper, lower):
+    """The row-local backward between two attention backward passes: upper block's qkv dgrad + ln1 backward, lower block's mlp /
+    ln2 / proj dgrads.  Either may be None."""
+    _call("mmfn_gpt_block_bwd_rows_f32", None if upper is None else ctypes.addressof(upper),
+          None if lower is None else ctypes.addressof(lower), stream())
 
 
 def lane0_attention_fwd(qkv, kv_len, B, L, heads, head_dim, scale, att0, prob):
