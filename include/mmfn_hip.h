@@ -418,6 +418,9 @@ typedef struct mmfn_gpt_block_desc {
 /* MMFN_EINVAL unless C in {64, 128}, NH == 4, T == 192 */
 int mmfn_gpt_block_supported(int C, int NH, int T);
 int mmfn_sizeof_gpt_block_desc(void);
+/* Development aid (builds with -DMMFN_GPT_STAMPS): 64 s_memtime stamps of workgroup 0 (waves 0 and 7) of the last row-block launch
+ * to HOST memory; MMFN_EINVAL when the instrumentation is off. */
+int mmfn_gpt_debug_read(int64_t* out64);
 int mmfn_gpt_block_attn_fwd_f32(const mmfn_gpt_block_desc* d, void* stream);
 int mmfn_gpt_block_mlp_fwd_f32(const mmfn_gpt_block_desc* d, void* stream);
 int mmfn_gpt_block_bwd_rows_f32(const mmfn_gpt_block_desc* upper, const mmfn_gpt_block_desc* lower, void* stream);

@@ -461,6 +461,10 @@ __global__ __launch_bounds__(NTHR) void gpt_attn_fwd_kernel(const GptArgs g) {
   if (!decode_block(NH, g.B, half, hd, b)) return;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const size_t rowbase = (size_t)b * T;
+  // the projection weights of this wave (waves 0-2: key, 3-5: value, 6-7: query) start travelling before the LayerNorm phase
+  const int sel = w < 3 ? 0 : (w < 6 ? 2 : 1);               // packed order: key | query | value
+  GptWRing<C, NHT, 4, false> ring;
+  ring.start(g.wqkv + (size_t)(sel * C + hd * HS) * C, C, l15, l4);
   // ---- x rows of the sample -> LDS
   {
     constexpr int Q = C / 4, UNITS = T * Q;
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(NTHR) void gpt_attn_fwd_kernel(const GptArgs g) {
       *reinterpret_cast<f32x4*>(sm + (u / Q) * PX + 4 * (u % Q)) = ld4(src + (size_t)(u / Q) * C + 4 * (u % Q));
     }
   }
-  __syncthreads();
+  gpt_barrier();
   // ---- a = ln1(x) in place: 4 rows per wave pass (16 lanes per row), 6 passes
   {
     f32x4 wv[NCHX], bv[NCHX];
@@ -507,10 +511,9 @@ __global__ __launch_bounds__(NTHR) void gpt_attn_fwd_kernel(const GptArgs g) {
       if (mine && hd == 0 && l15 == 0) { g.mu1[rowbase + t] = mu; g.rs1[rowbase + t] = rs; }
     }
   }
-  __syncthreads();
+  gpt_barrier();
   // ---- key / value (all T tokens) and query (this half) of head hd: [HS] x [token tile] accumulators, in registers until
   // every wave has finished reading a (their destination overlays it)
-  const int sel = w < 3 ? 0 : (w < 6 ? 2 : 1);               // packed order: key | query | value
   const int tile0 = w < 6 ? 4 * (w % 3) : (T / 32) * half + 3 * (w - 6);   // first 16-token tile of this wave
   f32x4 pacc[NHT][4];
 #pragma unroll
@@ -518,23 +521,22 @@ __global__ __launch_bounds__(NTHR) void gpt_attn_fwd_kernel(const GptArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) pacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
-    const float* W = g.wqkv + (size_t)(sel * C + hd * HS) * C;
     if (w < 6) {
-      gpt_rows_gemm_nt<C, NHT, 4, 4>(W, C, sm + 16 * tile0 * PX, l15, l4, pacc);
+      ring.template run<4>(sm + 16 * tile0 * PX, l15, l4, pacc);
     } else {
       f32x4 q3[NHT][3];
 #pragma unroll
       for (int i = 0; i < NHT; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) q3[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      gpt_rows_gemm_nt<C, NHT, 3, 4>(W, C, sm + 16 * tile0 * PX, l15, l4, q3);
+      ring.template run<3>(sm + 16 * tile0 * PX, l15, l4, q3);
 #pragma unroll
       for (int i = 0; i < NHT; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) pacc[i][j] = q3[i][j];
     }
   }
-  __syncthreads();   // a is no longer read
+  gpt_barrier();   // a is no longer read
   float* sK = sm;                    // [T][P]
   float* sQ = sm + T * P;            // [T/2][P]
   float* sV = sm + (T + T / 2) * P;  // [T][P]
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(NTHR) void gpt_attn_fwd_kernel(const GptArgs g) {
         }
     }
   }
-  __syncthreads();
+  gpt_barrier();
   // ---- attention (attn_wg_fwd_kernel without a key mask; K, Q, V are staged already)
   const int qg = w >> 2, ks = w & 3;
   const int q0 = half * 2 * G + qg * G;
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(NTHR) void gpt_attn_fwd_kernel(const GptArgs g) {
     t = quad_sum(t);
     if (l4 == 0) { sm_stat[0][qg][ks][16 * y + l15] = m; sm_stat[1][qg][ks][16 * y + l15] = t; }
   }
-  __syncthreads();
+  gpt_barrier();
   Drop dr;
   dr.init(g.attn_pdrop, g.rng_state, g.rng_stream, NH, b, hd);
   const bool drop = dr.on;
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(NTHR) void gpt_attn_fwd_kernel(const GptArgs g) {
 #pragma unroll
     for (int j = 0; j < NDT; ++j) o[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   second_phase<HS, NT>(s, sV + k0 * P, l15, l4, o);
-  __syncthreads();   // K, Q, V no longer read: the area becomes the merge parking space
+  gpt_barrier();   // K, Q, V no longer read: the area becomes the merge parking space
   merge_store<HS, NT, float>(o, sm, qg, ks, lane, l15, l4, g.o + (rowbase + q0) * C + hd * HS, C);
 }
 

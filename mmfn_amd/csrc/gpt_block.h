@@ -10,81 +10,68 @@ __device__ __forceinline__ f32x4 gpt_ld4(const float* p) { return *reinterpret_c
 __device__ __forceinline__ void gpt_st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ f32x4 gpt_mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// acc[i][j] += W[16 i + .][:] . A[16 j + .][:]^T over K columns ("NT": both operands contract along their rows' columns).
-//   W: global (L2-resident weights), row pitch ldw floats, pointing at the first of this wave's NWT 16-row tiles;
-//   sA: LDS activations, row pitch K + 4 floats, pointing at the first of this wave's NTT 16-row tiles.
-// MFMA roles: A operand = weight rows (accumulator rows 4*l4 + r = output column n), B operand = activation rows (accumulator
-// column l15 = token), so a lane ends up with 4 consecutive output columns of one token: 16-byte stores to LDS / HBM.
-// Lane (l15, l4) reads the float4 at columns 16c + 4*l4 of its row: element e feeds MFMA step e, whose four k slots are the
-// columns {16c + 4*slot + e} - the same permutation of the chunk on both operands (attention_wg.hip product_phase).
-// The weight fragments run D chunks ahead of the MFMAs in a register ring (L2 latency ~ 1-2 chunks of MFMA time).
-template <int K, int NWT, int NTT, int D>
-__device__ __forceinline__ void gpt_rows_gemm_nt(const float* __restrict__ W, int ldw, const float* sA, int l15, int l4,
-                                                 f32x4 (*acc)[NTT]) {
-  constexpr int NCH = K / 16, P = K + 4;
-  f32x4 wf[D][NWT];
-  const float* wp = W + (size_t)l15 * ldw + 4 * l4;
-#pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (d < NCH) {
-#pragma unroll
-      for (int i = 0; i < NWT; ++i) wf[d][i] = gpt_ld4(wp + (size_t)(16 * i) * ldw + 16 * d);
-    }
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    f32x4 af[NTT], wv[NWT];
-#pragma unroll
-    for (int j = 0; j < NTT; ++j) af[j] = *reinterpret_cast<const f32x4*>(sA + (16 * j + l15) * P + 16 * c + 4 * l4);
-#pragma unroll
-    for (int i = 0; i < NWT; ++i) wv[i] = wf[c % D][i];
-    if (c + D < NCH) {
-#pragma unroll
-      for (int i = 0; i < NWT; ++i) wf[c % D][i] = gpt_ld4(wp + (size_t)(16 * i) * ldw + 16 * (c + D));
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int i = 0; i < NWT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTT; ++j) acc[i][j] = gpt_mfma16(wv[i][e], af[j][e], acc[i][j]);
-  }
-}
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() is a workgroup-scope release fence + s_barrier, and
+// the fence drains the wave's global STORES too (s_waitcnt vmcnt(0)): every phase of the fused kernels ends in an epilogue that
+// stores a saved tensor (x1, a2, h, gh, ...), and waiting for those stores to be acknowledged cost 2-4 us per phase (s_memtime
+// stamps, tools/experiments/gpt_phases.sh: 13 of the 31 us of gpt_mlp_fwd_kernel<128>).  Nothing behind these barriers reads what
+// the workgroup stored to HBM; loads feeding an LDS write are ordered by their data dependency.
+__device__ __forceinline__ void gpt_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// acc[i][j] += sum_n W[n][16 i + .] * A[16 j + .][n] over N rows of W ("NN": the data gradient dx = g . W, W [N][Kout]).
-//   W: global, row pitch ldw, pointing at column 16 * (first tile) of row 0;  sA: LDS [rows][N + 4] gradient rows.
-// The weight fragment of a lane is column 16 i + l15 of rows {16c + 4*l4 + e}: four 4-byte loads, 64 contiguous bytes per
-// 16 lanes.
-template <int N, int NWT, int NTT, int D>
-__device__ __forceinline__ void gpt_rows_gemm_nn(const float* __restrict__ W, int ldw, const float* sA, int l15, int l4,
-                                                 f32x4 (*acc)[NTT]) {
-  constexpr int NCH = N / 16, P = N + 4;
+// Weight fragments of a row-block product, D chunks (of 16 contraction indices) ahead of the MFMAs in a register ring.  start()
+// is called BEFORE the barrier / epilogue / LayerNorm phase that precedes the product, so the first chunks' L2 latency (1-2 us on
+// a cold matrix) is not exposed at every phase boundary of the fused kernels.
+//   NN = false ("NT"): out[t][n] = sum_k A[t][k] W[n][k]  (forward Linear; W [N][K], row pitch ldw, this wave's first row)
+//        lane (l15, l4) reads the float4 at columns 16c + 4*l4 of weight row 16 i + l15: element e feeds MFMA step e, whose four
+//        k slots are the columns {16c + 4*slot + e} - the same permutation of the chunk on both operands (attention_wg.hip).
+//   NN = true:        out[t][k] = sum_n A[t][n] W[n][k]  (data gradient dx = g . W; W [N][Kout], this wave's first COLUMN)
+//        the lane's fragment is column 16 i + l15 of rows {16c + 4*l4 + e}: four 4-byte loads, 64 contiguous bytes per 16 lanes.
+// MFMA roles: A operand = weights (accumulator rows 4*l4 + r = output column), B operand = activation rows from LDS (accumulator
+// column l15 = token), so a lane ends up with 4 consecutive output columns of one token: 16-byte stores to LDS / HBM.
+template <int K, int NWT, int D, bool NN>
+struct GptWRing {
+  static constexpr int NCH = K / 16;
   f32x4 wf[D][NWT];
-  const float* wp = W + (size_t)(4 * l4) * ldw + l15;
-  auto fetch = [&](int c, f32x4* dst) {
+  const float* wp;
+  int ldw;
+  __device__ __forceinline__ void fetch(int c, f32x4* dst) const {
 #pragma unroll
-    for (int i = 0; i < NWT; ++i)
+    for (int i = 0; i < NWT; ++i) {
+      if (NN) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dst[i][e] = wp[(size_t)(16 * c + e) * ldw + 16 * i];
-  };
-#pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (d < NCH) fetch(d, wf[d]);
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    f32x4 af[NTT], wv[NWT];
-#pragma unroll
-    for (int j = 0; j < NTT; ++j) af[j] = *reinterpret_cast<const f32x4*>(sA + (16 * j + l15) * P + 16 * c + 4 * l4);
-#pragma unroll
-    for (int i = 0; i < NWT; ++i) wv[i] = wf[c % D][i];
-    if (c + D < NCH) fetch(c + D, wf[c % D]);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int i = 0; i < NWT; ++i)
-#pragma unroll
-        for (int j = 0; j < NTT; ++j) acc[i][j] = gpt_mfma16(wv[i][e], af[j][e], acc[i][j]);
+        for (int e = 0; e < 4; ++e) dst[i][e] = wp[(size_t)(16 * c + e) * ldw + 16 * i];
+      } else {
+        dst[i] = gpt_ld4(wp + (size_t)(16 * i) * ldw + 16 * c);
+      }
+    }
   }
-}
+  __device__ __forceinline__ void start(const float* __restrict__ W, int ldw_, int l15, int l4) {
+    ldw = ldw_;
+    wp = NN ? W + (size_t)(4 * l4) * ldw + l15 : W + (size_t)l15 * ldw + 4 * l4;
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < NCH) fetch(d, wf[d]);
+  }
+  // acc[i][j] += (weight tile i) x (activation tile j); sA: LDS rows of this wave's first 16-row tile, row pitch K + 4 floats
+  template <int NTT>
+  __device__ __forceinline__ void run(const float* sA, int l15, int l4, f32x4 (*acc)[NTT]) {
+    constexpr int P = K + 4;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      f32x4 af[NTT], wv[NWT];
+#pragma unroll
+      for (int j = 0; j < NTT; ++j) af[j] = *reinterpret_cast<const f32x4*>(sA + (16 * j + l15) * P + 16 * c + 4 * l4);
+#pragma unroll
+      for (int i = 0; i < NWT; ++i) wv[i] = wf[c % D][i];
+      if (c + D < NCH) fetch(c + D, wf[c % D]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < NWT; ++i)
+#pragma unroll
+          for (int j = 0; j < NTT; ++j) acc[i][j] = gpt_mfma16(wv[i][e], af[j][e], acc[i][j]);
+    }
+  }
+};
 
 // sum over the 16 lanes that share l4 (lanes l15 = 0..15 of a row group)
 __device__ __forceinline__ float gpt_row16_sum(float v) {

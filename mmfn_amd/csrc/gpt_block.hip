@@ -20,6 +20,17 @@ namespace {
 constexpr int NTHR = 512;
 constexpr int R = 32;   // token rows per workgroup
 
+#ifdef MMFN_GPT_STAMPS   // experiment builds (tools/experiments/gpt_phases.sh): s_memtime at the phase boundaries, workgroup 0, waves 0 / 7
+__device__ long long g_gpt_dbg[64];
+#define GPT_STAMP(i)                                                                                       \
+  do {                                                                                                     \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 7)) \
+      g_gpt_dbg[((threadIdx.x >> 6) ? 32 : 0) + (i)] = (long long)__builtin_amdgcn_s_memtime();           \
+  } while (0)
+#else
+#define GPT_STAMP(i) do { } while (0)
+#endif
+
 // Which output tiles a wave owns in a [R = 32 rows] x [N columns] product: N / 16 >= 8 column tiles -> NWT = N / 128 adjacent
 // column tiles x both row tiles; 4 column tiles (N = 64) -> one column tile x one row tile.
 template <int N>
@@ -80,31 +91,49 @@ __global__ __launch_bounds__(NTHR) void gpt_mlp_fwd_kernel(const GptArgs a) {
   __shared__ __attribute__((aligned(16))) float sH[R * PH];    // hidden activations
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const size_t row0 = (size_t)blockIdx.x * R;
+  using OC = Own<C>;
+  using OH = Own<H>;
+  const int nt0 = OC::nt0(w), tt0 = OC::tt0(w), hn0 = OH::nt0(w), ht0 = OH::tt0(w);
+  GPT_STAMP(0);
+  GptWRing<C, OC::NWT, 4, false> rproj;
+  rproj.start(a.wproj + (size_t)(16 * nt0) * C, C, l15, l4);
   stage_rows<C>(a.o + row0 * C, C, sO, tid);
-  __syncthreads();
+  gpt_barrier();
+  GPT_STAMP(1);
   // ---- x1 = x + drop(o . Wproj^T + b)
+  GptWRing<C, OH::NWT, (OH::NWT >= 4 ? 2 : 4), false> rfc1;
   {
-    using O = Own<C>;
-    f32x4 acc[O::NWT][O::NTT];
-    zero<O::NWT, O::NTT>(acc);
-    const int nt0 = O::nt0(w), tt0 = O::tt0(w);
-    gpt_rows_gemm_nt<C, O::NWT, O::NTT, 4>(a.wproj + (size_t)(16 * nt0) * C, C, sO + 16 * tt0 * PC, l15, l4, acc);
+    // (epilogue operands are requested before the product: their latency would otherwise be exposed after the last MFMA)
+    f32x4 bias[OC::NWT], xres[OC::NWT][OC::NTT];
+#pragma unroll
+    for (int i = 0; i < OC::NWT; ++i) {
+      bias[i] = gpt_ld4(a.bproj + 16 * (nt0 + i) + 4 * l4);
+#pragma unroll
+      for (int j = 0; j < OC::NTT; ++j) xres[i][j] = gpt_ld4(a.x + (row0 + 16 * (tt0 + j) + l15) * C + 16 * (nt0 + i) + 4 * l4);
+    }
+    f32x4 acc[OC::NWT][OC::NTT];
+    zero<OC::NWT, OC::NTT>(acc);
+    rproj.template run<OC::NTT>(sO + 16 * tt0 * PC, l15, l4, acc);
+    GPT_STAMP(2);
+    rfc1.start(a.w1 + (size_t)(16 * hn0) * C, C, l15, l4);   // mlp.0's first chunks travel under the epilogue and the LayerNorm
     DropKey dk;
     dk.init(a.rng_state, a.rng_stream + 1, a.resid_pdrop);
 #pragma unroll
-    for (int i = 0; i < O::NWT; ++i)
+    for (int i = 0; i < OC::NWT; ++i)
 #pragma unroll
-      for (int j = 0; j < O::NTT; ++j) {
+      for (int j = 0; j < OC::NTT; ++j) {
         const int n = 16 * (nt0 + i) + 4 * l4, t = 16 * (tt0 + j) + l15;
         const size_t off = (row0 + t) * C + n;
-        f32x4 v = acc[i][j] + gpt_ld4(a.bproj + n);
+        f32x4 v = acc[i][j] + bias[i];
         v = dk.apply(v, off);
-        v += gpt_ld4(a.x + off);
+        v += xres[i][j];
         gpt_st4(a.x1 + off, v);
         *reinterpret_cast<f32x4*>(sX1 + t * PC + n) = v;
       }
   }
-  __syncthreads();
+  GPT_STAMP(3);
+  gpt_barrier();
+  GPT_STAMP(4);
   // ---- a2 = ln2(x1): wave w takes rows 4w .. 4w+3, 16 lanes per row
   {
     const int t = 4 * w + l4;
@@ -134,48 +163,59 @@ __global__ __launch_bounds__(NTHR) void gpt_mlp_fwd_kernel(const GptArgs a) {
     }
     if (l15 == 0) { a.mu2[row0 + t] = mu; a.rs2[row0 + t] = rs; }
   }
-  __syncthreads();
+  GPT_STAMP(5);
+  gpt_barrier();
+  GPT_STAMP(6);
   // ---- h = relu(a2 . W1^T + b1)
+  GptWRing<H, OC::NWT, 6, false> rfc2;
   {
-    using O = Own<H>;
-    f32x4 acc[O::NWT][O::NTT];
-    zero<O::NWT, O::NTT>(acc);
-    const int nt0 = O::nt0(w), tt0 = O::tt0(w);
-    gpt_rows_gemm_nt<C, O::NWT, O::NTT, (O::NWT >= 4 ? 2 : 4)>(a.w1 + (size_t)(16 * nt0) * C, C, sO + 16 * tt0 * PC, l15, l4, acc);
+    f32x4 bias[OH::NWT];
 #pragma unroll
-    for (int i = 0; i < O::NWT; ++i)
+    for (int i = 0; i < OH::NWT; ++i) bias[i] = gpt_ld4(a.b1 + 16 * (hn0 + i) + 4 * l4);
+    f32x4 acc[OH::NWT][OH::NTT];
+    zero<OH::NWT, OH::NTT>(acc);
+    rfc1.template run<OH::NTT>(sO + 16 * ht0 * PC, l15, l4, acc);
+    GPT_STAMP(7);
+    rfc2.start(a.w2 + (size_t)(16 * nt0) * H, H, l15, l4);
 #pragma unroll
-      for (int j = 0; j < O::NTT; ++j) {
-        const int n = 16 * (nt0 + i) + 4 * l4, t = 16 * (tt0 + j) + l15;
-        f32x4 v = acc[i][j] + gpt_ld4(a.b1 + n);
+    for (int i = 0; i < OH::NWT; ++i)
+#pragma unroll
+      for (int j = 0; j < OH::NTT; ++j) {
+        const int n = 16 * (hn0 + i) + 4 * l4, t = 16 * (ht0 + j) + l15;
+        f32x4 v = acc[i][j] + bias[i];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         gpt_st4(a.h + (row0 + t) * H + n, v);
         *reinterpret_cast<f32x4*>(sH + t * PH + n) = v;
       }
   }
-  __syncthreads();
+  GPT_STAMP(8);
+  gpt_barrier();
+  GPT_STAMP(9);
   // ---- x2 = x1 + drop(h . W2^T + b2)
   {
-    using O = Own<C>;
-    f32x4 acc[O::NWT][O::NTT];
-    zero<O::NWT, O::NTT>(acc);
-    const int nt0 = O::nt0(w), tt0 = O::tt0(w);
-    gpt_rows_gemm_nt<H, O::NWT, O::NTT, 6>(a.w2 + (size_t)(16 * nt0) * H, H, sH + 16 * tt0 * PH, l15, l4, acc);
+    f32x4 bias[OC::NWT];
+#pragma unroll
+    for (int i = 0; i < OC::NWT; ++i) bias[i] = gpt_ld4(a.b2 + 16 * (nt0 + i) + 4 * l4);
+    f32x4 acc[OC::NWT][OC::NTT];
+    zero<OC::NWT, OC::NTT>(acc);
+    rfc2.template run<OC::NTT>(sH + 16 * tt0 * PH, l15, l4, acc);
+    GPT_STAMP(10);
     DropKey dk;
     dk.init(a.rng_state, a.rng_stream + 2, a.resid_pdrop);
 #pragma unroll
-    for (int i = 0; i < O::NWT; ++i)
+    for (int i = 0; i < OC::NWT; ++i)
 #pragma unroll
-      for (int j = 0; j < O::NTT; ++j) {
+      for (int j = 0; j < OC::NTT; ++j) {
         const int n = 16 * (nt0 + i) + 4 * l4, t = 16 * (tt0 + j) + l15;
         const size_t off = (row0 + t) * C + n;
-        f32x4 v = acc[i][j] + gpt_ld4(a.b2 + n);
+        f32x4 v = acc[i][j] + bias[i];
         v = dk.apply(v, off);
         v += *reinterpret_cast<const f32x4*>(sX1 + t * PC + n);
         gpt_st4(a.x2 + off, v);
       }
   }
+  GPT_STAMP(11);
 }
 
 // --------------------------------------------------------------------------------------------------------- backward
@@ -238,7 +278,7 @@ __device__ __forceinline__ void ln_bwd_rows(const float* sGy, const float* __res
         red[(2 * 8 + w) * C + n] = v2;
       }
     }
-  __syncthreads();
+  gpt_barrier();
   for (int c = tid; c < part_rows * C; c += NTHR) {
     const int which = c / C, n = c % C;
     float s = 0.f;
@@ -260,22 +300,27 @@ __global__ __launch_bounds__(NTHR) void gpt_bwd_rows_kernel(const GptArgs up, co
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const size_t row0 = (size_t)blockIdx.x * R;
   using OC = Own<C>;
-  const int nt0 = OC::nt0(w), tt0 = OC::tt0(w);
+  using OH = Own<H>;
+  const int nt0 = OC::nt0(w), tt0 = OC::tt0(w), hn0 = OH::nt0(w), ht0 = OH::tt0(w);
+  GptWRing<C, OH::NWT, (OH::NWT >= 4 ? 5 : 4), true> rw2;   // (started before the phase that precedes its product, see gpt_block.h)
   if (has_up) {
     // ---- ga = dqkv . Wqkv  (contraction over the 3C outputs of the packed projection)
+    GptWRing<3 * C, OC::NWT, 10, true> rqkv;
+    rqkv.start(up.wqkv + 16 * nt0, C, l15, l4);
     stage_rows<3 * C>(up.dqkv + row0 * 3 * C, 3 * C, sBig, tid);
-    __syncthreads();
+    gpt_barrier();
     {
       f32x4 acc[OC::NWT][OC::NTT];
       zero<OC::NWT, OC::NTT>(acc);
-      gpt_rows_gemm_nn<3 * C, OC::NWT, OC::NTT, 3>(up.wqkv + 16 * nt0, C, sBig + 16 * tt0 * PQ, l15, l4, acc);
+      rqkv.template run<OC::NTT>(sBig + 16 * tt0 * PQ, l15, l4, acc);
+      if (has_lo) rw2.start(lo.w2 + 16 * hn0, H, l15, l4);
 #pragma unroll
       for (int i = 0; i < OC::NWT; ++i)
 #pragma unroll
         for (int j = 0; j < OC::NTT; ++j)
           *reinterpret_cast<f32x4*>(sGy + (16 * (tt0 + j) + l15) * PC + 16 * (nt0 + i) + 4 * l4) = acc[i][j];
     }
-    __syncthreads();
+    gpt_barrier();
     // ---- g = ln1 backward(ga) + g1;  gd = g under the mask of the block below
     DropKey dk;
     dk.init(up.rng_state, up.rng_stream_below + 2, up.gd_below ? up.resid_pdrop : 0.f);
@@ -295,23 +340,25 @@ __global__ __launch_bounds__(NTHR) void gpt_bwd_rows_kernel(const GptArgs up, co
           return od;
         });
     if (!has_lo) return;
-    __syncthreads();
+    gpt_barrier();
   } else {
+    rw2.start(lo.w2 + 16 * hn0, H, l15, l4);
     stage_rows<C>(lo.g + row0 * C, C, sG, tid);
     stage_rows<C>((lo.gd ? lo.gd : lo.g) + row0 * C, C, sGd, tid);
-    __syncthreads();
+    gpt_barrier();
   }
   // ---- gh = (gd . W2) masked by h > 0   (W2 [C][4C]: contraction over its rows)
+  GptWRing<H, OC::NWT, 12, true> rw1;
   {
-    using O = Own<H>;
-    f32x4 acc[O::NWT][O::NTT];
-    zero<O::NWT, O::NTT>(acc);
-    const int n0 = O::nt0(w), t0 = O::tt0(w);
-    gpt_rows_gemm_nn<C, O::NWT, O::NTT, 2>(lo.w2 + 16 * n0, H, sGd + 16 * t0 * PC, l15, l4, acc);
+    f32x4 acc[OH::NWT][OH::NTT];
+    zero<OH::NWT, OH::NTT>(acc);
+    const int n0 = hn0, t0 = ht0;
+    rw2.template run<OH::NTT>(sGd + 16 * t0 * PC, l15, l4, acc);
+    rw1.start(lo.w1 + 16 * nt0, C, l15, l4);
 #pragma unroll
-    for (int i = 0; i < O::NWT; ++i)
+    for (int i = 0; i < OH::NWT; ++i)
 #pragma unroll
-      for (int j = 0; j < O::NTT; ++j) {
+      for (int j = 0; j < OH::NTT; ++j) {
         const int n = 16 * (n0 + i) + 4 * l4, t = 16 * (t0 + j) + l15;
         const f32x4 hv = gpt_ld4(lo.h + (row0 + t) * H + n);
         f32x4 v = acc[i][j];
@@ -321,19 +368,21 @@ __global__ __launch_bounds__(NTHR) void gpt_bwd_rows_kernel(const GptArgs up, co
         *reinterpret_cast<f32x4*>(sBig + t * PH + n) = v;
       }
   }
-  __syncthreads();
+  gpt_barrier();
   // ---- ga2 = gh . W1  (W1 [4C][C])
+  GptWRing<C, OC::NWT, 8, true> rproj;
   {
     f32x4 acc[OC::NWT][OC::NTT];
     zero<OC::NWT, OC::NTT>(acc);
-    gpt_rows_gemm_nn<H, OC::NWT, OC::NTT, 3>(lo.w1 + 16 * nt0, C, sBig + 16 * tt0 * PH, l15, l4, acc);
+    rw1.template run<OC::NTT>(sBig + 16 * tt0 * PH, l15, l4, acc);
+    rproj.start(lo.wproj + 16 * nt0, C, l15, l4);
 #pragma unroll
     for (int i = 0; i < OC::NWT; ++i)
 #pragma unroll
       for (int j = 0; j < OC::NTT; ++j)
         *reinterpret_cast<f32x4*>(sGy + (16 * (tt0 + j) + l15) * PC + 16 * (nt0 + i) + 4 * l4) = acc[i][j];
   }
-  __syncthreads();
+  gpt_barrier();
   // ---- g1 = ln2 backward(ga2) + g;  gd2 = g1 under proj's mask
   {
     DropKey dk;
@@ -353,12 +402,12 @@ __global__ __launch_bounds__(NTHR) void gpt_bwd_rows_kernel(const GptArgs up, co
           return od;
         });
   }
-  __syncthreads();
+  gpt_barrier();
   // ---- go = gd2 . Wproj
   {
     f32x4 acc[OC::NWT][OC::NTT];
     zero<OC::NWT, OC::NTT>(acc);
-    gpt_rows_gemm_nn<C, OC::NWT, OC::NTT, 4>(lo.wproj + 16 * nt0, C, sGd + 16 * tt0 * PC, l15, l4, acc);
+    rproj.template run<OC::NTT>(sGd + 16 * tt0 * PC, l15, l4, acc);
 #pragma unroll
     for (int i = 0; i < OC::NWT; ++i)
 #pragma unroll
@@ -372,6 +421,17 @@ bool shape_ok(const GptArgs& d) {
 }
 
 }  // namespace
+
+extern "C" int mmfn_gpt_debug_read(int64_t* out64) {   // dev only: copies the 64 stamps to host memory
+#ifdef MMFN_GPT_STAMPS
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_gpt_dbg)) != hipSuccess) return MMFN_EINVAL;
+  return (int)hipMemcpy(out64, p, 64 * sizeof(long long), hipMemcpyDeviceToHost);
+#else
+  (void)out64;
+  return MMFN_EINVAL;
+#endif
+}
 
 extern "C" int mmfn_sizeof_gpt_block_desc(void) { return (int)sizeof(mmfn_gpt_block_desc); }
 
