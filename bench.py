@@ -106,6 +106,43 @@ class ImageBranchOnly(object):
         return pooled
 
 
+
+def attention_roofline(eng, B, dev, iters=20):
+    """The fusion-attention kernels of the widest transformer (head size n_embd / n_head = 128, T tokens) timed alone on the stream the
+    step launches them on, ONE normalisation: the FLOPs their MFMAs execute (forward 2 products, backward 3 + 4 incl. the recomputed
+    S and dP) / kernel time (HIP events around `iters` back-to-back launches) / the nominal fp32 MFMA peak."""
+    import math
+    gpt = eng.gpts[-1]
+    T, C, NH = gpt.T, gpt.C, gpt.nh
+    HS = C // NH
+    qkv = torch.randn(B * T, 3 * C, device=dev)
+    dO = torch.randn(B * T, C, device=dev)
+    o, dqkv = torch.empty(B * T, C, device=dev), torch.empty(B * T, 3 * C, device=dev)
+    lse, delta = torch.empty(B, NH, T, device=dev), torch.empty(B, NH, T, device=dev)
+    rng = torch.tensor([5, 1], dtype=torch.int64, device=dev)
+    p, sc = float(eng.cfg.attn_pdrop), 1.0 / math.sqrt(HS)
+    fwd = lambda: ops.attention_fwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, C, lse, B, T, NH, HS, sc, drop_p=p, rng_state=rng, rng_stream=3)
+    bwd = lambda: ops.attention_bwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, dO, C, lse, delta, dqkv[:, C:], dqkv, dqkv[:, 2 * C:], 3 * C,
+                                    B, T, NH, HS, sc, drop_p=p, rng_state=rng, rng_stream=3)
+    out = {"head_size": HS, "tokens": T, "heads": NH, "batch": B, "dropout": p, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "normalisation": "executed MFMA FLOPs / kernel time (HIP events over %d back-to-back launches) / nominal fp32 MFMA peak" % iters}
+    unit = 2.0 * T * T * C * B   # one T x T x head-size product over all heads and samples
+    for name, fn, products in (("fwd", fwd, 2), ("bwd", bwd, 7)):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        e1.synchronize()
+        us = e0.elapsed_time(e1) / iters * 1e3
+        tf = products * unit / (us * 1e-6) / 1e12
+        out[name] = {"us": round(us, 1), "achieved": round(tf, 1), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 3),
+                     "kernels": "attn_wg_fwd" if name == "fwd" else "attn_wg_dq + attn_wg_dkv"}
+    return out
+
+
 def also_config(args, name):
     """Another BASELINE configuration measured by the SAME driver run: a second bench process started after the fp32 line's
     timed region (this process keeps its buffers; 288 GB holds both), same steps / warm-up.  `name` is a PRESETS key: "bf16"
@@ -341,6 +378,7 @@ def main():
     ap.add_argument("--single-stream", action="store_true", help="disable encoder-branch concurrency (profiling runs)")
     ap.add_argument("--profile-steps", type=int, default=2, help="instrumented steps for the roofline block")
     ap.add_argument("--breakdown", action="store_true", help="print the per-operation table of the roofline block's instrumented steps to stderr")
+    ap.add_argument("--no-attention-roofline", action="store_true", help="skip roofline.attention (the widest transformer's attention kernels timed alone)")
     ap.add_argument("--no-also", action="store_true",
                     help="default one-GPU run only: do not append the other BASELINE configurations' records (`also.bf16`, `also.img128`, "
                          "`also.rad16`: further bench processes after the fp32 line's timed region)")
@@ -631,17 +669,21 @@ def main():
                           "time of the launches that implement them; the Winograd F(4x4,3x3) path executes 4x fewer on the MFMA units "
                           "(executed_gflop_per_step, executed_tflops), so a convolution-only workload can exceed 1.0 here",
         }
-        if image_only and args.dtype == "f32":
-            # the convolution-only workload (BASELINE configs[3], "conv MFMA roofline run"): every FLOP of it is a 3x3 / 7x7 / 1x1
-            # convolution and three quarters of the 3x3 MACs are never executed (Winograd), so the algorithmic fraction exceeds 1
-            # and says nothing about the matrix pipe - the line leads with what the MFMA units really execute
+        if args.dtype == "f32":
+            # ONE meaning of achieved / frac on every fp32 line (vec32, img128, rad16): the FLOPs the MFMA units EXECUTE over the time
+            # of the launches that implement the family (Winograd F(4x4,3x3) executes 1/4 of a 3x3 convolution's MACs; its transform
+            # kernels are inside the timed span) - the quantity the MFMA-busy counters track and the conservative one.  SURVEY 8d's
+            # ALGORITHMIC count (output pixels x taps x Cin x Cout) stays beside it as achieved_algorithmic / frac_algorithmic; on a
+            # convolution-only workload (configs[3]) it exceeds 1.0.
             r = result["roofline"]
             r["frac_algorithmic"], r["achieved_algorithmic"] = r["frac"], r["achieved"]
             r["achieved"] = r["executed_tflops"]
-            r["frac"] = round(r["executed_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)
-            r["accounting"] = ("achieved / frac = FLOPs the MFMA units EXECUTE (Winograd F(4x4,3x3) executes 1/4 of a 3x3 convolution's MACs) over the "
-                               "time of the launches incl. the transform kernels; achieved_algorithmic / frac_algorithmic count SURVEY 8d's "
-                               "algorithmic FLOPs and exceed 1.0 on this convolution-only workload")
+            r["frac"] = r["frac_executed"]
+            r["accounting"] = ("achieved / frac = FLOPs the MFMA units EXECUTE (executed_gflop_per_step) over the time of the family's launches "
+                               "incl. the Winograd transform kernels, against the nominal fp32 MFMA peak; achieved_algorithmic / "
+                               "frac_algorithmic count SURVEY 8d's algorithmic FLOPs (a 3x3 convolution as a direct convolution) over the same time")
+            if not image_only and not args.no_attention_roofline:
+                r["attention"] = attention_roofline(eng, B, dev)
         if args.dtype != "f32":
             # bf16 mode: the dominant kernel is the bf16-operand GEMM; price ITS launches against the dense bf16 MFMA peak.
             # What stays on the fp32 instruction (conv weight gradients in the Winograd domain, 7x7 stems, stride-2 data
@@ -693,7 +735,22 @@ def main():
             result["cpu_baseline"] = cpu_baseline()
         if world == 1 and default_workload and not args.no_also and args.config is None:
             # BASELINE configs[2] (per-GPU arithmetic), configs[3], configs[4]: driver-timed beside the headline
-            result["also"] = {name: also_config(args, name) for name in ("bf16", "img128", "rad16")}
+            also = {name: also_config(args, name) for name in ("bf16", "img128", "rad16")}
+            # the other configurations' throughputs as top-level scalars ahead of the long blocks AND in a short last object: a
+            # truncated copy of this line (head or tail) still carries them
+            scal = {"also_" + k: (v or {}).get("value") for k, v in also.items()}
+            head = {}
+            for k, v in result.items():
+                head[k] = v
+                if k == "ms_per_step":
+                    head.update(scal)
+            result = head
+            result["also"] = also
+            result["tail"] = dict(value=result["value"], unit="samples/s", ms_per_step=result["ms_per_step"],
+                                  roofline_frac=result.get("roofline", {}).get("frac"),
+                                  roofline_frac_algorithmic=result.get("roofline", {}).get("frac_algorithmic"),
+                                  attention_fwd_frac=result.get("roofline", {}).get("attention", {}).get("fwd", {}).get("frac"),
+                                  attention_bwd_frac=result.get("roofline", {}).get("attention", {}).get("bwd", {}).get("frac"), **scal)
         print(json.dumps(result))
     if dist is not None:
         dist.barrier()

@@ -100,6 +100,14 @@ class RcclComm(object):
         """Register an object that owns hipGraphs with captured collectives of this communicator (graphs.Recorder; weakly held)."""
         self._holders.add(holder)
 
+    def destroy_unused(self):
+        """Destroy a communicator NOTHING was ever captured or launched on (an init that came up after its time limit,
+        open_transport): only the C-ABI call - no garbage collection and no drain of retired hipGraphs, which belong to the main
+        thread (it may be capturing or training on torch.distributed by now; this runs on the abandoned helper thread)."""
+        if self._comm:
+            lib().mmfn_comm_destroy(self._comm)
+            self._comm = ctypes.c_void_p()
+
     def destroy(self):
         """Destroy the communicator.  A hipGraph that captured its collectives must be gone first: RCCL hooks the graph's
         destruction and reaches into the communicator from there - freeing the communicator under a live (or merely retired,
@@ -173,6 +181,10 @@ def open_transport(rank, world, dist, dev, required=False, timeout_s=120.0, make
     import threading
     make_id = make_id or _local_rendezvous_id
     make_comm = make_comm or _real_communicator
+    # under the nccl backend broadcast_object_list / all_reduce stage through torch.cuda.current_device(): a caller that never set
+    # its device (trainer.fit -> connect) would have every rank use cuda:0 ("Duplicate GPU detected" or a hang)
+    if getattr(dev, "type", None) == "cuda" and torch.cuda.is_available():
+        torch.cuda.set_device(dev)
 
     def give_up(why):
         if required:
@@ -213,7 +225,7 @@ def open_transport(rank, world, dist, dev, required=False, timeout_s=120.0, make
                 box["comm"], late = c, None
         if late is not None:
             try:
-                late.destroy()
+                getattr(late, "destroy_unused", late.destroy)()   # (never used: no captured graph can refer to it)
             except BaseException:   # noqa: BLE001
                 pass
 

@@ -84,7 +84,11 @@ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Counter-based RNG: one 32-bit draw per (seed, step, stream, index); the backward pass regenerates the same mask instead of
-// storing it.  The draw is a 32-bit mixer (lowbias32: two 32-bit multiplies) of the index, salted with a hash of the 64-bit
+// storing it.  Strength: a dropout mask, not a general-purpose generator - the (seed, step, stream) key reaches a draw only through
+// a 32-bit XOR salt, so two streams / steps whose salts agree in the bits above log2(numel) get masks that are XOR-index
+// permutations of each other with equal keep counts (probability ~ numel / 2^32 per pair: ~1/256 for a 16 M-element tensor, i.e. it
+// happens over a long run).  Statistically harmless for dropout (each mask is still Bernoulli(p) per element); the masks of different
+// streams are NOT independent in the cryptographic sense and the tests only claim the Bernoulli rate and pairwise decorrelation.  The draw is a 32-bit mixer (lowbias32: two 32-bit multiplies) of the index, salted with a hash of the 64-bit
 // (seed, step, stream) key - the salt is uniform over a launch, so it costs scalar instructions once.  Rounds 1-4 ran the 64-bit
 // splitmix finaliser per element (three 64-bit multiplies = a dozen quarter-rate v_mul_lo/hi_u32 + ~15 more instructions): with
 // 36-96 elements per lane that was 9-10 k cycles of every attention kernel and the longest part of a dropout epilogue.

@@ -765,7 +765,7 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
 #pragma unroll
           for (int j = 0; j < 4; ++j) { ln_p1[i] += a[i][j]; ln_p2[i] = fmaf(a[i][j], a[i][j], ln_p2[i]); }
         }
-        if (AM == MMFN_A_COLMAJOR) cs_p[i] += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);
+        if (AM == MMFN_A_COLMAJOR && BMODE == MMFN_B_KN) cs_p[i] += (a[i][0] + a[i][1]) + (a[i][2] + a[i][3]);   // (not in the conv weight-gradient forms)
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
@@ -790,7 +790,7 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
 #pragma unroll
       for (int i = 0; i < TM; ++i) { ln_s1[i] += (double)ln_p1[i]; ln_s2[i] += (double)ln_p2[i]; }
     }
-    if (AM == MMFN_A_COLMAJOR) {
+    if (AM == MMFN_A_COLMAJOR && BMODE == MMFN_B_KN) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) csa[i] += (double)cs_p[i];
     }
@@ -827,7 +827,7 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
   if (d.flags & MMFN_EPI_DROPOUT) key = mmfn_rng_key(d.rng_state, d.rng_stream);
   const bool to_slab = d.splitk > 1;
   float* slab = to_slab ? d.workspace + ((size_t)by * max(1, d_in.batch) + (d_in.batch > 1 ? bz : 0)) * d.M * d.N : nullptr;
-  if (AM == MMFN_A_COLMAJOR && (d.flags & MMFN_EPI_COLSUM_A) && wn == 0 && n0 == 0) {
+  if (AM == MMFN_A_COLMAJOR && BMODE == MMFN_B_KN && (d.flags & MMFN_EPI_COLSUM_A) && wn == 0 && n0 == 0) {
     // the two lane halves saw complementary k's of the same rows; one block column (n0 == 0) of every row tile and k-slice writes:
     // without split-K straight into colsum, else into its slice's row of the partials behind the slabs (combined in slice order by
     // the split-K combine launch)
@@ -1577,6 +1577,9 @@ extern "C" int mmfn_gemm_f32(const mmfn_gemm_desc* dp, void* stream) {
     if (!d.colsum || d.a_mode != MMFN_A_COLMAJOR || d.b_mode != MMFN_B_KN || d.batch > 1 || !fast_ok(d) ||
         (d.flags & (MMFN_EPI_BF16_OPERANDS | MMFN_EPI_BF16X3)))
       return MMFN_EINVAL;
+#ifdef MMFN_GEMM_NO_FAST   // (an experiment build without the fast kernel would leave colsum unwritten)
+    return MMFN_EINVAL;
+#endif
   }
   hipStream_t s = (hipStream_t)stream;
   if (bf16_ok(d)) return launch_bf16(d, s);

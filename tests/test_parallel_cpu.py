@@ -307,3 +307,105 @@ def test_connect_falls_back_when_the_c_abi_transport_fails_on_one_rank_only(scen
         assert gone == [1], gone
     else:
         assert gone == [] and ids == [], "without the library on one rank nobody may get as far as the id broadcast / init"
+
+
+def _order_worker(rank, world, port, group_ranges, tail, program, out):
+    """One rank of test_bucket_issue_order_is_the_program_order_on_every_rank: DataParallel over a stand-in layout with the REAL
+    model's 17 readiness groups (ranges scaled down), reports arriving with rank-dependent delays."""
+    import random
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class _Layout(object):
+        pass
+
+    class _Mod(object):
+        pass
+
+    L = _Layout()
+    L.group_ranges, L.tail, L.device = group_ranges, tail, torch.device("cpu")
+    L.grads = torch.arange(tail + 8, dtype=torch.float32) * (rank + 1)
+    m = _Mod()
+    m._layout = L
+    dp = DataParallel(m, dist, max_bucket_bytes=1 << 10)
+    issued = []
+    real = dist.all_reduce
+
+    class _Logged(object):   # torch.distributed with all_reduce logging the range it was called on
+        ReduceOp = dist.ReduceOp
+
+        @staticmethod
+        def get_world_size():
+            return world
+
+        @staticmethod
+        def all_reduce(t, op=None, async_op=False):
+            issued.append((t.storage_offset(), t.numel()))
+            return real(t, op=op, async_op=async_op)
+
+    dp.dist = _Logged
+    rnd = random.Random(1000 + rank)
+    dp.begin()
+    for key in program:
+        time.sleep(rnd.random() * 0.02)    # this rank's lanes finish (are enqueued) at their own pace
+        dp.reduce(key)
+    dp.finish()
+    want = torch.arange(tail + 8, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    ok = torch.equal(L.grads[:tail], want[:tail])
+    logs = [None] * world
+    dist.all_gather_object(logs, issued)
+    if rank == 0:
+        out.put((ok, logs, dp.n_buckets(), len(dp.group_order)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_issue_order_is_the_program_order_on_every_rank():
+    """The one hazard a real 8-rank RCCL run adds over gloo: collectives on one communicator must be issued in the same order on
+    every rank, whatever order the GPUs finish their lanes in.  DataParallel issues a bucket where the ENGINE'S HOST PROGRAM
+    reports it (Engine.backward_scale: transformer, then the lanes in the order Engine._branches enqueues them), never from a
+    completion callback - so with 8 ranks whose reports arrive with different delays the logged all-reduce sequences are identical,
+    chunk for chunk, and equal to the program's; a rank that reported two lanes the other way round would be caught by this check."""
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd.model import MMFN
+    L = MMFN(GlobalConfig(), "cpu")._layout
+    # the real 17 groups, each range scaled to a few hundred elements (order, adjacency and 4-alignment kept)
+    keys = sorted(L.group_ranges, key=lambda k: L.group_ranges[k][0])
+    assert len(keys) == 17
+    ranges, pos = {}, 0
+    for k in keys:
+        b, e = L.group_ranges[k]
+        n = max(8, ((e - b) // 65536 + 3) // 4 * 4)
+        ranges[k] = (pos, pos + n)
+        pos += n
+    # the engine's host order: per backward stage the transformer / head groups first, then the lanes as _branches enqueues them
+    # (side lanes before the main lane)
+    program = []
+    for st in range(4):
+        ks = [k for k in keys if k[0] == st]
+        lanes = [k for k in ks if k[1] in ("img", "lid", "map", "vec")]
+        program += [k for k in ks if k not in lanes] + [k for k in lanes if k[1] != "img"] + [k for k in lanes if k[1] == "img"]
+    assert sorted(program) == sorted(keys)
+    world = 8
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_order_worker, args=(r, world, port, ranges, pos, program, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ok, logs, n_buckets, n_groups = out.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ok, "sums over the 17 groups"
+    assert n_groups == 17 and len(logs[0]) == n_buckets >= 17
+    assert all(l == logs[0] for l in logs), "every rank must issue the same all-reduce sequence"
+    expect = [(b0, min(b0 + 256, e) - b0) for k in program for b, e in [ranges[k]] for b0 in range(b, e, 256)]
+    assert logs[0] == expect, "the sequence is the program's: group by group, chunk by chunk"
+    swapped = list(program)
+    i = next(i for i, k in enumerate(swapped) if k[1] == "lid")
+    swapped[i], swapped[i + 1] = swapped[i + 1], swapped[i]
+    other = [(b0, min(b0 + 256, e) - b0) for k in swapped for b, e in [ranges[k]] for b0 in range(b, e, 256)]
+    assert other != expect, "a rank reporting two lanes the other way round issues a different sequence (this check can fail)"
