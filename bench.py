@@ -112,6 +112,7 @@ def attention_roofline(eng, B, dev, iters=20):
     step launches them on, ONE normalisation: the FLOPs their MFMAs execute (forward 2 products, backward 3 + 4 incl. the recomputed
     S and dP) / kernel time (HIP events around `iters` back-to-back launches) / the nominal fp32 MFMA peak."""
     import math
+    from mmfn_amd import ops
     gpt = eng.gpts[-1]
     T, C, NH = gpt.T, gpt.C, gpt.nh
     HS = C // NH

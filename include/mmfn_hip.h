@@ -424,6 +424,13 @@ int mmfn_gpt_debug_read(int64_t* out64);
 int mmfn_gpt_block_attn_fwd_f32(const mmfn_gpt_block_desc* d, void* stream);
 int mmfn_gpt_block_mlp_fwd_f32(const mmfn_gpt_block_desc* d, void* stream);
 int mmfn_gpt_block_bwd_rows_f32(const mmfn_gpt_block_desc* upper, const mmfn_gpt_block_desc* lower, void* stream);
+/* The bf16 training mode's row-block kernels (v_mfma_f32_16x16x32_bf16): the same descriptor with every GEMM operand bf16 -
+ * o, a2, h (forward), dqkv, gd, gd_below, gh, gd2, go (backward) point at bf16 tensors of the same shapes, and the weight fields at
+ * the bf16 shadows: [out][in] for the forward (wproj, w1, w2), the TRANSPOSED [in][out] shadows for the backward (wqkv, w2, w1,
+ * wproj).  The residual stream and its gradient (x, x1, x2, g, g1, g_below), LayerNorm parameters / statistics / partial rows and the
+ * biases stay fp32.  gd / gd2 / gd_below are required (they are where a gradient becomes a bf16 operand, with or without dropout). */
+int mmfn_gpt_block_mlp_fwd_bf16(const mmfn_gpt_block_desc* d, void* stream);
+int mmfn_gpt_block_bwd_rows_bf16(const mmfn_gpt_block_desc* upper, const mmfn_gpt_block_desc* lower, void* stream);
 
 /* ---- waypoint head: GRUCell x steps + Linear(64,2) + L1 loss (model_vec.py:666-680, phase2:104) ---- */
 int64_t mmfn_gru_head_part_floats(void);

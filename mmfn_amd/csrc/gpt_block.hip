@@ -70,38 +70,44 @@ struct DropKey {
   }
 };
 
-// cooperative copy of R rows x W floats (global row pitch ld) into LDS with pitch W + 4
-template <int W>
-__device__ __forceinline__ void stage_rows(const float* __restrict__ src, size_t ld, float* dst, int tid) {
-  constexpr int Q = W / 4, UNITS = R * Q;
+// cooperative copy of R rows x W elements (global row pitch ld) into LDS with pitch W + (one 16-byte unit), 16 bytes per thread
+template <int W, typename T>
+__device__ __forceinline__ void stage_rows(const T* __restrict__ src, size_t ld, T* dst, int tid) {
+  constexpr int E = 16 / sizeof(T), Q = W / E, UNITS = R * Q;
 #pragma unroll
   for (int u0 = 0; u0 < UNITS; u0 += NTHR) {
     const int u = u0 + tid;
     if (UNITS % NTHR == 0 || u < UNITS)
-      *reinterpret_cast<f32x4*>(dst + (u / Q) * (W + 4) + 4 * (u % Q)) = gpt_ld4(src + (size_t)(u / Q) * ld + 4 * (u % Q));
+      *reinterpret_cast<f32x4*>(dst + (u / Q) * (W + E) + E * (u % Q)) = *reinterpret_cast<const f32x4*>(src + (size_t)(u / Q) * ld + E * (u % Q));
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------- forward
-template <int C>
+// BF: the bf16 mode - o, a2, h and the weight shadows (wproj / w1 / w2 point at the [out][in] bf16 shadows) are bf16; x, x1, x2 fp32.
+template <int C, bool BF>
 __global__ __launch_bounds__(NTHR) void gpt_mlp_fwd_kernel(const GptArgs a) {
-  constexpr int H = 4 * C, PC = C + 4, PH = H + 4, NCH = C / 64;
-  __shared__ __attribute__((aligned(16))) float sO[R * PC];    // o rows, then a2
+  typedef GptPrec<BF> PR;
+  typedef typename PR::act A;
+  constexpr int H = 4 * C, PC = C + 4, PA = C + PR::EPU, PH = H + PR::EPU, NCH = C / 64;
+  __shared__ __attribute__((aligned(16))) A sO[R * PA];        // o rows, then a2
   __shared__ __attribute__((aligned(16))) float sX1[R * PC];   // x1
-  __shared__ __attribute__((aligned(16))) float sH[R * PH];    // hidden activations
+  __shared__ __attribute__((aligned(16))) A sH[R * PH];        // hidden activations
+  const A* wproj = reinterpret_cast<const A*>(a.wproj); const A* w1 = reinterpret_cast<const A*>(a.w1);
+  const A* w2 = reinterpret_cast<const A*>(a.w2);
+  A* io_a2 = reinterpret_cast<A*>(a.a2); A* io_h = reinterpret_cast<A*>(a.h);
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const size_t row0 = (size_t)blockIdx.x * R;
   using OC = Own<C>;
   using OH = Own<H>;
   const int nt0 = OC::nt0(w), tt0 = OC::tt0(w), hn0 = OH::nt0(w), ht0 = OH::tt0(w);
   GPT_STAMP(0);
-  GptWRing<C, OC::NWT, 4, false> rproj;
-  rproj.start(a.wproj + (size_t)(16 * nt0) * C, C, l15, l4);
-  stage_rows<C>(a.o + row0 * C, C, sO, tid);
+  GptWRing<C, OC::NWT, (BF ? 2 : 4), false, BF> rproj;
+  rproj.start(wproj + (size_t)(16 * nt0) * C, C, l15, l4);
+  stage_rows<C>(reinterpret_cast<const A*>(a.o) + row0 * C, C, sO, tid);
   gpt_barrier();
   GPT_STAMP(1);
   // ---- x1 = x + drop(o . Wproj^T + b)
-  GptWRing<C, OH::NWT, (OH::NWT >= 4 ? 2 : 4), false> rfc1;
+  GptWRing<C, OH::NWT, (OH::NWT >= 4 ? 2 : 4), false, BF> rfc1;
   {
     // (epilogue operands are requested before the product: their latency would otherwise be exposed after the last MFMA)
     f32x4 bias[OC::NWT], xres[OC::NWT][OC::NTT];
@@ -113,9 +119,9 @@ __global__ __launch_bounds__(NTHR) void gpt_mlp_fwd_kernel(const GptArgs a) {
     }
     f32x4 acc[OC::NWT][OC::NTT];
     zero<OC::NWT, OC::NTT>(acc);
-    rproj.template run<OC::NTT>(sO + 16 * tt0 * PC, l15, l4, acc);
+    rproj.template run<OC::NTT>(sO + 16 * tt0 * PA, l15, l4, acc);
     GPT_STAMP(2);
-    rfc1.start(a.w1 + (size_t)(16 * hn0) * C, C, l15, l4);   // mlp.0's first chunks travel under the epilogue and the LayerNorm
+    rfc1.start(w1 + (size_t)(16 * hn0) * C, C, l15, l4);   // mlp.0's first chunks travel under the epilogue and the LayerNorm
     DropKey dk;
     dk.init(a.rng_state, a.rng_stream + 1, a.resid_pdrop);
 #pragma unroll
@@ -158,8 +164,8 @@ __global__ __launch_bounds__(NTHR) void gpt_mlp_fwd_kernel(const GptArgs a) {
       f32x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = (v[i][r] - mu) * rs * wv[r] + bv[r];
-      gpt_st4(a.a2 + (row0 + t) * C + n, o);
-      *reinterpret_cast<f32x4*>(sO + t * PC + n) = o;
+      stx4(io_a2 + (row0 + t) * C + n, o);
+      stx4(sO + t * PA + n, o);
     }
     if (l15 == 0) { a.mu2[row0 + t] = mu; a.rs2[row0 + t] = rs; }
   }
@@ -167,16 +173,16 @@ __global__ __launch_bounds__(NTHR) void gpt_mlp_fwd_kernel(const GptArgs a) {
   gpt_barrier();
   GPT_STAMP(6);
   // ---- h = relu(a2 . W1^T + b1)
-  GptWRing<H, OC::NWT, 6, false> rfc2;
+  GptWRing<H, OC::NWT, 6, false, BF> rfc2;
   {
     f32x4 bias[OH::NWT];
 #pragma unroll
     for (int i = 0; i < OH::NWT; ++i) bias[i] = gpt_ld4(a.b1 + 16 * (hn0 + i) + 4 * l4);
     f32x4 acc[OH::NWT][OH::NTT];
     zero<OH::NWT, OH::NTT>(acc);
-    rfc1.template run<OH::NTT>(sO + 16 * ht0 * PC, l15, l4, acc);
+    rfc1.template run<OH::NTT>(sO + 16 * ht0 * PA, l15, l4, acc);
     GPT_STAMP(7);
-    rfc2.start(a.w2 + (size_t)(16 * nt0) * H, H, l15, l4);
+    rfc2.start(w2 + (size_t)(16 * nt0) * H, H, l15, l4);
 #pragma unroll
     for (int i = 0; i < OH::NWT; ++i)
 #pragma unroll
@@ -185,8 +191,8 @@ __global__ __launch_bounds__(NTHR) void gpt_mlp_fwd_kernel(const GptArgs a) {
         f32x4 v = acc[i][j] + bias[i];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        gpt_st4(a.h + (row0 + t) * H + n, v);
-        *reinterpret_cast<f32x4*>(sH + t * PH + n) = v;
+        stx4(io_h + (row0 + t) * H + n, v);
+        stx4(sH + t * PH + n, v);
       }
   }
   GPT_STAMP(8);
@@ -288,32 +294,43 @@ __device__ __forceinline__ void ln_bwd_rows(const float* sGy, const float* __res
   }
 }
 
-template <int C>
+// BF: the bf16 mode - dqkv, gd / gd_below, gh, gd2, go and h are bf16, and wqkv / w2 / w1 / wproj point at the TRANSPOSED bf16
+// shadows ([in][out]: every data gradient is an NT product over them); x, x1, g, g1, g_below and the LayerNorm arithmetic stay fp32.
+template <int C, bool BF>
 __global__ __launch_bounds__(NTHR) void gpt_bwd_rows_kernel(const GptArgs up, const GptArgs lo, int has_up, int has_lo) {
-  constexpr int H = 4 * C, PC = C + 4, PH = H + 4, PQ = 3 * C + 4;
+  typedef GptPrec<BF> PR;
+  typedef typename PR::act A;
+  constexpr int E = PR::EPU;
+  constexpr int H = 4 * C, PC = C + 4, PA = C + E, PH = H + E, PQ = 3 * C + E;
   constexpr int BIG = R * PH > R * PQ ? R * PH : R * PQ;
-  __shared__ __attribute__((aligned(16))) float sBig[BIG];       // dqkv rows (upper), then gh rows (lower)
+  __shared__ __attribute__((aligned(16))) A sBig[BIG];           // dqkv rows (upper), then gh rows (lower)
   __shared__ __attribute__((aligned(16))) float sGy[R * PC];     // gradient entering a LayerNorm backward (ga, then ga2)
   __shared__ __attribute__((aligned(16))) float sG[R * PC];      // g: gradient at the lower block's output (residual path)
-  __shared__ __attribute__((aligned(16))) float sGd[R * PC];     // gd (mlp.2's operand), later gd2 (proj's operand)
+  __shared__ __attribute__((aligned(16))) A sGd[R * PA];         // gd (mlp.2's operand), later gd2 (proj's operand)
   __shared__ float red[3 * 8 * C];
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const size_t row0 = (size_t)blockIdx.x * R;
   using OC = Own<C>;
   using OH = Own<H>;
   const int nt0 = OC::nt0(w), tt0 = OC::tt0(w), hn0 = OH::nt0(w), ht0 = OH::tt0(w);
-  GptWRing<C, OH::NWT, (OH::NWT >= 4 ? 5 : 4), true> rw2;   // (started before the phase that precedes its product, see gpt_block.h)
+  constexpr bool NN = !BF;
+  // first element of this wave's weight tiles for a product with NOUT outputs contracting over NIN: fp32 - column 16 * tile of the
+  // [NIN][NOUT] matrix (row pitch NOUT); bf16 - row 16 * tile of its transposed shadow [NOUT][NIN] (row pitch NIN)
+  auto wbase = [](const float* wgt, int tile0, int nin) {
+    return BF ? reinterpret_cast<const A*>(wgt) + (size_t)(16 * tile0) * nin : reinterpret_cast<const A*>(wgt) + 16 * tile0;
+  };
+  GptWRing<C, OH::NWT, (BF ? 2 : (OH::NWT >= 4 ? 5 : 4)), NN, BF> rw2;   // (started before the phase that precedes its product, gpt_block.h)
   if (has_up) {
     // ---- ga = dqkv . Wqkv  (contraction over the 3C outputs of the packed projection)
-    GptWRing<3 * C, OC::NWT, 10, true> rqkv;
-    rqkv.start(up.wqkv + 16 * nt0, C, l15, l4);
-    stage_rows<3 * C>(up.dqkv + row0 * 3 * C, 3 * C, sBig, tid);
+    GptWRing<3 * C, OC::NWT, (BF ? 4 : 10), NN, BF> rqkv;
+    rqkv.start(wbase(up.wqkv, nt0, 3 * C), BF ? 3 * C : C, l15, l4);
+    stage_rows<3 * C>(reinterpret_cast<const A*>(up.dqkv) + row0 * 3 * C, 3 * C, sBig, tid);
     gpt_barrier();
     {
       f32x4 acc[OC::NWT][OC::NTT];
       zero<OC::NWT, OC::NTT>(acc);
       rqkv.template run<OC::NTT>(sBig + 16 * tt0 * PQ, l15, l4, acc);
-      if (has_lo) rw2.start(lo.w2 + 16 * hn0, H, l15, l4);
+      if (has_lo) rw2.start(wbase(lo.w2, hn0, C), BF ? C : H, l15, l4);
 #pragma unroll
       for (int i = 0; i < OC::NWT; ++i)
 #pragma unroll
@@ -321,9 +338,10 @@ __global__ __launch_bounds__(NTHR) void gpt_bwd_rows_kernel(const GptArgs up, co
           *reinterpret_cast<f32x4*>(sGy + (16 * (tt0 + j) + l15) * PC + 16 * (nt0 + i) + 4 * l4) = acc[i][j];
     }
     gpt_barrier();
-    // ---- g = ln1 backward(ga) + g1;  gd = g under the mask of the block below
+    // ---- g = ln1 backward(ga) + g1;  gd = g under the mask of the block below (bf16 mode: also the rounding to the operand type)
     DropKey dk;
     dk.init(up.rng_state, up.rng_stream_below + 2, up.gd_below ? up.resid_pdrop : 0.f);
+    A* gd_below = reinterpret_cast<A*>(up.gd_below);
     ln_bwd_rows<C>(
         sGy, up.x, up.mu1, up.rs1, up.ln1_w, row0, w, l15, l4, red, up.part_ln1, up.below_colsum ? 3 : 2, tid,
         [&](int t, int n) { return gpt_ld4(up.g1 + (row0 + t) * C + n); },
@@ -332,50 +350,51 @@ __global__ __launch_bounds__(NTHR) void gpt_bwd_rows_kernel(const GptArgs up, co
           gpt_st4(up.g_below + off, o);
           *reinterpret_cast<f32x4*>(sG + t * PC + n) = o;
           f32x4 od = o;
-          if (up.gd_below) {
+          if (gd_below) {
             od = dk.apply(o, off);
-            gpt_st4(up.gd_below + off, od);
+            stx4(gd_below + off, od);
           }
-          *reinterpret_cast<f32x4*>(sGd + t * PC + n) = od;
+          stx4(sGd + t * PA + n, od);
           return od;
         });
     if (!has_lo) return;
     gpt_barrier();
   } else {
-    rw2.start(lo.w2 + 16 * hn0, H, l15, l4);
+    rw2.start(wbase(lo.w2, hn0, C), BF ? C : H, l15, l4);
     stage_rows<C>(lo.g + row0 * C, C, sG, tid);
-    stage_rows<C>((lo.gd ? lo.gd : lo.g) + row0 * C, C, sGd, tid);
+    stage_rows<C>(reinterpret_cast<const A*>(lo.gd ? lo.gd : lo.g) + row0 * C, C, sGd, tid);
     gpt_barrier();
   }
   // ---- gh = (gd . W2) masked by h > 0   (W2 [C][4C]: contraction over its rows)
-  GptWRing<H, OC::NWT, 12, true> rw1;
+  GptWRing<H, OC::NWT, (BF ? 6 : 12), NN, BF> rw1;
   {
+    const A* io_h = reinterpret_cast<const A*>(lo.h);
+    A* io_gh = reinterpret_cast<A*>(lo.gh);
     f32x4 acc[OH::NWT][OH::NTT];
     zero<OH::NWT, OH::NTT>(acc);
-    const int n0 = hn0, t0 = ht0;
-    rw2.template run<OH::NTT>(sGd + 16 * t0 * PC, l15, l4, acc);
-    rw1.start(lo.w1 + 16 * nt0, C, l15, l4);
+    rw2.template run<OH::NTT>(sGd + 16 * ht0 * PA, l15, l4, acc);
+    rw1.start(wbase(lo.w1, nt0, H), BF ? H : C, l15, l4);
 #pragma unroll
     for (int i = 0; i < OH::NWT; ++i)
 #pragma unroll
       for (int j = 0; j < OH::NTT; ++j) {
-        const int n = 16 * (n0 + i) + 4 * l4, t = 16 * (t0 + j) + l15;
-        const f32x4 hv = gpt_ld4(lo.h + (row0 + t) * H + n);
+        const int n = 16 * (hn0 + i) + 4 * l4, t = 16 * (ht0 + j) + l15;
+        const f32x4 hv = ldx4(io_h + (row0 + t) * H + n);
         f32x4 v = acc[i][j];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = hv[r] > 0.f ? v[r] : 0.f;
-        gpt_st4(lo.gh + (row0 + t) * H + n, v);
-        *reinterpret_cast<f32x4*>(sBig + t * PH + n) = v;
+        stx4(io_gh + (row0 + t) * H + n, v);
+        stx4(sBig + t * PH + n, v);
       }
   }
   gpt_barrier();
   // ---- ga2 = gh . W1  (W1 [4C][C])
-  GptWRing<C, OC::NWT, 8, true> rproj;
+  GptWRing<C, OC::NWT, (BF ? 2 : 8), NN, BF> rproj;
   {
     f32x4 acc[OC::NWT][OC::NTT];
     zero<OC::NWT, OC::NTT>(acc);
     rw1.template run<OC::NTT>(sBig + 16 * tt0 * PH, l15, l4, acc);
-    rproj.start(lo.wproj + 16 * nt0, C, l15, l4);
+    rproj.start(wbase(lo.wproj, nt0, C), C, l15, l4);
 #pragma unroll
     for (int i = 0; i < OC::NWT; ++i)
 #pragma unroll
@@ -387,6 +406,7 @@ __global__ __launch_bounds__(NTHR) void gpt_bwd_rows_kernel(const GptArgs up, co
   {
     DropKey dk;
     dk.init(lo.rng_state, lo.rng_stream + 1, lo.gd2 ? lo.resid_pdrop : 0.f);
+    A* gd2 = reinterpret_cast<A*>(lo.gd2);
     ln_bwd_rows<C>(
         sGy, lo.x1, lo.mu2, lo.rs2, lo.ln2_w, row0, w, l15, l4, red, lo.part_ln2, 3, tid,
         [&](int t, int n) { return *reinterpret_cast<const f32x4*>(sG + t * PC + n); },
@@ -394,25 +414,26 @@ __global__ __launch_bounds__(NTHR) void gpt_bwd_rows_kernel(const GptArgs up, co
           const size_t off = (row0 + t) * C + n;
           gpt_st4(lo.g1 + off, o);
           f32x4 od = o;
-          if (lo.gd2) {
+          if (gd2) {
             od = dk.apply(o, off);
-            gpt_st4(lo.gd2 + off, od);
+            stx4(gd2 + off, od);
           }
-          *reinterpret_cast<f32x4*>(sGd + t * PC + n) = od;   // (each lane overwrites only what it read as gd rows ago: phases apart)
+          stx4(sGd + t * PA + n, od);   // (gd was last read two barriers ago)
           return od;
         });
   }
   gpt_barrier();
   // ---- go = gd2 . Wproj
   {
+    A* io_go = reinterpret_cast<A*>(lo.go);
     f32x4 acc[OC::NWT][OC::NTT];
     zero<OC::NWT, OC::NTT>(acc);
-    rproj.template run<OC::NTT>(sGd + 16 * tt0 * PC, l15, l4, acc);
+    rproj.template run<OC::NTT>(sGd + 16 * tt0 * PA, l15, l4, acc);
 #pragma unroll
     for (int i = 0; i < OC::NWT; ++i)
 #pragma unroll
       for (int j = 0; j < OC::NTT; ++j)
-        gpt_st4(lo.go + (row0 + 16 * (tt0 + j) + l15) * C + 16 * (nt0 + i) + 4 * l4, acc[i][j]);
+        stx4(io_go + (row0 + 16 * (tt0 + j) + l15) * C + 16 * (nt0 + i) + 4 * l4, acc[i][j]);
   }
 }
 
@@ -439,28 +460,43 @@ extern "C" int mmfn_gpt_block_supported(int C, int NH, int T) {
   return ((C == 64 || C == 128) && NH == 4 && T == 192) ? 0 : MMFN_EINVAL;
 }
 
-extern "C" int mmfn_gpt_block_mlp_fwd_f32(const mmfn_gpt_block_desc* d, void* stream) {
+namespace {
+template <bool BF>
+int mlp_fwd_launch(const mmfn_gpt_block_desc* d, void* stream) {
   if (!d || !shape_ok(*d)) return MMFN_EINVAL;
   if (d->resid_pdrop < 0.f || d->resid_pdrop >= 1.f || (d->resid_pdrop > 0.f && !d->rng_state)) return MMFN_EINVAL;
   const dim3 grid((unsigned)((size_t)d->B * d->T / R));
-  if (d->C == 64) hipLaunchKernelGGL(gpt_mlp_fwd_kernel<64>, grid, dim3(NTHR), 0, (hipStream_t)stream, *d);
-  else hipLaunchKernelGGL(gpt_mlp_fwd_kernel<128>, grid, dim3(NTHR), 0, (hipStream_t)stream, *d);
+  if (d->C == 64) hipLaunchKernelGGL((gpt_mlp_fwd_kernel<64, BF>), grid, dim3(NTHR), 0, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL((gpt_mlp_fwd_kernel<128, BF>), grid, dim3(NTHR), 0, (hipStream_t)stream, *d);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
 
-extern "C" int mmfn_gpt_block_bwd_rows_f32(const mmfn_gpt_block_desc* upper, const mmfn_gpt_block_desc* lower, void* stream) {
+template <bool BF>
+int bwd_rows_launch(const mmfn_gpt_block_desc* upper, const mmfn_gpt_block_desc* lower, void* stream) {
   const mmfn_gpt_block_desc* any = upper ? upper : lower;
   if (!any || !shape_ok(*any)) return MMFN_EINVAL;
   if (upper && lower && (upper->C != lower->C || upper->B != lower->B || upper->T != lower->T)) return MMFN_EINVAL;
   if (any->resid_pdrop < 0.f || any->resid_pdrop >= 1.f || (any->resid_pdrop > 0.f && !any->rng_state)) return MMFN_EINVAL;
+  // bf16 mode: the operand copies are where a gradient changes type - they cannot be "the same tensor as g"
+  if (BF && ((lower && (!lower->gd2 || (!upper && !lower->gd))) || (upper && lower && !upper->gd_below))) return MMFN_EINVAL;
   const dim3 grid((unsigned)((size_t)any->B * any->T / R));
   const mmfn_gpt_block_desc& u = upper ? *upper : *lower;
   const mmfn_gpt_block_desc& l = lower ? *lower : *upper;
   if (any->C == 64)
-    hipLaunchKernelGGL(gpt_bwd_rows_kernel<64>, grid, dim3(NTHR), 0, (hipStream_t)stream, u, l, upper ? 1 : 0, lower ? 1 : 0);
+    hipLaunchKernelGGL((gpt_bwd_rows_kernel<64, BF>), grid, dim3(NTHR), 0, (hipStream_t)stream, u, l, upper ? 1 : 0, lower ? 1 : 0);
   else
-    hipLaunchKernelGGL(gpt_bwd_rows_kernel<128>, grid, dim3(NTHR), 0, (hipStream_t)stream, u, l, upper ? 1 : 0, lower ? 1 : 0);
+    hipLaunchKernelGGL((gpt_bwd_rows_kernel<128, BF>), grid, dim3(NTHR), 0, (hipStream_t)stream, u, l, upper ? 1 : 0, lower ? 1 : 0);
   MMFN_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace
+
+extern "C" int mmfn_gpt_block_mlp_fwd_f32(const mmfn_gpt_block_desc* d, void* stream) { return mlp_fwd_launch<false>(d, stream); }
+extern "C" int mmfn_gpt_block_mlp_fwd_bf16(const mmfn_gpt_block_desc* d, void* stream) { return mlp_fwd_launch<true>(d, stream); }
+extern "C" int mmfn_gpt_block_bwd_rows_f32(const mmfn_gpt_block_desc* upper, const mmfn_gpt_block_desc* lower, void* stream) {
+  return bwd_rows_launch<false>(upper, lower, stream);
+}
+extern "C" int mmfn_gpt_block_bwd_rows_bf16(const mmfn_gpt_block_desc* upper, const mmfn_gpt_block_desc* lower, void* stream) {
+  return bwd_rows_launch<true>(upper, lower, stream);
 }

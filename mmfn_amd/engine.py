@@ -653,7 +653,7 @@ class GPT(object):
         fold = (not ctx.bf16) and ops.current_precision() == "f32" and self.blocks[0]["fold"] is not None and M % 64 == 0 \
             and ctx.engine.ln_fold_now(ctx.training)
         self.folded_fwd = fold
-        fused = self.fused_now(ctx) and not fold
+        fused = self.fused_now(ctx) and not fold          # fp32: both fused launches; bf16 mode: the row-block launch after attention16
         self.fused_fwd = fused
         for i, blk in enumerate(self.blocks):
             sb = self.stream_base + 1 + 3 * i
@@ -666,11 +666,18 @@ class GPT(object):
                 x1 = bufs.get("%s.b%d.x1" % (nm, i), (M, C), sdt)
                 x2 = bufs.get("%s.b%d.x2" % (nm, i), (M, C), sdt)
                 a, o, a2, h = S_a[i], S_o[i], S_a2[i], S_h[i]
-                d = self._desc(blk, B, ctx, sb, x=x, a=a, mu1=mu1, rs1=rs1, qkv=qkv, o=o, lse=lse, x1=x1, a2=a2, mu2=mu2, rs2=rs2,
-                               h=h, x2=x2)
-                ops.gpt_block_attn_fwd(d)
+                if ctx.bf16:
+                    ln1.fwd(ctx, x, out=a)
+                    ops.linear_fwd(a, blk["wqkv16"], blk["bqkv"], out=qkv)
+                    ops.attention_fwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, C, lse, B, T, nh, hs, scale, drop_p=p_attn,
+                                      rng_state=ctx.rng_state, rng_stream=sb)
+                    d = self._desc(blk, B, ctx, sb, weights="fwd16", x=x, o=o, x1=x1, a2=a2, mu2=mu2, rs2=rs2, h=h, x2=x2)
+                else:
+                    d = self._desc(blk, B, ctx, sb, x=x, a=a, mu1=mu1, rs1=rs1, qkv=qkv, o=o, lse=lse, x1=x1, a2=a2, mu2=mu2,
+                                   rs2=rs2, h=h, x2=x2)
+                    ops.gpt_block_attn_fwd(d)
+                    ln1.saved = (x, mu1, rs1, ACT_NONE)
                 ops.gpt_block_mlp_fwd(d)
-                ln1.saved = (x, mu1, rs1, ACT_NONE)
                 ln2.saved = (x1, mu2, rs2, ACT_NONE)
                 self.acts.append((x, a, qkv, o, lse, x1, a2, h))
                 x = x2
@@ -715,16 +722,23 @@ class GPT(object):
 
     def fused_now(self, ctx):
         """The fused block kernels serve this transformer in this pass: fp32 mode and arithmetic, n_embd 64 / 128, 4 heads, T = 192."""
-        return (GPT_FUSED != "0" and not ctx.bf16 and ops.current_precision() == "f32"
+        return (GPT_FUSED != "0" and (ctx.bf16 or ops.current_precision() == "f32")
                 and ops.gpt_block_supported(self.C, self.nh, self.T))
 
-    def _desc(self, blk, B, ctx, sb, sb_below=0, below_colsum=False, **tensors):
+    def _desc(self, blk, B, ctx, sb, sb_below=0, below_colsum=False, weights="f32", **tensors):
+        """weights: "f32" the master weights; "fwd16" / "bwd16" the bf16 mode's [out][in] / transposed [in][out] shadows."""
         p_embd, p_attn, p_resid = ctx.drop
+        if weights == "f32":
+            w = dict(wqkv=blk["wqkv"], wproj=blk["proj"].w, w1=blk["fc1"].w, w2=blk["fc2"].w)
+        elif weights == "fwd16":
+            w = dict(wqkv=blk["wqkv16"], wproj=blk["proj"].w16, w1=blk["fc1"].w16, w2=blk["fc2"].w16)
+        else:
+            w = dict(wqkv=blk["wqkv16t"], wproj=blk["proj"].w16t, w1=blk["fc1"].w16t, w2=blk["fc2"].w16t)
         return ops.gpt_block_desc(
             B, self.T, self.C, self.nh, eps=1e-5, attn_pdrop=p_attn, resid_pdrop=p_resid, rng_state=ctx.rng_state, rng_stream=sb,
             rng_stream_below=sb_below, below_colsum=below_colsum,
-            ln1_w=blk["ln1"].w, ln1_b=blk["ln1"].b, wqkv=blk["wqkv"], bqkv=blk["bqkv"], wproj=blk["proj"].w, bproj=blk["proj"].b,
-            ln2_w=blk["ln2"].w, ln2_b=blk["ln2"].b, w1=blk["fc1"].w, b1=blk["fc1"].b, w2=blk["fc2"].w, b2=blk["fc2"].b, **tensors)
+            ln1_w=blk["ln1"].w, ln1_b=blk["ln1"].b, bqkv=blk["bqkv"], bproj=blk["proj"].b,
+            ln2_w=blk["ln2"].w, ln2_b=blk["ln2"].b, b1=blk["fc1"].b, b2=blk["fc2"].b, **w, **tensors)
 
     def _bwd_fused(self, ctx, g_y):
         """GPT.bwd with the row-local chain of every block in one launch (csrc/gpt_block.hip gpt_bwd_rows_kernel): per block the chain is
@@ -736,19 +750,20 @@ class GPT(object):
         p_embd, p_attn, p_resid = ctx.drop
         scale = 1.0 / math.sqrt(hs)
         nblk = len(self.blocks)
-        drop = p_resid > 0.0
+        # bf16 mode: the "dropped copy" is also where the stream gradient becomes a bf16 GEMM operand, so it exists without dropout too
+        drop = p_resid > 0.0 or ctx.bf16
         sb_of = lambda i: self.stream_base + 1 + 3 * i
-        f32 = torch.float32
+        f32, adt = torch.float32, ctx.adt   # the residual stream's gradient (G, G1) is fp32 in both modes
         G = bufs.get(nm + ".S.g", (nblk, M, C), f32)
-        GD = bufs.get(nm + ".S.gdrop", (nblk, M, C), f32) if drop else None
+        GD = bufs.get(nm + ".S.gdrop", (nblk, M, C), adt) if drop else None
         G1 = bufs.get(nm + ".S.g1", (nblk, M, C), f32)
-        GD2 = bufs.get(nm + ".S.gdrop2", (nblk, M, C), f32) if drop else None
-        GH = bufs.get(nm + ".S.gh", (nblk, M, 4 * C), f32)
-        DQKV = bufs.get(nm + ".S.dqkv", (nblk, M, 3 * C), f32)
+        GD2 = bufs.get(nm + ".S.gdrop2", (nblk, M, C), adt) if drop else None
+        GH = bufs.get(nm + ".S.gh", (nblk, M, 4 * C), adt)
+        DQKV = bufs.get(nm + ".S.dqkv", (nblk, M, 3 * C), adt)
         nrow = M // ops.GPT_ROWS
         P1 = bufs.get(nm + ".S.part1", (nblk, nrow, 3, C), f32)
         P2 = bufs.get(nm + ".S.part2", (nblk, nrow, 3, C), f32)
-        go = bufs.get(nm + ".go", (M, C), f32)
+        go = bufs.get(nm + ".go", (M, C), adt)
         g_tok = bufs.get(nm + ".g_tok", (M, C), f32)
         delta = bufs.get(nm + ".delta", (B, nh, T))
         side = []
@@ -759,7 +774,7 @@ class GPT(object):
             x, a, qkv, o, lse, x1, a2, h = self.acts[i]
             descs.append(self._desc(
                 blk, B, ctx, sb_of(i), sb_below=sb_of(i - 1) if i > 0 else 0, below_colsum=i > 0,
-                x=x, mu1=blk["ln1"].saved[1], rs1=blk["ln1"].saved[2], x1=x1, mu2=blk["ln2"].saved[1], rs2=blk["ln2"].saved[2], h=h,
+                weights="bwd16" if ctx.bf16 else "f32", x=x, mu1=blk["ln1"].saved[1], rs1=blk["ln1"].saved[2], x1=x1, mu2=blk["ln2"].saved[1], rs2=blk["ln2"].saved[2], h=h,
                 g=G[i], gd=GD[i] if drop else None, gh=GH[i], g1=G1[i], gd2=GD2[i] if drop else None, go=go, dqkv=DQKV[i],
                 g_below=G[i - 1] if i > 0 else g_tok, gd_below=GD[i - 1] if (drop and i > 0) else None, part_ln1=P1[i], part_ln2=P2[i]))
         ops.gpt_block_bwd_rows(None, descs[nblk - 1])

@@ -1007,6 +1007,8 @@ def attention_bwd(q, k, v, ld, o, dO, ldo, lse, delta, dq, dk, dv, ldg, B, T, NH
 
 # ---------------------------------------------------------------- fused GPT block (narrow fusion transformers)
 GPT_ROWS = 32   # token rows per workgroup of the row-block kernels = rows per LayerNorm partial row
+# bf16 mode: the fields of mmfn_gpt_block_desc that are bf16 (GEMM operands in HBM and the weight shadows); everything else stays fp32
+GPT_BF16_FIELDS = frozenset(("wqkv", "wproj", "w1", "w2", "a", "qkv", "o", "a2", "h", "gd", "gh", "gd2", "go", "dqkv", "gd_below"))
 
 
 def gpt_block_supported(C, NH, T):
@@ -1015,15 +1017,25 @@ def gpt_block_supported(C, NH, T):
 
 def gpt_block_desc(B, T, C, NH, eps=1e-5, attn_pdrop=0.0, resid_pdrop=0.0, rng_state=None, rng_stream=0, rng_stream_below=0,
                    below_colsum=False, **tensors):
-    """mmfn_gpt_block_desc (include/mmfn_hip.h): tensors by field name (fp32, contiguous); missing fields stay NULL.  The returned
-    structure keeps its tensors alive."""
+    """mmfn_gpt_block_desc (include/mmfn_hip.h): tensors by field name (contiguous); missing fields stay NULL.  fp32 everywhere on the
+    fp32 path; in the bf16 mode the GEMM operands (GPT_BF16_FIELDS, and the weight shadows) are bf16.  The returned structure
+    keeps its tensors alive and remembers whether it describes the bf16 mode (`d.bf16`)."""
     d = GptBlockDesc()
+    bf16 = False
     for name, t in tensors.items():
         if name not in GptBlockDesc._PTRS:
             raise KeyError(name)
         if t is not None:
-            assert t.dtype == torch.float32 and t.is_contiguous(), name
+            assert t.is_contiguous(), name
+            if t.dtype == BF16:
+                assert name in GPT_BF16_FIELDS, name
+                bf16 = True
+            else:
+                assert t.dtype == torch.float32, name
         setattr(d, name, ptr(t))
+    if bf16:   # a descriptor is all-fp32 or has every operand it names in bf16
+        assert all(t is None or t.dtype == BF16 for n, t in tensors.items() if n in GPT_BF16_FIELDS), "mixed operand precisions"
+    d.bf16 = bf16
     d.rng_state = ptr(rng_state)
     d.B, d.T, d.C, d.NH = B, T, C, NH
     d.attn_pdrop, d.resid_pdrop, d.eps = float(attn_pdrop), float(resid_pdrop), float(eps)
@@ -1033,19 +1045,22 @@ def gpt_block_desc(B, T, C, NH, eps=1e-5, attn_pdrop=0.0, resid_pdrop=0.0, rng_s
 
 
 def gpt_block_attn_fwd(d):
-    """ln1 -> key / query / value -> attention of one transformer block, one launch (model_vec.py:96-105,126)."""
+    """ln1 -> key / query / value -> attention of one transformer block, one launch (model_vec.py:96-105,126).  fp32 path only."""
+    assert not d.bf16
     _call("mmfn_gpt_block_attn_fwd_f32", ctypes.addressof(d), stream())
 
 
 def gpt_block_mlp_fwd(d):
     """proj (+ residual) -> ln2 -> mlp.0 -> ReLU -> mlp.2 (+ residual) of one transformer block, one launch (model_vec.py:107-108,126-131)."""
-    _call("mmfn_gpt_block_mlp_fwd_f32", ctypes.addressof(d), stream())
+    _call("mmfn_gpt_block_mlp_fwd_bf16" if d.bf16 else "mmfn_gpt_block_mlp_fwd_f32", ctypes.addressof(d), stream())
 
 
 def gpt_block_bwd_rows(upper, lower):
     """The row-local backward between two attention backward passes: upper block's qkv dgrad + ln1 backward, lower block's mlp /
     ln2 / proj dgrads.  Either may be None."""
-    _call("mmfn_gpt_block_bwd_rows_f32", None if upper is None else ctypes.addressof(upper),
+    bf16 = (upper if upper is not None else lower).bf16
+    assert upper is None or lower is None or upper.bf16 == lower.bf16
+    _call("mmfn_gpt_block_bwd_rows_bf16" if bf16 else "mmfn_gpt_block_bwd_rows_f32", None if upper is None else ctypes.addressof(upper),
           None if lower is None else ctypes.addressof(lower), stream())
 
 

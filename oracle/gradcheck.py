@@ -94,8 +94,16 @@ def stage_bar(cos_cpu, factor=4.0):
     direct implicit GEMM (longer sequential fp32 accumulation chains in the MFMA k-loop than oneDNN's blocked sums) and at
     1.8-2.3 x per stage / up to 2.8 x per trunk with the F(4x4,3x3) Winograd convolutions over the points 0, +-3/4, +-3/2
     (4.0-5.0 x over Lavin's points 0, +-1, +-2 of rounds 1-3); a wrong tap, scale or mask in ONE layer's backward lands at
-    ~10000 x (tests/test_parity_benchsize_gpu.py injects one)."""
-    bar = 1.0 - factor * (1.0 - cos_cpu) - 1e-6
+    ~10000 x (tests/test_parity_benchsize_gpu.py injects one).
+
+    The absolute allowance (1e-5 of 1 - cos, round 6; 1e-6 before): at this initialisation every path - the fp32 oracle included - sits
+    0.3-0.6 % (relative) off the fp64 gradient, because 85 train-mode BatchNorms amplify fp32 rounding, and WHICH 0.5 % a path draws is
+    decided by rounding-level details of its forward.  Measured when the narrow transformers' forward became the fused kernels (their
+    tensors agree with the separate kernels' to 1e-7 and are exactly as far from fp64: tools/experiments/gpt_block_accuracy.py):
+    per-group 1 - cos moved by up to 2.5e-5 in BOTH directions ((1, img) 3.8e-5 -> 3.3e-5, (3, gpt) 2.2e-5 -> 4.5e-5, (0, map) 5e-6 ->
+    1.3e-5) with the backward untouched (MMFN_GPT_FUSED=fwd vs 0).  The (0, map) group is where the oracle's own draw is unusually
+    lucky (1.5e-6, its sibling trunks 7e-6), so a purely multiplicative bar there measures the oracle's luck, not the HIP path."""
+    bar = 1.0 - factor * (1.0 - cos_cpu) - 1e-5
     if cos_cpu >= 0.9999:
         bar = max(bar, 0.999)
     return bar

@@ -187,3 +187,111 @@ def test_fused_block_backward_rows_equal_the_separate_kernels(C, pr):
         for name, want in ref.items():
             if want is not None:
                 _close(got[name], want, 3e-5, "%s (split=%s)" % (name, split))
+
+
+# ------------------------------------------------------------------------------------------------- bf16 training mode
+def _close16(got, ref, name, ulps=2.0):
+    """bf16 tensors: within `ulps` bf16 ulps of the reference's magnitude scale (the fused and the separate kernels round the same
+    fp32 accumulations, in another summation order); fp32 tensors: 1e-2 of the scale (they inherit bf16 operands)."""
+    g, r = got.double(), ref.to(got.device).double()
+    scale = r.abs().max().item() + 1e-12
+    tol = (ulps * 2.0 ** -8 if got.dtype == torch.bfloat16 else 1e-2) * scale
+    err = (g - r).abs().max().item()
+    assert err <= tol, "%s: max err %.3e > %.3e (scale %.3e)" % (name, err, tol, scale)
+
+
+def _shadows(p):
+    bf = torch.bfloat16
+    s = {k: p[k] for k in ("ln1_w", "ln1_b", "bqkv", "bproj", "ln2_w", "ln2_b", "b1", "b2")}
+    fwd = dict(s, **{k: p[k].to(bf).contiguous() for k in ("wqkv", "wproj", "w1", "w2")})
+    bwd = dict(s, **{k: p[k].t().contiguous().to(bf) for k in ("wqkv", "wproj", "w1", "w2")})
+    return fwd, bwd
+
+
+@pytest.mark.parametrize("C", [64, 128])
+@pytest.mark.parametrize("pr", [0.0, 0.1])
+def test_fused_mlp_forward_bf16_equals_the_separate_bf16_kernels(C, pr):
+    from mmfn_amd import ops
+    dev = _dev()
+    bf = torch.bfloat16
+    B, T, NH = 3, 192, 4
+    M = B * T
+    g = torch.Generator().manual_seed(3 * C)
+    p = _params(C, g, dev)
+    fw, _ = _shadows(p)
+    x = torch.randn(M, C, generator=g).to(dev)
+    o = torch.randn(M, C, generator=g).to(dev).to(bf)
+    rng = torch.tensor([21, 4], dtype=torch.int64, device=dev)
+    e32 = lambda *s: torch.full(s, float("nan"), device=dev)
+    e16 = lambda *s: torch.full(s, float("nan"), device=dev, dtype=bf)
+    got = dict(x1=e32(M, C), a2=e16(M, C), mu2=e32(M), rs2=e32(M), h=e16(M, 4 * C), x2=e32(M, C))
+    d = ops.gpt_block_desc(B, T, C, NH, resid_pdrop=pr, rng_state=rng, rng_stream=60, x=x, o=o, **fw, **got)
+    assert d.bf16
+    ops.gpt_block_mlp_fwd(d)
+    ref = dict(x1=e32(M, C), a2=e16(M, C), mu2=e32(M), rs2=e32(M), h=e16(M, 4 * C), x2=e32(M, C))
+    ops.linear_fwd(o, fw["wproj"], p["bproj"], out=ref["x1"], res=x, ldr=C, drop_p=pr, rng_state=rng, rng_stream=61)
+    ops.layernorm_fwd(ref["x1"], p["ln2_w"], p["ln2_b"], ref["a2"], ref["mu2"], ref["rs2"])
+    ops.linear_fwd(ref["a2"], fw["w1"], p["b1"], out=ref["h"], relu=True)
+    ops.linear_fwd(ref["h"], fw["w2"], p["b2"], out=ref["x2"], res=ref["x1"], ldr=C, drop_p=pr, rng_state=rng, rng_stream=62)
+    torch.cuda.synchronize()
+    for name in got:
+        _close16(got[name], ref[name], name)
+
+
+@pytest.mark.parametrize("C", [64, 128])
+@pytest.mark.parametrize("pr", [0.0, 0.1])
+def test_fused_backward_rows_bf16_equal_the_separate_bf16_kernels(C, pr):
+    from mmfn_amd import ops
+    dev = _dev()
+    bf = torch.bfloat16
+    B, T, NH = 2, 192, 4
+    M = B * T
+    g = torch.Generator().manual_seed(11 * C)
+    pu, pl = _params(C, g, dev), _params(C, g, dev)
+    _, bu = _shadows(pu)
+    _, bl = _shadows(pl)
+    r32 = lambda *s: torch.randn(*s, generator=g).to(dev)
+    rng = torch.tensor([5, 9], dtype=torch.int64, device=dev)
+    sb_up, sb_lo = 50, 47
+    x_up, x1_lo = r32(M, C), r32(M, C)
+    mu1, rs1 = x_up.mean(1), 1.0 / torch.sqrt(x_up.var(1, unbiased=False) + 1e-5)
+    mu2, rs2 = x1_lo.mean(1), 1.0 / torch.sqrt(x1_lo.var(1, unbiased=False) + 1e-5)
+    h = torch.relu(r32(M, 4 * C)).to(bf)
+    dqkv, g1_up = r32(M, 3 * C).to(bf), r32(M, C)
+    nrow = M // ops.GPT_ROWS
+    e32 = lambda *s: torch.full(s, float("nan"), device=dev)
+    e16 = lambda *s: torch.full(s, float("nan"), device=dev, dtype=bf)
+    o = dict(g_below=e32(M, C), gd_below=e16(M, C), part_ln1=e32(nrow, 3, C), gh=e16(M, 4 * C), g1=e32(M, C), gd2=e16(M, C),
+             go=e16(M, C), part_ln2=e32(nrow, 3, C))
+    up = ops.gpt_block_desc(B, T, C, NH, resid_pdrop=pr, rng_state=rng, rng_stream=sb_up, rng_stream_below=sb_lo, below_colsum=True,
+                            x=x_up, mu1=mu1, rs1=rs1, dqkv=dqkv, g1=g1_up, g_below=o["g_below"], gd_below=o["gd_below"],
+                            part_ln1=o["part_ln1"], **bu)
+    lo = ops.gpt_block_desc(B, T, C, NH, resid_pdrop=pr, rng_state=rng, rng_stream=sb_lo, x1=x1_lo, mu2=mu2, rs2=rs2, h=h,
+                            g=o["g_below"], gd=o["gd_below"], gh=o["gh"], g1=o["g1"], gd2=o["gd2"], go=o["go"], part_ln2=o["part_ln2"],
+                            **bl)
+    assert up.bf16 and lo.bf16
+    ops.gpt_block_bwd_rows(up, lo)
+    got = dict(o)
+    for tag, part in (("1", o["part_ln1"]), ("2", o["part_ln2"])):
+        gw, gb, cs = e32(C), e32(C), e32(C)
+        ops.layernorm_bwd_finalize(part, nrow, C, gw, gb, cs)
+        got.update({"ln%s_gw" % tag: gw, "ln%s_gb" % tag: gb, "cs%s" % tag: cs})
+    # the separate kernels of GPT.bwd in the bf16 mode
+    ref = {}
+    ga = ops.linear_dx(dqkv, bu["wqkv"], out=e16(M, C))
+    ref["g_below"], ref["gd_below"] = e32(M, C), e16(M, C)
+    ref["ln1_gw"], ref["ln1_gb"], ref["cs1"] = e32(C), e32(C), e32(C)
+    ops.layernorm_bwd(ga, x_up, pu["ln1_w"], pu["ln1_b"], mu1, rs1, ref["g_below"], ref["ln1_gw"], ref["ln1_gb"], 0, dres=g1_up,
+                      dx_dropped=ref["gd_below"], drop_p=pr, rng_state=rng, rng_stream=sb_lo + 2, dx_colsum=ref["cs1"])
+    ref["gh"] = e16(M, 4 * C)
+    ops.linear_dx(ref["gd_below"], bl["w2"], out=ref["gh"], aux=h, ldaux=4 * C)
+    ga2 = ops.linear_dx(ref["gh"], bl["w1"], out=e16(M, C))
+    ref["g1"], ref["gd2"] = e32(M, C), e16(M, C)
+    ref["ln2_gw"], ref["ln2_gb"], ref["cs2"] = e32(C), e32(C), e32(C)
+    ops.layernorm_bwd(ga2, x1_lo, pl["ln2_w"], pl["ln2_b"], mu2, rs2, ref["g1"], ref["ln2_gw"], ref["ln2_gb"], 0, dres=ref["g_below"],
+                      dx_dropped=ref["gd2"], drop_p=pr, rng_state=rng, rng_stream=sb_lo + 1, dx_colsum=ref["cs2"])
+    ref["go"] = ops.linear_dx(ref["gd2"], bl["wproj"], out=e16(M, C))
+    torch.cuda.synchronize()
+    for name, want in ref.items():
+        # (the separate path rounds ga / ga2 to bf16 before the LayerNorm backward, the fused one keeps them fp32: a few ulps)
+        _close16(got[name], want, name, ulps=4.0)
