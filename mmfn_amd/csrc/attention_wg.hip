@@ -36,17 +36,22 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int NTHR = 512;   // 8 waves: two per SIMD
 
-template <int HS, int NT>
+// NT: 16-row tiles per contraction slice (T = 4 slices x 16 NT rows); NY: tiles per wave group on the OWNED side (a workgroup owns
+// 2 groups = 32 NY rows: T/2 with NY = NT - the (sample, head, half) form - or T/4 with NY = NT/2: four workgroups per (sample, head),
+// for T = 256 where the halves' accumulator sets and operands no longer fit and B = 16 needs the extra workgroups to fill the chip)
+template <int HS, int NT, int NY = NT>
 struct Shape {
   static constexpr int NC = HS / 16;                  // 16-column chunks of the head dimension (first product)
   static constexpr int NDT = HS / 16;                 // 16-wide output tiles of the second product
   static constexpr int NOWN = NDT >= 4 ? 4 : NDT;     // waves (of the 4 slices) that own output tiles in the merge
   static constexpr int W = NDT / NOWN;                // tiles per owner = consecutive floats per lane
-  static constexpr int G = 16 * NT;                   // rows per wave group
+  static constexpr int G = 16 * NY;                   // owned rows per wave group
+  static constexpr int GX = 16 * NT;                  // rows per contraction slice
+  static constexpr int PARTS = 2 * NT / NY;           // workgroups per (sample, head)
   static constexpr int NFOREIGN = NDT - W;            // tiles a wave hands to other owners (owners), NDT for non-owners
   // merge buffer: [group 2][slice 4][tile slot NDT][row tile NT][reg 4][lane 64] floats; owners never write their own
   static constexpr int SLOTS = NDT >= 4 ? NDT - W : NDT;
-  static constexpr int MERGE_FLOATS_PER_GROUP = 4 * SLOTS * NT * 4 * 64;
+  static constexpr int MERGE_FLOATS_PER_GROUP = 4 * SLOTS * NY * 4 * 64;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -101,23 +106,22 @@ struct Groups {
 // first row of this wave's tiles inside staged LDS matrices.  Lane (l15, l4) reads the float4 at columns 16c + 4*l4 of its
 // row: element e feeds MFMA step e, whose four k slots are then the columns {16c + 4*slot + e}: a permutation of the
 // chunk's columns, the same one on both operands.
-template <int HS, int NT, int NCOLS>
-__device__ __forceinline__ void product_phase(const float* A, const float* B, int col0, int l15, int l4, f32x4 (*acc)[NT]) {
+template <int HS, int NT, int NCOLS, int NY = NT>
+__device__ __forceinline__ void product_phase(const float* A, const float* B, int col0, int l15, int l4, f32x4 (*acc)[NY]) {
   constexpr int NC = NCOLS / 16, P = Pitch<HS>::P;
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    f32x4 fa[NT], fb[NT];
+    f32x4 fa[NT], fb[NY];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      fa[t] = *reinterpret_cast<const f32x4*>(A + (16 * t + l15) * P + col0 + 16 * c + 4 * l4);
-      fb[t] = *reinterpret_cast<const f32x4*>(B + (16 * t + l15) * P + col0 + 16 * c + 4 * l4);
-    }
+    for (int t = 0; t < NT; ++t) fa[t] = *reinterpret_cast<const f32x4*>(A + (16 * t + l15) * P + col0 + 16 * c + 4 * l4);
+#pragma unroll
+    for (int t = 0; t < NY; ++t) fb[t] = *reinterpret_cast<const f32x4*>(B + (16 * t + l15) * P + col0 + 16 * c + 4 * l4);
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int x = 0; x < NT; ++x)
 #pragma unroll
-        for (int y = 0; y < NT; ++y) acc[x][y] = mfma16(fa[x][e], fb[y][e], acc[x][y]);
+        for (int y = 0; y < NY; ++y) acc[x][y] = mfma16(fa[x][e], fb[y][e], acc[x][y]);
   }
 }
 
@@ -126,11 +130,11 @@ __device__ __forceinline__ void product_phase(const float* A, const float* B, in
 //   tail() is called right before the last group's MFMAs (the caller issues the next phase's loads there).
 // Every group is one barrier.  With NS >= 2 the group being written (columns of group g+1) was last read NS groups ago, one
 // or more barriers back; with NS == 1 the only group is overwritten, so a barrier separates its last reader from the write.
-template <int HS, int NT, int NPROD, typename TIO, typename Src, typename Prod, typename Tail>
+template <int HS, int NT, int NPROD, typename TIO, int NY = NT, typename Src, typename Prod, typename Tail>
 __device__ __forceinline__ void product_chain(float* sFull, float* sHalf, int tid, Src&& src, Prod&& prod, Tail&& tail) {
   constexpr int T = 64 * NT, NS = Groups<HS>::NS, COLS = Groups<HS>::COLS, N = NPROD * NS;
   Stager<HS, T, COLS, NTHR> stF;
-  Stager<HS, T / 2, COLS, NTHR> stH;
+  Stager<HS, 32 * NY, COLS, NTHR> stH;   // the workgroup's own rows: two groups of 16 NY
   const TIO* pf; const TIO* ph; size_t lf, lh;
   src(0, pf, lf, ph, lh);
   stF.issue(pf, lf, tid, 0);
@@ -160,9 +164,9 @@ __device__ __forceinline__ void product_chain(float* sFull, float* sHalf, int ti
 
 // out[y][j] += sum over this wave's contraction rows r of P[r][row 16y + ..] * R[r][dcol(.., j)]:  P is the accumulator
 // of product_phase ([x = contraction tile][y = output-row tile]), R the staged LDS matrix at the wave's first row.
-template <int HS, int NT>
-__device__ __forceinline__ void second_phase(const f32x4 (*Pm)[NT], const float* rows, int l15, int l4, f32x4 (*out)[HS / 16]) {
-  using S = Shape<HS, NT>;
+template <int HS, int NT, int NY = NT>
+__device__ __forceinline__ void second_phase(const f32x4 (*Pm)[NY], const float* rows, int l15, int l4, f32x4 (*out)[HS / 16]) {
+  using S = Shape<HS, NT, NY>;
   constexpr int NDT = S::NDT, W = S::W, NGR = NDT / W, P = Pitch<HS>::P;
 #pragma unroll
   for (int step = 0; step < 4 * NT; ++step) {
@@ -179,7 +183,7 @@ __device__ __forceinline__ void second_phase(const f32x4 (*Pm)[NT], const float*
       }
     }
 #pragma unroll
-    for (int y = 0; y < NT; ++y)
+    for (int y = 0; y < NY; ++y)
 #pragma unroll
       for (int j = 0; j < NDT; ++j) out[y][j] = mfma16(Pm[x][y][e], rv[j], out[y][j]);
   }
@@ -187,8 +191,8 @@ __device__ __forceinline__ void second_phase(const f32x4 (*Pm)[NT], const float*
 
 // One key-tile row (y) of second_phase: out[j] += sum_r P[r][row 16y + ..] * R[r][dcol(.., j)].  Used where the full
 // [NT][NDT] output set does not fit the register file beside both accumulator sets (dK/dV pass at head size 128).
-template <int HS, int NT>
-__device__ __forceinline__ void second_phase_row(const f32x4 (*Pm)[NT], int y, const float* rows, int l15, int l4, f32x4* out) {
+template <int HS, int NT, int NY = NT>
+__device__ __forceinline__ void second_phase_row(const f32x4 (*Pm)[NY], int y, const float* rows, int l15, int l4, f32x4* out) {
   using S = Shape<HS, NT>;
   constexpr int NDT = S::NDT, W = S::W, NGR = NDT / W, P = Pitch<HS>::P;
 #pragma unroll
@@ -281,11 +285,11 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 // LDS plan of a workgroup (8 waves, 512 threads), in floats.  The operand area holds, at different times, two staged
 // operand matrices for the products (T + T/2 rows), one T-row matrix for the second product, and the merge parking area.
-template <int HS, int NT>
+template <int HS, int NT, int NY = NT>
 struct Lds {
-  using S = Shape<HS, NT>;
+  using S = Shape<HS, NT, NY>;
   static constexpr int T = 64 * NT, P = Pitch<HS>::P;
-  static constexpr int FULL = T * P, HALF = (T / 2) * P;   // an operand with all T rows / with this workgroup's half
+  static constexpr int FULL = T * P, HALF = (32 * NY) * P;   // an operand with all T rows / with this workgroup's own rows
   static constexpr int OPERANDS = FULL + HALF;
   static constexpr int MERGE = 2 * S::MERGE_FLOATS_PER_GROUP;
   static constexpr int AREA = OPERANDS > MERGE ? OPERANDS : MERGE;
@@ -302,7 +306,16 @@ __device__ __forceinline__ bool decode_block(int NH, int B, int& half, int& hd, 
   b = pair / NH;
   return pair < NH * B;
 }
-__device__ __forceinline__ bool decode_block(const AttnArgs& a, int& half, int& hd, int& b) { return decode_block(a.NH, a.B, half, hd, b); }
+// PARTS workgroups per (sample, head), adjacent in their XCD's dispatch order like the two halves
+template <int PARTS>
+__device__ __forceinline__ bool decode_parts(int NH, int B, int& part, int& hd, int& b) {
+  const int L = blockIdx.x, xcd = L & 7, slot = L >> 3;
+  const int pair = (slot / PARTS) * 8 + xcd;
+  part = slot % PARTS;
+  hd = pair % NH;
+  b = pair / NH;
+  return pair < NH * B;
+}
 
 // dev instrumentation: s_memtime stamps of waves 0 and 7 of workgroup (0,0,0) at the phase boundaries
 __device__ __forceinline__ void stamp(const AttnArgs& a, int idx) {
@@ -312,7 +325,7 @@ __device__ __forceinline__ void stamp(const AttnArgs& a, int idx) {
 }
 
 // ---------------------------------------------------------------------------------------------------------- forward
-template <int HS, int NT, typename TIO>
+template <int HS, int NT, typename TIO, int NY = NT>
 __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
   // activations in the bf16 mode are bf16 in HBM: they are widened to fp32 on their way into LDS, the arithmetic is unchanged
   const TIO* io_q = reinterpret_cast<const TIO*>(a.q); const TIO* io_k = reinterpret_cast<const TIO*>(a.k);
@@ -320,45 +333,45 @@ __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
   TIO* io_o = reinterpret_cast<TIO*>(a.o); TIO* io_dq = reinterpret_cast<TIO*>(a.dq); TIO* io_dk = reinterpret_cast<TIO*>(a.dk);
   TIO* io_dv = reinterpret_cast<TIO*>(a.dv);
   (void)io_q; (void)io_k; (void)io_v; (void)io_dO; (void)io_o; (void)io_dq; (void)io_dk; (void)io_dv;
-  using S = Shape<HS, NT>;
-  using L = Lds<HS, NT>;
-  constexpr int NDT = S::NDT, G = S::G, T = 64 * NT, P = L::P;
+  using S = Shape<HS, NT, NY>;
+  using L = Lds<HS, NT, NY>;
+  constexpr int NDT = S::NDT, G = S::G, GX = S::GX, T = 64 * NT, P = L::P;
   __shared__ __attribute__((aligned(16))) float sm[L::AREA];
   __shared__ float sm_stat[2][2][4][G];   // [slice max | slice sum][query group][key slice][query]
   int half, hd, b;
-  if (!decode_block(a, half, hd, b)) return;
+  if (!decode_parts<S::PARTS>(a.NH, a.B, half, hd, b)) return;   // half: this workgroup's part of the queries
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int qg = w >> 2, ks = w & 3;
   const size_t rowbase = (size_t)b * T;
   const int q0 = half * 2 * G + qg * G;   // first query of this wave's group
-  const int k0 = ks * G;                  // first key of this wave's slice
+  const int k0 = ks * GX;                 // first key of this wave's slice
   const int kvlen = a.kv_len ? min(T, a.kv_len[b]) : T;
   const bool nokeys = kvlen <= 0;
   const size_t ld = a.ld;
   float* sK = sm;               // [T][P]
   float* sQ = sm + L::FULL;     // [T/2][P]: the queries of this half
   stamp(a, 0);
-  f32x4 s[NT][NT];   // S^T: [key tile][query tile], acc row = key 4*l4 + r, lane column = query l15
+  f32x4 s[NT][NY];   // S^T: [key tile][query tile], acc row = key 4*l4 + r, lane column = query l15
 #pragma unroll
   for (int x = 0; x < NT; ++x)
 #pragma unroll
-    for (int y = 0; y < NT; ++y) s[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int y = 0; y < NY; ++y) s[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
   Stager<HS, T, HS, NTHR> stV;   // V goes into flight under the last MFMAs of the first product, lands in LDS (over K / Q)
-  product_chain<HS, NT, 1, TIO>(
+  product_chain<HS, NT, 1, TIO, NY>(
       sK, sQ, tid,
       [&](int, const TIO*& pf, size_t& lf, const TIO*& ph, size_t& lh) {
         pf = io_k + rowbase * ld + hd * HS; lf = ld;
         ph = io_q + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
       },
-      [&](int, int col0) { product_phase<HS, NT, Groups<HS>::COLS>(sK + k0 * P, sQ + qg * G * P, col0, l15, l4, s); },
+      [&](int, int col0) { product_phase<HS, NT, Groups<HS>::COLS, NY>(sK + k0 * P, sQ + qg * G * P, col0, l15, l4, s); },
       [&]() { stV.issue(io_v + rowbase * ld + hd * HS, ld, tid); });
   stamp(a, 2);
   // ---- softmax over keys, flash-style across the four key slices: every slice normalises by its OWN row maximum, the
   // (max, sum) pairs meet in LDS once, then each slice rescales by exp(m_slice - m) / l
-  float mx[NT];
+  float mx[NY];
   const bool masked = a.kv_len != nullptr;   // the fusion transformers pass no key mask: no per-element key test there (block-uniform)
 #pragma unroll
-  for (int y = 0; y < NT; ++y) {
+  for (int y = 0; y < NY; ++y) {
     float m = -INFINITY;
     if (!masked) {
 #pragma unroll
@@ -402,7 +415,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
   dr.init(a, b, hd);
   const bool drop = dr.on;
 #pragma unroll
-  for (int y = 0; y < NT; ++y) {
+  for (int y = 0; y < NY; ++y) {
     const int qi = 16 * y + l15;
     float m = sm_stat[0][qg][0][qi];
 #pragma unroll
@@ -427,15 +440,15 @@ __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
   __syncthreads();   // V staged
   stamp(a, 3);
   // ---- O = P . V over this wave's key slice, then the four slices are summed
-  f32x4 o[NT][NDT];
+  f32x4 o[NY][NDT];
 #pragma unroll
-  for (int y = 0; y < NT; ++y)
+  for (int y = 0; y < NY; ++y)
 #pragma unroll
     for (int j = 0; j < NDT; ++j) o[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  second_phase<HS, NT>(s, sm + k0 * P, l15, l4, o);
+  second_phase<HS, NT, NY>(s, sm + k0 * P, l15, l4, o);
   stamp(a, 4);
   __syncthreads();   // V no longer read: the area becomes the merge parking space
-  merge_store<HS, NT, TIO>(o, sm, qg, ks, lane, l15, l4, io_o + (rowbase + q0) * a.ldo + hd * HS, a.ldo);
+  merge_store<HS, NY, TIO>(o, sm, qg, ks, lane, l15, l4, io_o + (rowbase + q0) * a.ldo + hd * HS, a.ldo);
   stamp(a, 5);
 }
 
@@ -630,7 +643,7 @@ __global__ __launch_bounds__(NTHR) void gpt_attn_fwd_kernel(const GptArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------- backward, query-owned: dQ, delta
-template <int HS, int NT, typename TIO>
+template <int HS, int NT, typename TIO, int NY = NT>
 __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
   // activations in the bf16 mode are bf16 in HBM: they are widened to fp32 on their way into LDS, the arithmetic is unchanged
   const TIO* io_q = reinterpret_cast<const TIO*>(a.q); const TIO* io_k = reinterpret_cast<const TIO*>(a.k);
@@ -638,36 +651,36 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
   TIO* io_o = reinterpret_cast<TIO*>(a.o); TIO* io_dq = reinterpret_cast<TIO*>(a.dq); TIO* io_dk = reinterpret_cast<TIO*>(a.dk);
   TIO* io_dv = reinterpret_cast<TIO*>(a.dv);
   (void)io_q; (void)io_k; (void)io_v; (void)io_dO; (void)io_o; (void)io_dq; (void)io_dk; (void)io_dv;
-  using S = Shape<HS, NT>;
-  using L = Lds<HS, NT>;
-  constexpr int NDT = S::NDT, G = S::G, T = 64 * NT, P = L::P;
+  using S = Shape<HS, NT, NY>;
+  using L = Lds<HS, NT, NY>;
+  constexpr int NDT = S::NDT, G = S::G, GX = S::GX, T = 64 * NT, P = L::P;
   __shared__ __attribute__((aligned(16))) float sm[L::AREA];
   __shared__ float sm_stat[2][2][4][G];   // [sum P dP | sum P][query group][key slice][query]
   int half, hd, b;
-  if (!decode_block(a, half, hd, b)) return;
+  if (!decode_parts<S::PARTS>(a.NH, a.B, half, hd, b)) return;
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int qg = w >> 2, ks = w & 3;
   const size_t rowbase = (size_t)b * T;
   const int q0 = half * 2 * G + qg * G;
-  const int k0 = ks * G;
+  const int k0 = ks * GX;
   const int kvlen = a.kv_len ? min(T, a.kv_len[b]) : T;
   const bool nokeys = kvlen <= 0;   // constant scores: P = 1/T, dS = 0
   const size_t ld = a.ld;
   const size_t statbase = ((size_t)b * a.NH + hd) * T;
   float* sA = sm;               // [T][P]: K, then V, then K again
   float* sB = sm + L::FULL;     // [T/2][P]: Q, then dO of this half
-  float lse_y[NT];   // issued before the products: used right after them
+  float lse_y[NY];   // issued before the products: used right after them
 #pragma unroll
-  for (int y = 0; y < NT; ++y) lse_y[y] = a.lse[statbase + q0 + 16 * y + l15];
-  f32x4 acc[2][NT][NT];   // [0] S^T = K Q^T, [1] dP^T = V dO^T
+  for (int y = 0; y < NY; ++y) lse_y[y] = a.lse[statbase + q0 + 16 * y + l15];
+  f32x4 acc[2][NT][NY];   // [0] S^T = K Q^T, [1] dP^T = V dO^T
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int x = 0; x < NT; ++x)
 #pragma unroll
-      for (int y = 0; y < NT; ++y) acc[p][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int y = 0; y < NY; ++y) acc[p][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
   Stager<HS, T, HS, NTHR> stK;   // K again, for dQ = dS K: in flight under the last MFMAs, committed once V is no longer read
-  product_chain<HS, NT, 2, TIO>(
+  product_chain<HS, NT, 2, TIO, NY>(
       sA, sB, tid,
       [&](int i, const TIO*& pf, size_t& lf, const TIO*& ph, size_t& lh) {
         if (i == 0) {
@@ -678,7 +691,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
           ph = io_dO + (rowbase + half * 2 * G) * a.ldo + hd * HS; lh = a.ldo;
         }
       },
-      [&](int i, int col0) { product_phase<HS, NT, Groups<HS>::COLS>(sA + k0 * P, sB + qg * G * P, col0, l15, l4, acc[i]); },
+      [&](int i, int col0) { product_phase<HS, NT, Groups<HS>::COLS, NY>(sA + k0 * P, sB + qg * G * P, col0, l15, l4, acc[i]); },
       [&]() { stK.issue(io_k + rowbase * ld + hd * HS, ld, tid); });
   __syncthreads();
   stK.commit(sA, tid);
@@ -687,7 +700,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
   const bool drop = dr.on;
   const bool masked = a.kv_len != nullptr;
 #pragma unroll
-  for (int y = 0; y < NT; ++y) {
+  for (int y = 0; y < NY; ++y) {
     const int q = q0 + 16 * y + l15;
     const float lse = lse_y[y];
     float dl = 0.f, ps = 0.f;
@@ -715,7 +728,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
   }
   __syncthreads();   // statistics visible, K staged
 #pragma unroll
-  for (int y = 0; y < NT; ++y) {
+  for (int y = 0; y < NY; ++y) {
     const int qi = 16 * y + l15;
     // P is recomputed from the rounded log-sum-exp, so sum_j P_j = 1 + O(1e-6); dividing by it keeps sum_j dS_j = 0 to
     // rounding (attention.hip).  All slices add in the same order, so they agree on delta bit for bit.
@@ -729,18 +742,18 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
       for (int r = 0; r < 4; ++r)
         acc[0][x][y][r] = nokeys ? 0.f : acc[0][x][y][r] * (acc[1][x][y][r] - delta) * a.scale;
   }
-  f32x4 dq[NT][NDT];
+  f32x4 dq[NY][NDT];
 #pragma unroll
-  for (int y = 0; y < NT; ++y)
+  for (int y = 0; y < NY; ++y)
 #pragma unroll
     for (int j = 0; j < NDT; ++j) dq[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  second_phase<HS, NT>(acc[0], sA + k0 * P, l15, l4, dq);
+  second_phase<HS, NT, NY>(acc[0], sA + k0 * P, l15, l4, dq);
   __syncthreads();
-  merge_store<HS, NT, TIO>(dq, sm, qg, ks, lane, l15, l4, io_dq + (rowbase + q0) * a.ldg + hd * HS, a.ldg);
+  merge_store<HS, NY, TIO>(dq, sm, qg, ks, lane, l15, l4, io_dq + (rowbase + q0) * a.ldg + hd * HS, a.ldg);
 }
 
 // ------------------------------------------------------------------------------------------ backward, key-owned: dK, dV
-template <int HS, int NT, typename TIO>
+template <int HS, int NT, typename TIO, int NY = NT>
 __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
   // activations in the bf16 mode are bf16 in HBM: they are widened to fp32 on their way into LDS, the arithmetic is unchanged
   const TIO* io_q = reinterpret_cast<const TIO*>(a.q); const TIO* io_k = reinterpret_cast<const TIO*>(a.k);
@@ -748,18 +761,18 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
   TIO* io_o = reinterpret_cast<TIO*>(a.o); TIO* io_dq = reinterpret_cast<TIO*>(a.dq); TIO* io_dk = reinterpret_cast<TIO*>(a.dk);
   TIO* io_dv = reinterpret_cast<TIO*>(a.dv);
   (void)io_q; (void)io_k; (void)io_v; (void)io_dO; (void)io_o; (void)io_dq; (void)io_dk; (void)io_dv;
-  using S = Shape<HS, NT>;
-  using L = Lds<HS, NT>;
-  constexpr int NDT = S::NDT, G = S::G, T = 64 * NT, P = L::P;
+  using S = Shape<HS, NT, NY>;
+  using L = Lds<HS, NT, NY>;
+  constexpr int NDT = S::NDT, G = S::G, GX = S::GX, T = 64 * NT, P = L::P;
   __shared__ __attribute__((aligned(16))) float sm[L::AREA];
-  __shared__ float sm_rows[8][2][G];   // per wave: log-sum-exp and delta of its G queries
+  __shared__ float sm_rows[8][2][GX];   // per wave: log-sum-exp and delta of the GX queries of its slice
   int half, hd, b;
-  if (!decode_block(a, half, hd, b)) return;
+  if (!decode_parts<S::PARTS>(a.NH, a.B, half, hd, b)) return;   // half: this workgroup's part of the keys
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int kg = w >> 2, qs = w & 3;
   const size_t rowbase = (size_t)b * T;
   const int k0 = half * 2 * G + kg * G;   // first key of this wave's group
-  const int q0 = qs * G;                  // first query of this wave's slice
+  const int q0 = qs * GX;                 // first query of this wave's slice
   const int kvlen = a.kv_len ? min(T, a.kv_len[b]) : T;
   const bool nokeys = kvlen <= 0;
   const size_t ld = a.ld;
@@ -768,19 +781,19 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
   float* sB = sm + L::FULL;     // [T/2][P]: K, then V of this half
   // the wave's G per-query statistics go to a wave-private LDS strip now (one coalesced load each), and are picked up
   // after the products: no register cost, no global-load latency between the phases
-  if (lane < G) {
+  if (lane < GX) {
     sm_rows[w][0][lane] = a.lse[statbase + q0 + lane];
     sm_rows[w][1][lane] = a.delta[statbase + q0 + lane];
   }
-  f32x4 acc[2][NT][NT];   // [0] S = Q K^T, [1] dP = dO V^T: [query tile][key tile], acc row = query 4*l4 + r, column = key
+  f32x4 acc[2][NT][NY];   // [0] S = Q K^T, [1] dP = dO V^T: [query tile][key tile], acc row = query 4*l4 + r, column = key
 #pragma unroll
   for (int p = 0; p < 2; ++p)
 #pragma unroll
     for (int x = 0; x < NT; ++x)
 #pragma unroll
-      for (int y = 0; y < NT; ++y) acc[p][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int y = 0; y < NY; ++y) acc[p][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
   Stager<HS, T, HS, NTHR> stA;   // Q again (for dK): issued before the dV product, committed after the dV merge
-  product_chain<HS, NT, 2, TIO>(
+  product_chain<HS, NT, 2, TIO, NY>(
       sA, sB, tid,
       [&](int i, const TIO*& pf, size_t& lf, const TIO*& ph, size_t& lh) {
         if (i == 0) {
@@ -791,7 +804,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
           ph = io_v + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
         }
       },
-      [&](int i, int col0) { product_phase<HS, NT, Groups<HS>::COLS>(sA + q0 * P, sB + kg * G * P, col0, l15, l4, acc[i]); },
+      [&](int i, int col0) { product_phase<HS, NT, Groups<HS>::COLS, NY>(sA + q0 * P, sB + kg * G * P, col0, l15, l4, acc[i]); },
       [&]() {});
   Drop dr;
   dr.init(a, b, hd);
@@ -805,7 +818,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
       const int q = q0 + qi;
       const float lse = sm_rows[w][0][qi], dlt = sm_rows[w][1][qi];   // written by this wave (same lanes < G): in order
 #pragma unroll
-      for (int y = 0; y < NT; ++y) {
+      for (int y = 0; y < NY; ++y) {
         const int key = k0 + 16 * y + l15;
         float p;
         if (!masked) p = mmfn_exp(acc[0][x][y][r] * a.scale - lse);
@@ -820,7 +833,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
         acc[1][x][y][r] = nokeys ? 0.f : p * (acc[1][x][y][r] * msc - dlt) * a.scale;         // dK = dS^T Q
       }
     }
-  if constexpr ((HS == 128 && NT == 3) || NT == 4) {
+  if constexpr (HS == 128 && NT == 3 && NY == 3) {
     // one key-tile row at a time: 8 output tiles (32 registers) instead of 24 beside the two accumulator sets, and a
     // merge of a third of the size, which fits the half-operand area (sB) - so the full-operand area keeps dO / Q
     stA.issue(io_q + rowbase * ld + hd * HS, ld, tid);
@@ -832,7 +845,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
         f32x4 g1[1][NDT];
 #pragma unroll
         for (int j = 0; j < NDT; ++j) g1[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        second_phase_row<HS, NT>(acc[prod], y, sA + q0 * P, l15, l4, g1[0]);
+        second_phase_row<HS, NT, NY>(acc[prod], y, sA + q0 * P, l15, l4, g1[0]);
         __syncthreads();   // sB free: V (first pass) / the previous merge's copies have been read
         if (prod == 0 && y == NT - 1) stA.commit(sA, tid);   // dO is no longer read
         TIO* dst = (prod == 0 ? io_dv : io_dk) + (rowbase + k0 + 16 * y) * a.ldg + hd * HS;
@@ -841,25 +854,25 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
     }
     return;
   }
-  f32x4 g[NT][NDT];
+  f32x4 g[NY][NDT];
 #pragma unroll
-  for (int y = 0; y < NT; ++y)
+  for (int y = 0; y < NY; ++y)
 #pragma unroll
     for (int j = 0; j < NDT; ++j) g[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   stA.issue(io_q + rowbase * ld + hd * HS, ld, tid);          // Q again (for dK), in flight under the dV product
-  second_phase<HS, NT>(acc[0], sA + q0 * P, l15, l4, g);     // dO is still staged
+  second_phase<HS, NT, NY>(acc[0], sA + q0 * P, l15, l4, g);     // dO is still staged
   __syncthreads();
-  merge_store<HS, NT, TIO>(g, sm, kg, qs, lane, l15, l4, io_dv + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
+  merge_store<HS, NY, TIO>(g, sm, kg, qs, lane, l15, l4, io_dv + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
   __syncthreads();   // every owner has read the dV copies before the area is reused
   stA.commit(sA, tid);
   __syncthreads();
 #pragma unroll
-  for (int y = 0; y < NT; ++y)
+  for (int y = 0; y < NY; ++y)
 #pragma unroll
     for (int j = 0; j < NDT; ++j) g[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  second_phase<HS, NT>(acc[1], sA + q0 * P, l15, l4, g);
+  second_phase<HS, NT, NY>(acc[1], sA + q0 * P, l15, l4, g);
   __syncthreads();
-  merge_store<HS, NT, TIO>(g, sm, kg, qs, lane, l15, l4, io_dk + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
+  merge_store<HS, NY, TIO>(g, sm, kg, qs, lane, l15, l4, io_dk + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
 }
 
 #ifdef MMFN_ATTN_STAMPS   // experiment builds (tools/experiments/attn_phases.sh): phase time stamps of the forward kernel
@@ -872,26 +885,26 @@ long long* debug_buffer() {
 long long* debug_buffer() { return nullptr; }   // (phase time stamps of the forward kernel: a development build option, off)
 #endif
 
-template <int HS, int NT, typename TIO>
+template <int HS, int NT, typename TIO, int NY>
 int launch_io(int which, const AttnArgs& a_in, hipStream_t s) {
   AttnArgs a = a_in;
   a.dbg = which == 0 ? debug_buffer() : nullptr;
-  dim3 grid(2 * 8 * ceil_div(a.NH * a.B, 8));
-  if (which == 0) hipLaunchKernelGGL((attn_wg_fwd_kernel<HS, NT, TIO>), grid, dim3(NTHR), 0, s, a);
-  else if (which == 1) hipLaunchKernelGGL((attn_wg_dq_kernel<HS, NT, TIO>), grid, dim3(NTHR), 0, s, a);
-  else hipLaunchKernelGGL((attn_wg_dkv_kernel<HS, NT, TIO>), grid, dim3(NTHR), 0, s, a);
+  dim3 grid(Shape<HS, NT, NY>::PARTS * 8 * ceil_div(a.NH * a.B, 8));
+  if (which == 0) hipLaunchKernelGGL((attn_wg_fwd_kernel<HS, NT, TIO, NY>), grid, dim3(NTHR), 0, s, a);
+  else if (which == 1) hipLaunchKernelGGL((attn_wg_dq_kernel<HS, NT, TIO, NY>), grid, dim3(NTHR), 0, s, a);
+  else hipLaunchKernelGGL((attn_wg_dkv_kernel<HS, NT, TIO, NY>), grid, dim3(NTHR), 0, s, a);
   MMFN_LAUNCH_CHECK();
   return 0;
 }
 
-template <int HS, int NT>
+template <int HS, int NT, int NY = NT>
 int launch(int which, const AttnArgs& a, hipStream_t s) {
-  return a.io_bf16 ? launch_io<HS, NT, bf16_t>(which, a, s) : launch_io<HS, NT, float>(which, a, s);
+  return a.io_bf16 ? launch_io<HS, NT, bf16_t, NY>(which, a, s) : launch_io<HS, NT, float, NY>(which, a, s);
 }
 
-template <int HS, int NT>
-constexpr bool fits_lds() {   // the largest of the three kernels: operand area + sm_stat[2][2][4][G] / sm_rows[8][2][G]
-  return (Lds<HS, NT>::AREA + 16 * Shape<HS, NT>::G) * 4 <= 160 * 1024;
+template <int HS, int NT, int NY = NT>
+constexpr bool fits_lds() {   // the largest of the three kernels: operand area + sm_stat[2][2][4][G] / sm_rows[8][2][GX]
+  return (Lds<HS, NT, NY>::AREA + 16 * Shape<HS, NT, NY>::GX) * 4 <= 160 * 1024;
 }
 
 template <int HS>
@@ -900,12 +913,12 @@ int by_tokens(int which, const AttnArgs& a, hipStream_t s) {
     case 64: return launch<HS, 1>(which, a, s);
     case 128: return launch<HS, 2>(which, a, s);
     case 192: return launch<HS, 3>(which, a, s);
-    // several frames / views per sample, the rad variant's 256 tokens: the same kernels where a workgroup's operands
-    // ((T + T/2) rows x (HS + 4) floats) fit the CU's LDS AND the key-owned pass keeps its two T/4 x T/8 accumulator sets in
-    // registers - head sizes 16 and 32 (measured at B = 16 against the tile kernels of attention.hip: T = 256 forward 18 -> 13 /
-    // 20 -> 17 us, backward 48 -> 38 / 58 -> 53 us).  Head size 64 spills in dK/dV and gains nothing; head size 128 does not fit
-    // from T = 256 on (203 KB): both stay with the tile kernels, like every longer sequence.
-    case 256: if constexpr (HS <= 32 && fits_lds<HS, 4>()) return launch<HS, 4>(which, a, s); break;
+    // the rad variant's 256 tokens (and several frames / views per sample): FOUR workgroups per (sample, head), each owning T/4 = 64
+    // queries (forward, dQ) or keys (dK/dV) against all 256 of the other side - at B = 16 that is 256 workgroups (the halves were
+    // 128: half the chip), the key-owned pass holds two 4 x 2-tile accumulator sets (64 registers) instead of two 4 x 4 (128: it
+    // spilled 20-75 registers at head sizes 16 / 32), and the operands ((256 + 64) rows x (HS + 4) floats) fit LDS up to head size
+    // 64.  Head size 128 (169 KB) stays with the tile kernels of attention.hip, like every longer sequence.
+    case 256: if constexpr (HS <= 64 && fits_lds<HS, 4, 2>()) return launch<HS, 4, 2>(which, a, s); break;
   }
   return -1;
 }

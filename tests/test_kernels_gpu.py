@@ -356,7 +356,7 @@ def test_gap_and_transpose():
 @pytest.mark.parametrize("T,NH,HS", [(192, 4, 16), (192, 4, 32), (192, 4, 64), (192, 4, 128), (256, 4, 128),
                                      (128, 2, 64), (128, 4, 128), (64, 2, 64), (64, 3, 32), (9, 2, 64), (50, 2, 64),
                                      (384, 4, 16), (384, 4, 32), (320, 4, 64), (384, 4, 128),     # seq_len / n_views > 1: tile kernels ...
-                                     (256, 4, 16), (256, 4, 32), (320, 4, 16)])    # ... and the workgroup kernels where they fit
+                                     (256, 4, 16), (256, 4, 32), (256, 4, 64), (320, 4, 16)])    # ... and the workgroup kernels where they fit (T = 256: four per (sample, head))
 @pytest.mark.parametrize("masked", [False, True])
 def test_attention(T, NH, HS, masked):
     from mmfn_amd import ops
