@@ -140,7 +140,7 @@ def attention_roofline(eng, B, dev, iters=20):
         us = e0.elapsed_time(e1) / iters * 1e3
         tf = products * unit / (us * 1e-6) / 1e12
         out[name] = {"us": round(us, 1), "achieved": round(tf, 1), "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 3),
-                     "kernels": ("attn_wg_fwd" if name == "fwd" else "attn_wg_dq + attn_wg_dkv") if (T <= 192 or HS <= 64)
+                     "kernels": ("attn_wg_fwd" if name == "fwd" else "attn_wg_dq + attn_wg_dkv") if T in (64, 128, 192, 256)
                      else ("attn_fwd (attention.hip tile kernels)" if name == "fwd" else "attn_bwd_dq + attn_bwd_dkv (attention.hip tile kernels)")}
     return out
 

@@ -91,6 +91,14 @@ struct Stager {
         *reinterpret_cast<f32x4*>(dst + (u / Q) * Pitch<HS>::P + col0 + 4 * (u % Q)) = r[i];
     }
   }
+  // the same columns as a matrix of their own: [NROWS][NCOLS] with row pitch NCOLS + 4 (a column-group window, product_chain_w)
+  __device__ __forceinline__ void commit_window(float* dst, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int u = tid + i * NTHR;
+      if (UNITS % NTHR == 0 || u < UNITS) *reinterpret_cast<f32x4*>(dst + (u / Q) * (NCOLS + 4) + 4 * (u % Q)) = r[i];
+    }
+  }
 };
 
 // Column groups of the first products: the operands arrive in NS groups of HS / NS columns; group g+1 is in flight
@@ -157,6 +165,67 @@ __device__ __forceinline__ void product_chain(float* sFull, float* sHalf, int ti
       if (NS == 1) __syncthreads();
       stF.commit(sFull, tid, ((i + 1) % NS) * COLS);
       stH.commit(sHalf, tid, ((i + 1) % NS) * COLS);
+      __syncthreads();
+    }
+  }
+}
+
+// ---- windowed first products (T = 256 at head size 128).  The all-T operand of a first product is only ever read one column
+// group at a time, so it need not be resident as a [T][HS] matrix (135 KB: with the workgroup's own rows 169 KB > LDS): its
+// column groups pass through a two-slot ring of [T][COLS + 4] windows (2 x 37 KB), the own-row operand keeps its full-width
+// layout.  Slot (g+1) % 2 is rewritten while group g is multiplied; it was last read by group g-1, one barrier back.
+template <int HS, int NT, int NCOLS, int NY>
+__device__ __forceinline__ void product_phase_w(const float* Aw, const float* B, int col0, int l15, int l4, f32x4 (*acc)[NY]) {
+  constexpr int NC = NCOLS / 16, P = Pitch<HS>::P, PW = NCOLS + 4;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    f32x4 fa[NT], fb[NY];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) fa[t] = *reinterpret_cast<const f32x4*>(Aw + (16 * t + l15) * PW + 16 * c + 4 * l4);
+#pragma unroll
+    for (int t = 0; t < NY; ++t) fb[t] = *reinterpret_cast<const f32x4*>(B + (16 * t + l15) * P + col0 + 16 * c + 4 * l4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int x = 0; x < NT; ++x)
+#pragma unroll
+        for (int y = 0; y < NY; ++y) acc[x][y] = mfma16(fa[x][e], fb[y][e], acc[x][y]);
+  }
+}
+
+template <int HS, int NT>
+struct Window {
+  static constexpr int COLS = Groups<HS>::COLS, PW = COLS + 4, SLOT = 64 * NT * PW, RING = 2 * SLOT;
+};
+
+// prod(i, window, col0): window = the ring slot holding columns [col0, col0 + COLS) of product i's all-T operand
+template <int HS, int NT, int NPROD, typename TIO, int NY, typename Src, typename Prod, typename Tail>
+__device__ __forceinline__ void product_chain_w(float* sRing, float* sHalf, int tid, Src&& src, Prod&& prod, Tail&& tail) {
+  constexpr int T = 64 * NT, NS = Groups<HS>::NS, COLS = Groups<HS>::COLS, N = NPROD * NS, SLOT = Window<HS, NT>::SLOT;
+  static_assert(NS >= 2, "a window ring needs at least two column groups");
+  Stager<HS, T, COLS, NTHR> stF;
+  Stager<HS, 32 * NY, COLS, NTHR> stH;
+  const TIO* pf; const TIO* ph; size_t lf, lh;
+  src(0, pf, lf, ph, lh);
+  stF.issue(pf, lf, tid, 0);
+  stH.issue(ph, lh, tid, 0);
+  stF.commit_window(sRing, tid);
+  stH.commit(sHalf, tid, 0);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int col0 = (i % NS) * COLS;
+    if (i + 1 < N) {
+      src((i + 1) / NS, pf, lf, ph, lh);
+      stF.issue(pf, lf, tid, ((i + 1) % NS) * COLS);
+      stH.issue(ph, lh, tid, ((i + 1) % NS) * COLS);
+    } else {
+      tail();
+    }
+    prod(i / NS, sRing + (i & 1) * SLOT, col0);
+    if (i + 1 < N) {
+      stF.commit_window(sRing + ((i + 1) & 1) * SLOT, tid);
+      stH.commit(sHalf, tid, ((i + 1) % NS) * COLS);   // (a product's own-row columns are new; the next product's overwrite group 0 last read NS - 1 barriers ago)
       __syncthreads();
     }
   }
@@ -290,8 +359,13 @@ struct Lds {
   using S = Shape<HS, NT, NY>;
   static constexpr int T = 64 * NT, P = Pitch<HS>::P;
   static constexpr int FULL = T * P, HALF = (32 * NY) * P;   // an operand with all T rows / with this workgroup's own rows
-  static constexpr int OPERANDS = FULL + HALF;
   static constexpr int MERGE = 2 * S::MERGE_FLOATS_PER_GROUP;
+  // WIN: the resident form (all-T operand + own rows) would not fit the CU's 160 KB beside the statistics: first products through
+  // the window ring (product_chain_w); the second products' all-T operand (FULL) then has the area to itself
+  static constexpr bool WIN = (FULL + HALF + 16 * S::GX) * 4 > 160 * 1024;
+  static constexpr int RING = WIN ? Window<HS, NT>::RING : 0;
+  static constexpr int OWN = WIN ? RING : FULL;            // offset of the own-row operand
+  static constexpr int OPERANDS = WIN ? (RING + HALF > FULL ? RING + HALF : FULL) : FULL + HALF;
   static constexpr int AREA = OPERANDS > MERGE ? OPERANDS : MERGE;
 };
 
@@ -348,8 +422,8 @@ __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
   const int kvlen = a.kv_len ? min(T, a.kv_len[b]) : T;
   const bool nokeys = kvlen <= 0;
   const size_t ld = a.ld;
-  float* sK = sm;               // [T][P]
-  float* sQ = sm + L::FULL;     // [T/2][P]: the queries of this half
+  float* sK = sm;               // [T][P] (windowed form: the ring of K's column groups)
+  float* sQ = sm + L::OWN;      // [2G][P]: the queries of this workgroup
   stamp(a, 0);
   f32x4 s[NT][NY];   // S^T: [key tile][query tile], acc row = key 4*l4 + r, lane column = query l15
 #pragma unroll
@@ -357,14 +431,23 @@ __global__ __launch_bounds__(NTHR) void attn_wg_fwd_kernel(const AttnArgs a) {
 #pragma unroll
     for (int y = 0; y < NY; ++y) s[x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
   Stager<HS, T, HS, NTHR> stV;   // V goes into flight under the last MFMAs of the first product, lands in LDS (over K / Q)
-  product_chain<HS, NT, 1, TIO, NY>(
-      sK, sQ, tid,
-      [&](int, const TIO*& pf, size_t& lf, const TIO*& ph, size_t& lh) {
-        pf = io_k + rowbase * ld + hd * HS; lf = ld;
-        ph = io_q + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
-      },
-      [&](int, int col0) { product_phase<HS, NT, Groups<HS>::COLS, NY>(sK + k0 * P, sQ + qg * G * P, col0, l15, l4, s); },
-      [&]() { stV.issue(io_v + rowbase * ld + hd * HS, ld, tid); });
+  auto src = [&](int, const TIO*& pf, size_t& lf, const TIO*& ph, size_t& lh) {
+    pf = io_k + rowbase * ld + hd * HS; lf = ld;
+    ph = io_q + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
+  };
+  auto tail = [&]() { stV.issue(io_v + rowbase * ld + hd * HS, ld, tid); };
+  if constexpr (L::WIN) {
+    constexpr int PW = Window<HS, NT>::PW;
+    product_chain_w<HS, NT, 1, TIO, NY>(
+        sm, sQ, tid, src,
+        [&](int, const float* win, int col0) { product_phase_w<HS, NT, Groups<HS>::COLS, NY>(win + k0 * PW, sQ + qg * G * P, col0, l15, l4, s); },
+        tail);
+  } else {
+    product_chain<HS, NT, 1, TIO, NY>(
+        sK, sQ, tid, src,
+        [&](int, int col0) { product_phase<HS, NT, Groups<HS>::COLS, NY>(sK + k0 * P, sQ + qg * G * P, col0, l15, l4, s); },
+        tail);
+  }
   stamp(a, 2);
   // ---- softmax over keys, flash-style across the four key slices: every slice normalises by its OWN row maximum, the
   // (max, sum) pairs meet in LDS once, then each slice rescales by exp(m_slice - m) / l
@@ -668,7 +751,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
   const size_t ld = a.ld;
   const size_t statbase = ((size_t)b * a.NH + hd) * T;
   float* sA = sm;               // [T][P]: K, then V, then K again
-  float* sB = sm + L::FULL;     // [T/2][P]: Q, then dO of this half
+  float* sB = sm + L::OWN;      // [2G][P]: Q, then dO of this workgroup's queries
   float lse_y[NY];   // issued before the products: used right after them
 #pragma unroll
   for (int y = 0; y < NY; ++y) lse_y[y] = a.lse[statbase + q0 + 16 * y + l15];
@@ -680,19 +763,28 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dq_kernel(const AttnArgs a) {
 #pragma unroll
       for (int y = 0; y < NY; ++y) acc[p][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
   Stager<HS, T, HS, NTHR> stK;   // K again, for dQ = dS K: in flight under the last MFMAs, committed once V is no longer read
-  product_chain<HS, NT, 2, TIO, NY>(
-      sA, sB, tid,
-      [&](int i, const TIO*& pf, size_t& lf, const TIO*& ph, size_t& lh) {
-        if (i == 0) {
-          pf = io_k + rowbase * ld + hd * HS; lf = ld;
-          ph = io_q + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
-        } else {
-          pf = io_v + rowbase * ld + hd * HS; lf = ld;
-          ph = io_dO + (rowbase + half * 2 * G) * a.ldo + hd * HS; lh = a.ldo;
-        }
-      },
-      [&](int i, int col0) { product_phase<HS, NT, Groups<HS>::COLS, NY>(sA + k0 * P, sB + qg * G * P, col0, l15, l4, acc[i]); },
-      [&]() { stK.issue(io_k + rowbase * ld + hd * HS, ld, tid); });
+  auto src = [&](int i, const TIO*& pf, size_t& lf, const TIO*& ph, size_t& lh) {
+    if (i == 0) {
+      pf = io_k + rowbase * ld + hd * HS; lf = ld;
+      ph = io_q + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
+    } else {
+      pf = io_v + rowbase * ld + hd * HS; lf = ld;
+      ph = io_dO + (rowbase + half * 2 * G) * a.ldo + hd * HS; lh = a.ldo;
+    }
+  };
+  auto tail = [&]() { stK.issue(io_k + rowbase * ld + hd * HS, ld, tid); };
+  if constexpr (L::WIN) {
+    constexpr int PW = Window<HS, NT>::PW;
+    product_chain_w<HS, NT, 2, TIO, NY>(
+        sm, sB, tid, src,
+        [&](int i, const float* win, int col0) { product_phase_w<HS, NT, Groups<HS>::COLS, NY>(win + k0 * PW, sB + qg * G * P, col0, l15, l4, acc[i]); },
+        tail);
+  } else {
+    product_chain<HS, NT, 2, TIO, NY>(
+        sA, sB, tid, src,
+        [&](int i, int col0) { product_phase<HS, NT, Groups<HS>::COLS, NY>(sA + k0 * P, sB + qg * G * P, col0, l15, l4, acc[i]); },
+        tail);
+  }
   __syncthreads();
   stK.commit(sA, tid);
   Drop dr;
@@ -778,7 +870,7 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
   const size_t ld = a.ld;
   const size_t statbase = ((size_t)b * a.NH + hd) * T;
   float* sA = sm;               // [T][P]: Q, then dO (kept for dV), then Q again
-  float* sB = sm + L::FULL;     // [T/2][P]: K, then V of this half
+  float* sB = sm + L::OWN;      // [2G][P]: K, then V of this workgroup's keys
   // the wave's G per-query statistics go to a wave-private LDS strip now (one coalesced load each), and are picked up
   // after the products: no register cost, no global-load latency between the phases
   if (lane < GX) {
@@ -793,19 +885,30 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
 #pragma unroll
       for (int y = 0; y < NY; ++y) acc[p][x][y] = f32x4{0.f, 0.f, 0.f, 0.f};
   Stager<HS, T, HS, NTHR> stA;   // Q again (for dK): issued before the dV product, committed after the dV merge
-  product_chain<HS, NT, 2, TIO, NY>(
-      sA, sB, tid,
-      [&](int i, const TIO*& pf, size_t& lf, const TIO*& ph, size_t& lh) {
-        if (i == 0) {
-          pf = io_q + rowbase * ld + hd * HS; lf = ld;
-          ph = io_k + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
-        } else {
-          pf = io_dO + rowbase * a.ldo + hd * HS; lf = a.ldo;
-          ph = io_v + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
-        }
-      },
-      [&](int i, int col0) { product_phase<HS, NT, Groups<HS>::COLS, NY>(sA + q0 * P, sB + kg * G * P, col0, l15, l4, acc[i]); },
-      [&]() {});
+  Stager<HS, T / 2, HS, NTHR> stHalf;   // windowed form: the all-T operands of the second products arrive in two row halves (32 registers)
+  auto src = [&](int i, const TIO*& pf, size_t& lf, const TIO*& ph, size_t& lh) {
+    if (i == 0) {
+      pf = io_q + rowbase * ld + hd * HS; lf = ld;
+      ph = io_k + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
+    } else {
+      pf = io_dO + rowbase * a.ldo + hd * HS; lf = a.ldo;
+      ph = io_v + (rowbase + half * 2 * G) * ld + hd * HS; lh = ld;
+    }
+  };
+  if constexpr (L::WIN) {
+    // the products saw dO one window at a time: the whole matrix (for dV) goes into flight under the last group's MFMAs and the
+    // softmax recomputation, and lands once nobody reads the ring any more
+    constexpr int PW = Window<HS, NT>::PW;
+    product_chain_w<HS, NT, 2, TIO, NY>(
+        sm, sB, tid, src,
+        [&](int i, const float* win, int col0) { product_phase_w<HS, NT, Groups<HS>::COLS, NY>(win + q0 * PW, sB + kg * G * P, col0, l15, l4, acc[i]); },
+        [&]() { stHalf.issue(io_dO + rowbase * a.ldo + hd * HS, a.ldo, tid); });
+  } else {
+    product_chain<HS, NT, 2, TIO, NY>(
+        sA, sB, tid, src,
+        [&](int i, int col0) { product_phase<HS, NT, Groups<HS>::COLS, NY>(sA + q0 * P, sB + kg * G * P, col0, l15, l4, acc[i]); },
+        [&]() {});
+  }
   Drop dr;
   dr.init(a, b, hd);
   const bool drop = dr.on;
@@ -831,6 +934,12 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
         if (drop) msc = dr.scale(q, key, T);
         acc[0][x][y][r] = p * msc;                                                           // dV = (P o mask)^T dO
         acc[1][x][y][r] = nokeys ? 0.f : p * (acc[1][x][y][r] * msc - dlt) * a.scale;         // dK = dS^T Q
+        if constexpr (L::WIN) {
+          // materialise both values HERE: left alone, the compiler sinks these expressions to their uses (the second products'
+          // MFMA operands), which keeps p, the mask scale, the log-sum-exp and delta of every element alive across the dV phase
+          // (~60 registers: this instantiation then spills)
+          asm volatile("" : "+v"(acc[0][x][y][r]), "+v"(acc[1][x][y][r]));
+        }
       }
     }
   if constexpr (HS == 128 && NT == 3 && NY == 3) {
@@ -859,12 +968,31 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
   for (int y = 0; y < NY; ++y)
 #pragma unroll
     for (int j = 0; j < NDT; ++j) g[y][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  stA.issue(io_q + rowbase * ld + hd * HS, ld, tid);          // Q again (for dK), in flight under the dV product
-  second_phase<HS, NT, NY>(acc[0], sA + q0 * P, l15, l4, g);     // dO is still staged
+  if constexpr (L::WIN) {
+    __syncthreads();        // the window ring and the own rows are no longer read
+    stHalf.commit(sA, tid);    // dO for dV: rows 0 .. T/2 (in flight since the last group), then the rest
+    stHalf.issue(io_dO + (rowbase + T / 2) * a.ldo + hd * HS, a.ldo, tid);
+    stHalf.commit(sA + (T / 2) * P, tid);
+    __syncthreads();
+  } else {
+    stA.issue(io_q + rowbase * ld + hd * HS, ld, tid);          // Q again (for dK), in flight under the dV product
+  }
+  second_phase<HS, NT, NY>(acc[0], sA + q0 * P, l15, l4, g);     // dO is staged
+  if constexpr (L::WIN) {   // Q (for dK): its first half travels under the dV merge - and not earlier (registers): the index is laundered
+    int t2 = tid;           // so that the loads cannot be hoisted above the product's MFMAs
+    asm volatile("" : "+v"(t2));
+    stHalf.issue(io_q + rowbase * ld + hd * HS, ld, t2);
+  }
   __syncthreads();
   merge_store<HS, NY, TIO>(g, sm, kg, qs, lane, l15, l4, io_dv + (rowbase + k0) * a.ldg + hd * HS, a.ldg);
   __syncthreads();   // every owner has read the dV copies before the area is reused
-  stA.commit(sA, tid);
+  if constexpr (L::WIN) {
+    stHalf.commit(sA, tid);
+    stHalf.issue(io_q + (rowbase + T / 2) * ld + hd * HS, ld, tid);
+    stHalf.commit(sA + (T / 2) * P, tid);
+  } else {
+    stA.commit(sA, tid);
+  }
   __syncthreads();
 #pragma unroll
   for (int y = 0; y < NY; ++y)
@@ -917,8 +1045,8 @@ int by_tokens(int which, const AttnArgs& a, hipStream_t s) {
     // queries (forward, dQ) or keys (dK/dV) against all 256 of the other side - at B = 16 that is 256 workgroups (the halves were
     // 128: half the chip), the key-owned pass holds two 4 x 2-tile accumulator sets (64 registers) instead of two 4 x 4 (128: it
     // spilled 20-75 registers at head sizes 16 / 32), and the operands ((256 + 64) rows x (HS + 4) floats) fit LDS up to head size
-    // 64.  Head size 128 (169 KB) stays with the tile kernels of attention.hip, like every longer sequence.
-    case 256: if constexpr (HS <= 64 && fits_lds<HS, 4, 2>()) return launch<HS, 4, 2>(which, a, s); break;
+    // 64; at head size 128 (169 KB) the first products run through a ring of column-group windows (product_chain_w).
+    case 256: return launch<HS, 4, 2>(which, a, s);
   }
   return -1;
 }
