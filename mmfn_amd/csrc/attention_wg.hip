@@ -19,11 +19,11 @@
 //   * the four slices meet through LDS three times: row max, row sum (delta in the backward), and the partial output
 //     tiles - each wave finishes the quarter of the head dimension it owns, so the merge is balanced as well and the
 //     result leaves as 64..128-byte contiguous runs per row;
-//   * the key-owned pass at head size 128 keeps BOTH accumulator sets (P o mask for dV, dS for dK: 72 registers) across
-//     its two second products, so it runs them one 16-key row at a time (8 output tiles = 32 registers instead of 96) and
-//     merges each row in the half-operand area, which leaves dO / Q in place: 0 bytes of scratch where the whole-tile
-//     form spilled 77 registers (312 bytes per lane), 62.6 -> 54 us.  build.check_scratch() fails the build on scratch in
-//     any kernel not named in scratch_allowlist.txt.
+//   * the key-owned pass keeps BOTH accumulator sets (P o mask for dV, dS for dK: 72 registers at T = 192) across its two
+//     second products; at head size 128 (96 more for the output tiles, 48 for the operand in flight) the recomputed
+//     probabilities are pinned where they are formed (an empty asm per element) - left to itself the compiler sinks those
+//     expressions to their MFMA uses and keeps every element's inputs alive instead: 312 bytes of scratch per lane and
+//     62.6 us up to round 5, none and 54 us now.  build.check_scratch() fails the build on scratch in any kernel.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -255,31 +255,6 @@ __device__ __forceinline__ void second_phase(const f32x4 (*Pm)[NY], const float*
     for (int y = 0; y < NY; ++y)
 #pragma unroll
       for (int j = 0; j < NDT; ++j) out[y][j] = mfma16(Pm[x][y][e], rv[j], out[y][j]);
-  }
-}
-
-// One key-tile row (y) of second_phase: out[j] += sum_r P[r][row 16y + ..] * R[r][dcol(.., j)].  Used where the full
-// [NT][NDT] output set does not fit the register file beside both accumulator sets (dK/dV pass at head size 128).
-template <int HS, int NT, int NY = NT>
-__device__ __forceinline__ void second_phase_row(const f32x4 (*Pm)[NY], int y, const float* rows, int l15, int l4, f32x4* out) {
-  using S = Shape<HS, NT>;
-  constexpr int NDT = S::NDT, W = S::W, NGR = NDT / W, P = Pitch<HS>::P;
-#pragma unroll
-  for (int step = 0; step < 4 * NT; ++step) {
-    const int x = step >> 2, e = step & 3;
-    const float* p = rows + (16 * x + 4 * l4 + e) * P + l15 * W;
-    float rv[NDT];
-#pragma unroll
-    for (int g = 0; g < NGR; ++g) {
-      if (W == 2) {
-        const f32x2 t = *reinterpret_cast<const f32x2*>(p + 32 * g);
-        rv[2 * g] = t[0]; rv[2 * g + 1] = t[1];
-      } else {
-        rv[g] = p[16 * g];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NDT; ++j) out[j] = mfma16(Pm[x][y][e], rv[j], out[j]);
   }
 }
 
@@ -934,35 +909,14 @@ __global__ __launch_bounds__(NTHR) void attn_wg_dkv_kernel(const AttnArgs a) {
         if (drop) msc = dr.scale(q, key, T);
         acc[0][x][y][r] = p * msc;                                                           // dV = (P o mask)^T dO
         acc[1][x][y][r] = nokeys ? 0.f : p * (acc[1][x][y][r] * msc - dlt) * a.scale;         // dK = dS^T Q
-        if constexpr (L::WIN) {
+        if constexpr (HS == 128) {
           // materialise both values HERE: left alone, the compiler sinks these expressions to their uses (the second products'
           // MFMA operands), which keeps p, the mask scale, the log-sum-exp and delta of every element alive across the dV phase
-          // (~60 registers: this instantiation then spills)
+          // (~60-80 registers: at head size 128 the pass then spills - 312 bytes per lane at T = 192 up to round 5)
           asm volatile("" : "+v"(acc[0][x][y][r]), "+v"(acc[1][x][y][r]));
         }
       }
     }
-  if constexpr (HS == 128 && NT == 3 && NY == 3) {
-    // one key-tile row at a time: 8 output tiles (32 registers) instead of 24 beside the two accumulator sets, and a
-    // merge of a third of the size, which fits the half-operand area (sB) - so the full-operand area keeps dO / Q
-    stA.issue(io_q + rowbase * ld + hd * HS, ld, tid);
-#pragma unroll
-    for (int prod = 0; prod < 2; ++prod) {
-#pragma unroll
-      for (int y = 0; y < NT; ++y) {
-        __builtin_amdgcn_sched_barrier(0);   // keeps one row's MFMAs from being interleaved with the next (register pressure)
-        f32x4 g1[1][NDT];
-#pragma unroll
-        for (int j = 0; j < NDT; ++j) g1[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        second_phase_row<HS, NT, NY>(acc[prod], y, sA + q0 * P, l15, l4, g1[0]);
-        __syncthreads();   // sB free: V (first pass) / the previous merge's copies have been read
-        if (prod == 0 && y == NT - 1) stA.commit(sA, tid);   // dO is no longer read
-        TIO* dst = (prod == 0 ? io_dv : io_dk) + (rowbase + k0 + 16 * y) * a.ldg + hd * HS;
-        merge_store<HS, 1, TIO>(g1, sB, kg, qs, lane, l15, l4, dst, a.ldg);
-      }
-    }
-    return;
-  }
   f32x4 g[NY][NDT];
 #pragma unroll
   for (int y = 0; y < NY; ++y)
