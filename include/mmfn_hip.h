@@ -415,8 +415,11 @@ typedef struct mmfn_gpt_block_desc {
   int32_t below_colsum;  /* part_ln1 carries a third row: the column sums of what leaves in gd_below (or g_below) */
   int32_t reserved;
 } mmfn_gpt_block_desc;
-/* MMFN_EINVAL unless C in {64, 128}, NH == 4, T == 192 */
+/* MMFN_EINVAL unless C in {64, 128}, NH == 4, T == 192: all of the block's fused launches (the attention launch is shaped for 192 tokens) */
 int mmfn_gpt_block_supported(int C, int NH, int T);
+/* the row-block launches alone (mlp_fwd, bwd_rows; attention and its projections as separate launches): C in {64, 128}, T % 32 == 0 -
+ * the rad variant's 256 tokens, the bf16 mode */
+int mmfn_gpt_block_rows_supported(int C, int T);
 int mmfn_sizeof_gpt_block_desc(void);
 /* Development aid (builds with -DMMFN_GPT_STAMPS): 64 s_memtime stamps of workgroup 0 (waves 0 and 7) of the last row-block launch
  * to HOST memory; MMFN_EINVAL when the instrumentation is off. */

@@ -437,8 +437,8 @@ __global__ __launch_bounds__(NTHR) void gpt_bwd_rows_kernel(const GptArgs up, co
   }
 }
 
-bool shape_ok(const GptArgs& d) {
-  return mmfn_gpt_block_supported(d.C, d.NH, d.T) == 0 && d.B > 0 && ((size_t)d.B * d.T) % R == 0;
+bool shape_ok(const GptArgs& d) {   // the row-block kernels see B * T rows: any token count whose rows tile by 32
+  return mmfn_gpt_block_rows_supported(d.C, d.T) == 0 && d.B > 0 && ((size_t)d.B * d.T) % R == 0;
 }
 
 }  // namespace
@@ -458,6 +458,9 @@ extern "C" int mmfn_sizeof_gpt_block_desc(void) { return (int)sizeof(mmfn_gpt_bl
 
 extern "C" int mmfn_gpt_block_supported(int C, int NH, int T) {
   return ((C == 64 || C == 128) && NH == 4 && T == 192) ? 0 : MMFN_EINVAL;
+}
+extern "C" int mmfn_gpt_block_rows_supported(int C, int T) {
+  return ((C == 64 || C == 128) && T > 0 && T % 32 == 0) ? 0 : MMFN_EINVAL;
 }
 
 namespace {

@@ -666,12 +666,13 @@ class GPT(object):
                 x1 = bufs.get("%s.b%d.x1" % (nm, i), (M, C), sdt)
                 x2 = bufs.get("%s.b%d.x2" % (nm, i), (M, C), sdt)
                 a, o, a2, h = S_a[i], S_o[i], S_a2[i], S_h[i]
-                if ctx.bf16:
+                if not self.fused_attn_now(ctx):   # bf16 mode, or a token count the fused attention launch is not shaped for (rad: 256)
                     ln1.fwd(ctx, x, out=a)
-                    ops.linear_fwd(a, blk["wqkv16"], blk["bqkv"], out=qkv)
+                    ops.linear_fwd(a, blk["wqkv16"] if ctx.bf16 else blk["wqkv"], blk["bqkv"], out=qkv)
                     ops.attention_fwd(qkv[:, C:], qkv, qkv[:, 2 * C:], 3 * C, o, C, lse, B, T, nh, hs, scale, drop_p=p_attn,
                                       rng_state=ctx.rng_state, rng_stream=sb)
-                    d = self._desc(blk, B, ctx, sb, weights="fwd16", x=x, o=o, x1=x1, a2=a2, mu2=mu2, rs2=rs2, h=h, x2=x2)
+                    d = self._desc(blk, B, ctx, sb, weights="fwd16" if ctx.bf16 else "f32", x=x, o=o, x1=x1, a2=a2, mu2=mu2, rs2=rs2,
+                                   h=h, x2=x2)
                 else:
                     d = self._desc(blk, B, ctx, sb, x=x, a=a, mu1=mu1, rs1=rs1, qkv=qkv, o=o, lse=lse, x1=x1, a2=a2, mu2=mu2,
                                    rs2=rs2, h=h, x2=x2)
@@ -723,7 +724,11 @@ class GPT(object):
     def fused_now(self, ctx):
         """The fused block kernels serve this transformer in this pass: fp32 mode and arithmetic, n_embd 64 / 128, 4 heads, T = 192."""
         return (GPT_FUSED != "0" and (ctx.bf16 or ops.current_precision() == "f32")
-                and ops.gpt_block_supported(self.C, self.nh, self.T))
+                and ops.gpt_block_rows_supported(self.C, self.T))
+
+    def fused_attn_now(self, ctx):
+        """... and the attention launch with the projections as its prologue too (fp32, 4 heads, 192 tokens)."""
+        return not ctx.bf16 and ops.gpt_block_supported(self.C, self.nh, self.T)
 
     def _desc(self, blk, B, ctx, sb, sb_below=0, below_colsum=False, weights="f32", **tensors):
         """weights: "f32" the master weights; "fwd16" / "bwd16" the bf16 mode's [out][in] / transposed [in][out] shadows."""

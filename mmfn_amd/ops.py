@@ -1015,6 +1015,10 @@ def gpt_block_supported(C, NH, T):
     return lib().mmfn_gpt_block_supported(C, NH, T) == 0
 
 
+def gpt_block_rows_supported(C, T):
+    return lib().mmfn_gpt_block_rows_supported(C, T) == 0
+
+
 def gpt_block_desc(B, T, C, NH, eps=1e-5, attn_pdrop=0.0, resid_pdrop=0.0, rng_state=None, rng_stream=0, rng_stream_below=0,
                    below_colsum=False, **tensors):
     """mmfn_gpt_block_desc (include/mmfn_hip.h): tensors by field name (contiguous); missing fields stay NULL.  fp32 everywhere on the
