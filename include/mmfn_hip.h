@@ -233,6 +233,51 @@ int mmfn_gemm_bf16_stats_rows(const mmfn_gemm16_desc* d);
  * of 8, 16-byte aligned pointers; conv wgrad needs OW and OH*OW powers of two. */
 int mmfn_gemm_bf16(const mmfn_gemm16_desc* d, void* stream);
 
+/* ---- bf16 training mode: 3x3 stride-1 pad-1 convolution with the halo patch of a pixel tile resident in LDS and the
+ * PRODUCER's elementwise pass applied while the patch is staged (csrc/conv16_halo.hip).
+ * Replaces, per torchvision BasicBlock convolution (model_vec.py:509-521,539-593 - resnet.py BasicBlock.forward: conv -> bn ->
+ * relu -> conv -> bn -> += identity -> relu), TWO aten dispatches of the reference's autocast step with one launch:
+ *   pro 1, flip 0: native_batch_norm's apply (+ add + relu) of the layer below  +  cudnn convolution forward;
+ *   pro 2, flip 1: native_batch_norm_backward's elementwise pass              +  cudnn convolution backward-data;
+ *   pro 0:         the convolution alone (input already an activation).
+ * Operands bf16 [B, H, W, K] (contraction channels K = 64 .. 512, multiple of 64) and w bf16 [N][3][3][K] (forward: the filter
+ * [Cout][3][3][Cin]; data gradient: the [Cin][3][3][Cout] shadow of mmfn_shadow_transpose_bf16, taps reversed by `flip`);
+ * out bf16 [B, H, W, N], N a multiple of 64; H, W powers of two >= 8 (W) / 4 (H).  The k order is the implicit GEMM's, so on
+ * equal inputs `out` equals mmfn_gemm_bf16's MMFN_G16_CONV_FWD / _DGRAD bit for bit. */
+typedef struct mmfn_conv16_halo_desc {
+  const void* x;        /* pro 0: the activation; pro 1: the producer's convolution output co; pro 2: g = dL/dy of the BatchNorm */
+  const void* w;
+  void* out;
+  double* stats;        /* optional partial sums [mmfn_conv3x3_halo_bf16_stats_rows()][2][N], by stats_mode (0 / 2 of mmfn_gemm16_desc) */
+  const void* out_res;  /* optional bf16 [B, H, W, N] added to the output (a skip connection's gradient joining the data gradient) */
+  const void* bn2_y;    /* stats_mode 2: as mmfn_gemm16_desc.bn_y / bn_x / bn_mean / bn_rstd */
+  const void* bn2_x;
+  const float* bn2_mean;
+  const float* bn2_rstd;
+  const float* p_mean;  /* prologue: [K] batch mean / rstd / BatchNorm weight / bias of the producer */
+  const float* p_rstd;
+  const float* p_weight;
+  const float* p_bias;  /* pro 1 */
+  const float* p_means; /* pro 2: [2][K] = mean(ge), mean(ge * xhat) (mmfn_bn_bwd_finalize_f64) */
+  const void* p_res;    /* pro 1: optional residual bf16 [B, H, W, K] added before the ReLU */
+  const void* p_y;      /* pro 2: optional BatchNorm output whose sign gates g (ReLU) */
+  const void* p_x;      /* pro 2: the BatchNorm input (the producer's convolution output) */
+  void* a_out;          /* optional bf16 [B, H, W, K]: the applied tensor (pro 1: y; pro 2: dco), written once by the tile that owns a pixel */
+  void* ge_out;         /* pro 2, optional: the ReLU-masked g */
+  int32_t B, H, W, K, N;
+  int32_t pro;          /* 0 / 1 / 2 */
+  int32_t relu;         /* pro 1 */
+  int32_t flip;         /* 1: tap (kh, kw) multiplies the pixel at (1 - kh, 1 - kw) (data gradient) instead of (kh - 1, kw - 1) */
+  int32_t tile;         /* 0 auto, 1 = 128 pixels x 64 channels, 2 = 128 x 128, 3 = 64 x 64, 4 = 64 x 128 */
+  int32_t stages;       /* filter ring depth: 0 auto, 2 .. 4 */
+  int32_t stats_mode;
+} mmfn_conv16_halo_desc;
+int mmfn_sizeof_conv16_halo_desc(void);
+/* the tile a launch of this descriptor would use, 0 if the shape is not served (the caller then runs apply + mmfn_gemm_bf16) */
+int mmfn_conv3x3_halo_bf16_ok(const mmfn_conv16_halo_desc* d);
+int mmfn_conv3x3_halo_bf16_stats_rows(const mmfn_conv16_halo_desc* d);
+int mmfn_conv3x3_halo_bf16(const mmfn_conv16_halo_desc* d, void* stream);
+
 /* C = epilogue(A*B).  Replaces aten addmm / cudnn convolution fwd, dgrad, wgrad dispatched by
  * nn.Linear (model_vec.py:82-89,121-123,...) and torchvision ResNet convs (model_vec.py:509-575). */
 int mmfn_gemm_f32(const mmfn_gemm_desc* d, void* stream);
@@ -532,6 +577,9 @@ int mmfn_colsum_partials_f64(const double* partials, int rows, int C, float* out
 int mmfn_bn_bwd_partials_bf16(const double* partials, int rows, const void* g, const void* y, const void* x, int64_t M, int C,
                               const float* mean, const float* rstd, const float* weight, void* dx, void* ge_out, float* dweight,
                               float* dbias, void* workspace, void* stream);
+/* The finalize half of mmfn_bn_bwd_partials_bf16 alone: dweight, dbias and means[2][C] = (mean ge, mean ge * xhat) from partial rows
+ * [rows][2][C]; the elementwise half of native_batch_norm_backward then runs in the loader of mmfn_conv3x3_halo_bf16 (pro 2). */
+int mmfn_bn_bwd_finalize_f64(const double* partials, int rows, int64_t M, int C, float* dweight, float* dbias, float* means, void* stream);
 int mmfn_maxpool3x3s2_fwd_bf16(const void* x, void* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
 int mmfn_maxpool3x3s2_bwd_bf16(const void* gy, const uint8_t* idx, void* gx, int B, int H, int W, int C, void* stream);
 /* tok_is_f32 / gtok_is_f32: the token matrix / the token gradient is the fp32 residual stream (features stay bf16); the fp32

@@ -68,6 +68,14 @@ class GptBlockDesc(ctypes.Structure):
     ]
 
 
+class Conv16HaloDesc(ctypes.Structure):
+    """mmfn_conv16_halo_desc (include/mmfn_hip.h): the LDS-resident-patch 3x3 convolution of the bf16 mode."""
+    _PTRS = ("x", "w", "out", "stats", "out_res", "bn2_y", "bn2_x", "bn2_mean", "bn2_rstd", "p_mean", "p_rstd", "p_weight", "p_bias",
+             "p_means", "p_res", "p_y", "p_x", "a_out", "ge_out")
+    _fields_ = [(n, _vp) for n in _PTRS] + [(n, _i32) for n in ("B", "H", "W", "K", "N", "pro", "relu", "flip", "tile", "stages",
+                                                                "stats_mode")]
+
+
 G16_NT, G16_CONV_FWD, G16_CONV_DGRAD, G16_TN, G16_CONV_WGRAD = 0, 1, 2, 3, 4
 EPI16_OUT_F32 = 1024
 EPI16_RES_F32 = 2048
@@ -127,6 +135,8 @@ def lib():
             raise MMFNLibraryError("mmfn_gemm_desc layout mismatch between C and ctypes")
         if handle.mmfn_sizeof_gemm16_desc() != ctypes.sizeof(Gemm16Desc):
             raise MMFNLibraryError("mmfn_gemm16_desc layout mismatch between C and ctypes")
+        if handle.mmfn_sizeof_conv16_halo_desc() != ctypes.sizeof(Conv16HaloDesc):
+            raise MMFNLibraryError("mmfn_conv16_halo_desc layout mismatch between C and ctypes")
         if handle.mmfn_sizeof_gpt_block_desc() != ctypes.sizeof(GptBlockDesc):
             raise MMFNLibraryError("mmfn_gpt_block_desc layout mismatch between C and ctypes")
         _lib = handle

@@ -815,6 +815,16 @@ extern "C" int mmfn_bn_bwd_partials_bf16(const double* partials, int rows, const
   return 0;
 }
 
+/* the finalize half of mmfn_bn_bwd_partials_bf16 alone (the elementwise half runs in the loader of mmfn_conv3x3_halo_bf16, pro 2) */
+extern "C" int mmfn_bn_bwd_finalize_f64(const double* partials, int rows, int64_t M, int C, float* dweight, float* dbias, float* means,
+                                        void* stream) {
+  if (!partials || rows <= 0 || C <= 0 || M <= 0 || !dweight || !dbias || !means) return MMFN_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, FIN_COLS)), dim3(FIN_COLS * FIN_LANES), 0, (hipStream_t)stream, partials, rows, M, C,
+                     dweight, dbias, means);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int mmfn_colsum_batched_f32(const float* in, int batch, int64_t stride_in, int64_t M, int C, int ld, float* out,
                                        int64_t stride_out, void* workspace, void* stream) {
   return colsum_batched_launch(in, batch, stride_in, M, C, ld, out, stride_out, workspace, stream);

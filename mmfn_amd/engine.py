@@ -132,6 +132,17 @@ FUSE_BN_BWD_REDUCE = True   # see ConvBN.bwd16 (bf16 mode)
 LAZY_BN_APPLY = os.environ.get("MMFN_LAZY_BN", "1") == "1"
 
 
+# bf16 mode: the same laziness - a 3x3 stride-1 convolution whose input is the PendingBN of its producer runs as
+# mmfn_conv3x3_halo_bf16 (csrc/conv16_halo.hip), which applies the producer's BatchNorm (+ skip + ReLU) while it stages its halo
+# patch and writes the activation for the pixels it owns.  Measured per shape (tools/halo_bench.py, B = 32): 64 / 128 contraction
+# channels 1.3-1.4 x the apply + implicit-GEMM pair; 256 / 512 channels are bound by the filter stream per 64-pixel tile and stay on
+# the implicit GEMM (MMFN_HALO_MAX_K).  MMFN_HALO_CONV=0 restores round 5's launch sequence.
+HALO_MAX_K = int(os.environ.get("MMFN_HALO_MAX_K", "128"))
+# backward: 0 = implicit-GEMM data gradients (round 5), 1 = the halo kernel as the data gradient, 2 = also the BatchNorm backward's
+# elementwise pass in its loader (ConvBN.bwd16)
+HALO_BWD = int(os.environ.get("MMFN_HALO_BWD", "2"))
+
+
 class PendingBN(object):
     """The output of a ConvBN whose BatchNorm apply (+ residual) (+ ReLU) has not run: the convolution output and the batch
     statistics are in HBM, the activation y = [relu](bn(co) [+ res]) is not.  Two ways out:
@@ -147,7 +158,7 @@ class PendingBN(object):
         self.y = None
 
     def _out(self, ctx):
-        return ctx.bufs.get(self.owner.name + ".out", self.shape)
+        return ctx.bufs.get(self.owner.name + ".out", self.shape, ctx.adt if ctx.bf16 else torch.float32)
 
     def tensor(self, ctx):
         if self.y is None:
@@ -221,12 +232,24 @@ class ConvBN(object):
         ops.linear_dw(dco.view(-1, Co), col, out=dwp)
         ops.repitch_rows(dwp, self.gw, Co, K, KP, K)
 
-    def fwd16(self, ctx, x, relu=True, res=None):
+    def fwd16(self, ctx, x, relu=True, res=None, lazy=False):
         """bf16 mode.  A trunk convolution (bf16 input): direct implicit GEMM on the bf16 MFMA pipe whose epilogue also emits
         the BatchNorm batch-statistics partial sums of its fp32 accumulators (no statistics pass over the output); a stem (fp32
         input from the ingest kernels, 3 / 2 channels): the fp32 convolution, fp32 output, and the BatchNorm apply is where the
         activation becomes bf16."""
         from . import ops16
+        # the LDS-resident-patch kernel (3x3 stride 1): takes the producer's PendingBN as it is and applies it in its loader
+        halo = x.dtype == torch.bfloat16 and x.shape[-1] <= HALO_MAX_K and ops16.halo_ok(tuple(x.shape), tuple(self.w.shape), self.stride, self.pad) > 0
+        x_bn = None
+        if isinstance(x, PendingBN):
+            if halo and x.y is None and LAZY_BN_APPLY:
+                pend = x
+                x_bn = pend.consume(ctx, True)    # (res, mean, rstd, weight, bias, relu, y_out): y is written by this convolution
+                xin, x = pend.co, pend.y
+            else:
+                x = xin = x.tensor(ctx)
+        else:
+            xin = x
         _, oshape = ops.conv_geom(x.shape, self.w.shape, self.stride, self.pad)
         M = oshape[0] * oshape[1] * oshape[2]
         stem = x.dtype == torch.float32
@@ -250,6 +273,13 @@ class ConvBN(object):
                                         bn.num_batches_tracked, bn.eps, bn.momentum)
             else:
                 ops.conv2d_fwd(x, self.w, self.stride, self.pad, out=co)
+        elif halo:
+            ws = ops.norm_workspace(x.device, 2 * ((M + 63) // 64) * 2 * self.cout * 8) if ctx.training else None
+            bn_apply = None if x_bn is None else (x_bn[1], x_bn[2], x_bn[3], x_bn[4], x_bn[0], x_bn[5], x_bn[6])
+            rows = ops16.conv3x3_halo(xin, self.w16, co, stats=ws, bn_apply=bn_apply)
+            if ctx.training:
+                ops.bn_finalize_stats(ws, rows, M, self.cout, mean, rstd, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                      bn.eps, bn.momentum)
         elif ctx.training:
             ws = ops.norm_workspace(x.device, 2 * ((M + 63) // 64) * 2 * self.cout * 8)   # sized for the smallest tile
             ops16.conv2d_fwd(x, self.w16, self.stride, self.pad, co, stats=ws)
@@ -260,11 +290,11 @@ class ConvBN(object):
             ops16.conv2d_fwd(x, self.w16, self.stride, self.pad, co)
         if not ctx.training:
             ops.bn_eval_prepare(bn.running_mean, bn.running_var, mean, rstd, bn.eps)
-        y = ctx.bufs.get(self.name + ".out", oshape, ctx.adt)
-        ops.bn_apply(co.view(M, self.cout), y.view(M, self.cout), mean, rstd, self.bn_w, self.bn_b, relu,
-                     res=None if res is None else res.view(M, self.cout))
-        self.saved = (x, co, y, mean, rstd, relu)
-        return y
+        self.saved = [x, co, None, mean, rstd, relu]   # saved[2]: the activation, written by PendingBN.tensor() or by the consumer's loader
+        pend = PendingBN(self, co, res, relu)
+        if lazy and LAZY_BN_APPLY and HALO_MAX_K > 0:
+            return pend
+        return pend.tensor(ctx)
 
     def bwd16(self, ctx, g, need_dx=True, ge_out=None, dx_res=None, mask_y=None, emit=None):
         """emit: the ConvBN whose BatchNorm receives THIS call's data gradient as its output gradient (the layer below on the
@@ -276,7 +306,18 @@ class ConvBN(object):
         dco = ctx.bufs.get(self.name + ".dconv", co.shape, co.dtype)
         ymask = (y if mask_y is None else mask_y).view(M, self.cout) if relu else None
         pre, self._pre = getattr(self, "_pre", None), None
-        if pre is not None and mask_y is None and co.dtype == torch.bfloat16:
+        # data gradient through the LDS-resident-patch kernel (3x3 stride 1, contraction = this layer's output channels); with the
+        # reductions already emitted by the layer above (`pre`) the BatchNorm backward's elementwise pass runs in ITS loader: the
+        # chain is finalize -> data gradient (which writes dco for the weight gradient) instead of finalize -> apply -> data gradient
+        halo_dg = need_dx and HALO_BWD >= 1 and x.dtype == torch.bfloat16 and co.dtype == torch.bfloat16 and self.cout <= HALO_MAX_K and \
+            ops16.halo_ok(tuple(co.shape), tuple(self.w16t.shape), self.stride, self.pad) > 0
+        fuse = halo_dg and HALO_BWD >= 2 and pre is not None and mask_y is None
+        bn_bwd_arg = None
+        if fuse:
+            means = ctx.bufs.get(self.name + ".bnmeans", (2, self.cout))
+            ops16.bn_bwd_finalize(pre[0], pre[1], M, self.cout, self.g_bn_w, self.g_bn_b, means)
+            bn_bwd_arg = (mean, rstd, self.bn_w, means, y if relu else None, co, dco, ge_out)
+        elif pre is not None and mask_y is None and co.dtype == torch.bfloat16:
             ops16.bn_bwd_partials(pre[0], pre[1], g.view(M, self.cout), ymask, co.view(M, self.cout), mean, rstd, self.bn_w,
                                   dco.view(M, self.cout), self.g_bn_w, self.g_bn_b,
                                   ge_out=None if ge_out is None else ge_out.view(M, self.cout))
@@ -289,7 +330,8 @@ class ConvBN(object):
             else:
                 ops.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, out=self.gw)
             return None
-        ops16.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, self.gw)
+        if not fuse:
+            ops16.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, self.gw)
         if not need_dx:
             return None
         dx = ctx.bufs.get(self.name + ".dx", x.shape, ctx.adt)
@@ -300,6 +342,14 @@ class ConvBN(object):
             Mx = x.shape[0] * x.shape[1] * x.shape[2]
             part = ctx.bufs.get(emit.name + ".bnpart", (ops16.max_stats_rows(Mx), 2, cin), torch.float64)
             extra = dict(stats=part, stats_mode=2, bn=(ey if erelu else None, eco, emean, erstd))
+        if halo_dg:
+            rows = ops16.conv3x3_halo(g if fuse else dco, self.w16t, dx, flip=True, out_res=dx_res, stats=extra.get("stats"), stats_mode=2,
+                                      bn2=extra.get("bn"), bn_bwd=bn_bwd_arg)
+            if "stats" in extra:
+                emit._pre = (extra["stats"], rows)
+            if fuse:   # dco exists only now: the loader of the data gradient wrote it
+                ops16.conv2d_wgrad(dco, x, tuple(self.w.shape), self.stride, self.pad, self.gw)
+            return dx
         if dx_res is not None:
             extra.update(res=dx_res.view(-1, cin), ldr=cin)
         ops16.conv2d_dgrad(dco, self.w16t, tuple(x.shape), tuple(self.w.shape), self.stride, self.pad, dx, **extra)
@@ -313,7 +363,7 @@ class ConvBN(object):
         (the caller hands it to the next convolution, or calls .tensor()).  want_x (x pending): the producer's activation is
         needed as a tensor as well (it is a block output)."""
         if ctx.bf16:
-            return self.fwd16(ctx, as_tensor(ctx, x), relu, res)
+            return self.fwd16(ctx, x, relu, res, lazy)
         x_bn = None
         if isinstance(x, PendingBN):
             # the producer's BatchNorm apply inside this convolution's input transform: F(4x4) forward, and - when training - a

@@ -30,7 +30,7 @@ if len(ad) < 6:
 w0, w1 = ad[3][1], ad[4][1]
 win = [e for e in ev if e[0] >= w0 and e[1] <= w1]
 def fam(k):
-    if k.startswith('gemm') or k.startswith('splitk'): return 'gemm'
+    if k.startswith('gemm') or k.startswith('splitk') or k.startswith('conv16_halo'): return 'gemm'
     if k.startswith('wino'): return 'wino-transform'
     if k.startswith('attn'): return 'attention'
     if k.startswith('bn_') or k.startswith('col_partial'): return 'batchnorm'
