@@ -139,8 +139,9 @@ LAZY_BN_APPLY = os.environ.get("MMFN_LAZY_BN", "1") == "1"
 # the implicit GEMM (MMFN_HALO_MAX_K).  MMFN_HALO_CONV=0 restores round 5's launch sequence.
 HALO_MAX_K = int(os.environ.get("MMFN_HALO_MAX_K", "128"))
 # backward: 0 = implicit-GEMM data gradients (round 5), 1 = the halo kernel as the data gradient, 2 = also the BatchNorm backward's
-# elementwise pass in its loader (ConvBN.bwd16)
-HALO_BWD = int(os.environ.get("MMFN_HALO_BWD", "2"))
+# elementwise pass in its loader (ConvBN.bwd16).  Same-box A/B (vec B = 32, medians of 3 x 100 steps): 16.35 / 16.09 / 16.19 ms - the
+# fused loader reads three tensors per patch element and makes the weight gradient wait for the data gradient: 1 is the default.
+HALO_BWD = int(os.environ.get("MMFN_HALO_BWD", "1"))
 
 
 class PendingBN(object):
