@@ -75,6 +75,10 @@ int mmfn_wino_outgrad_bn_f32(const float* g, const float* y, const float* x, con
  * (+ res).  H, W multiples of 4; replaces cuDNN's backward-data for the BasicBlock 3x3 convolutions (model_vec.py:539-593). */
 int mmfn_wino_input_adjoint_f32(const float* dV, const float* res, float* dx, int B, int H, int W, int C, void* stream);
 int mmfn_wino_wgrad_out_f32(const float* dU, float* dw, int Co, int Ci, void* stream);
+/* The same transform over the un-combined partial products of a split-K batched GEMM (MMFN_EPI_KEEP_SLABS): slabs
+ * [splits][36][Co][Ci], summed in slice order while they are read - the split-K combine launch of every Winograd weight gradient
+ * (65 per training step) disappears into this one.  Ci a multiple of 64. */
+int mmfn_wino_wgrad_out_slabs_f32(const float* slabs, int splits, float* dw, int Co, int Ci, void* stream);
 /* The 7x7 stride-2 stems (torchvision conv1, model_vec.py:509,515: 3 camera / 2 BEV channels) as explicit im2col + plain GEMM:
  * col[B*OH*OW][KP] (fp32, or bf16 with out_bf16) = the zero-padded patch matrix of x [B,H,W,Cin] (fp32, Cin <= 4), k = (kh, kw, ci),
  * columns K = KH*KW*Cin .. KP zero.  Forward = col . w_padded^T, weight gradient = dY^T . col (the same matrix, kept). */
@@ -123,6 +127,9 @@ enum {
                               into three bf16 terms, six cross products accumulated in fp32: product error < 2^-22 relative */,
   MMFN_EPI_LN_FOLD = 4096, /* see mmfn_gemm_desc.ln_c1 */
   MMFN_EPI_COLSUM_A = 8192, /* see mmfn_gemm_desc.colsum */
+  MMFN_EPI_KEEP_SLABS = 16384, /* a launch that splits K (mmfn_gemm_f32_splits(d) > 1) leaves its partial products in the workspace,
+                              [split][batch][M][N], and runs NO combine kernel: the consumer sums them in slice order as it reads
+                              (mmfn_wino_wgrad_out_slabs_f32).  C is then not written.  No other epilogue flag may be set. */
   MMFN_EPI_RELU_LAST = 512 /* max(v, 0) as the LAST step, after residual / accumulate: conv + folded BatchNorm + skip + ReLU in one
                               launch (eval mode, mmfn_bn_fold_f32) */
 };
@@ -283,6 +290,8 @@ int mmfn_conv3x3_halo_bf16(const mmfn_conv16_halo_desc* d, void* stream);
 int mmfn_gemm_f32(const mmfn_gemm_desc* d, void* stream);
 /* bytes of split-K workspace mmfn_gemm_f32 needs for this descriptor (0 if none) */
 int64_t mmfn_gemm_workspace_bytes(const mmfn_gemm_desc* d);
+/* contraction slices the launch of this descriptor will use (1: the result goes to C); d->workspace must be what the launch gets */
+int mmfn_gemm_f32_splits(const mmfn_gemm_desc* d);
 
 /* ---- normalisation ------------------------------------------------------------------- */
 /* scratch for the norm kernels below (bytes); one buffer of this size for the largest C suffices */

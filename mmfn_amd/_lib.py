@@ -17,6 +17,7 @@ EPI_BIAS, EPI_RELU, EPI_GELU, EPI_MASK_AUX, EPI_DROPOUT, EPI_RESIDUAL, EPI_ACCUM
 EPI_RELU_LAST = 512
 EPI_LN_FOLD = 4096
 EPI_COLSUM_A = 8192
+EPI_KEEP_SLABS = 16384
 
 _vp = ctypes.c_void_p
 _i32 = ctypes.c_int32

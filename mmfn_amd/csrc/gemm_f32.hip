@@ -1380,7 +1380,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
     MMFN_F32_TILES(MMFN_LAUNCH_FAST)
 #undef MMFN_LAUNCH_FAST
     MMFN_LAUNCH_CHECK();
-    if (zdim > 1) {
+    if (zdim > 1 && !(d.flags & MMFN_EPI_KEEP_SLABS)) {
       launch_splitk_reduce(dd, s);
       MMFN_LAUNCH_CHECK();
     }
@@ -1401,7 +1401,7 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
   else MMFN_LAUNCH_TILE(64, 64)
 #undef MMFN_LAUNCH_TILE
   MMFN_LAUNCH_CHECK();
-  if (zdim > 1) {
+  if (zdim > 1 && !(d.flags & MMFN_EPI_KEEP_SLABS)) {
     launch_splitk_reduce(dd, s);
     MMFN_LAUNCH_CHECK();
   }
@@ -1560,10 +1560,21 @@ extern "C" int64_t mmfn_gemm_workspace_bytes(const mmfn_gemm_desc* d) {
   return sk > 1 ? (int64_t)sk * (std::max(1, d->batch) * (int64_t)d->M * d->N + cs) * (int64_t)sizeof(float) : 0;
 }
 
+extern "C" int mmfn_gemm_f32_splits(const mmfn_gemm_desc* d) {
+  if (!d || d->K <= 0) return 1;
+  if (bf16_ok(*d)) return 1;   // (the bf16-operand kernels always combine)
+  int tile, sk;
+  pick_config(*d, &tile, &sk);
+  const int nkt = ceil_div(d->K, BK);
+  return ceil_div(nkt, ceil_div(nkt, std::max(1, sk)));
+}
+
 extern "C" int mmfn_gemm_f32(const mmfn_gemm_desc* dp, void* stream) {
   if (!dp) return MMFN_EINVAL;
   const mmfn_gemm_desc& d = *dp;
   if (d.M <= 0 || d.N <= 0 || d.K <= 0 || !d.A || !d.B || !d.C) return MMFN_EINVAL;
+  if ((d.flags & MMFN_EPI_KEEP_SLABS) && ((d.flags & ~MMFN_EPI_KEEP_SLABS) || (d.batch > 1 && !batch_packed(d)) || bf16_ok(d)))
+    return MMFN_EINVAL;
   if ((d.flags & MMFN_EPI_DROPOUT) && (!d.rng_state || d.drop_p < 0.f || d.drop_p >= 1.f)) return MMFN_EINVAL;
   if ((d.flags & MMFN_EPI_BIAS) && !d.bias) return MMFN_EINVAL;
   if ((d.flags & MMFN_EPI_RESIDUAL) && !d.res) return MMFN_EINVAL;

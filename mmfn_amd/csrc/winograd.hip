@@ -617,6 +617,51 @@ __global__ __launch_bounds__(NT) void wino4_wgrad_out_kernel(const float* __rest
   }
 }
 
+// The same over the un-combined slabs [splits][36][Co][Ci] of a split-K batched GEMM (MMFN_EPI_KEEP_SLABS): a block owns 64
+// consecutive ci of one co; all 256 threads first sum the slabs of its 36 x 64 frequency values in slice order (coalesced 256-byte
+// rows, two partial sums so the loads pipeline) into LDS, then 64 threads transform.
+__global__ __launch_bounds__(NT) void wino4_wgrad_out_slabs_kernel(const float* __restrict__ slabs, int splits, float* __restrict__ dw,
+                                                                   int Co, int Ci) {
+  __shared__ float du[36][64];
+  const int blocks_ci = Ci >> 6;
+  const int co = blockIdx.x / blocks_ci, ci0 = (blockIdx.x - co * blocks_ci) << 6;
+  const int j = threadIdx.x & 63, fg = threadIdx.x >> 6;
+  const size_t slab = (size_t)36 * Co * Ci, plane = (size_t)Co * Ci;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int f = fg + 4 * q;
+    const float* p = slabs + (size_t)f * plane + (size_t)co * Ci + ci0 + j;
+    float s0 = 0.f, s1 = 0.f;
+    int z = 0;
+    for (; z + 1 < splits; z += 2) {
+      s0 += p[(size_t)z * slab];
+      s1 += p[(size_t)(z + 1) * slab];
+    }
+    if (z < splits) s0 += p[(size_t)z * slab];
+    du[f][j] = s0 + s1;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int ci = ci0 + j;
+  float t[3][6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) {
+    float u[6], g[3];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) u[a] = du[a * 6 + e][j];
+    f4_gt(u, g);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) t[a][e] = g[a];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float g[3];
+    f4_gt(t[a], g);
+#pragma unroll
+    for (int b = 0; b < 3; ++b) dw[(((size_t)co * 3 + a) * 3 + b) * Ci + ci] = g[b];
+  }
+}
+
 // Output transform that also emits the BatchNorm batch statistics of what it writes: block b owns a contiguous run of
 // tiles, thread (tile lane, channel quad) accumulates sum / sum of squares of its 16 pixels x 4 channels in fp64, the tile
 // lanes are combined through LDS and row b of partials [gridDim][2][C] is written (same format as col_partial_kernel<0>,
@@ -776,6 +821,13 @@ extern "C" int mmfn_wino_input_adjoint_f32(const float* dV, const float* res, fl
 extern "C" int mmfn_wino_wgrad_out_f32(const float* dU, float* dw, int Co, int Ci, void* stream) {
   if (!dU || !dw || Co <= 0 || Ci <= 0) return MMFN_EINVAL;
   hipLaunchKernelGGL(wino4_wgrad_out_kernel, dim3(grid_for((int64_t)Co * Ci)), dim3(NT), 0, (hipStream_t)stream, dU, dw, Co, Ci);
+  MMFN_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int mmfn_wino_wgrad_out_slabs_f32(const float* slabs, int splits, float* dw, int Co, int Ci, void* stream) {
+  if (!slabs || !dw || splits < 1 || Co <= 0 || Ci <= 0 || (Ci & 63)) return MMFN_EINVAL;
+  hipLaunchKernelGGL(wino4_wgrad_out_slabs_kernel, dim3(Co * (Ci >> 6)), dim3(NT), 0, (hipStream_t)stream, slabs, splits, dw, Co, Ci);
   MMFN_LAUNCH_CHECK();
   return 0;
 }

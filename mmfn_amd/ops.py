@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (A_COLMAJOR, A_DGRAD, A_IM2COL, A_ROWMAJOR, B_DGRADW, B_IM2COL, B_KN, B_NK,
+from ._lib import (EPI_KEEP_SLABS, A_COLMAJOR, A_DGRAD, A_IM2COL, A_ROWMAJOR, B_DGRADW, B_IM2COL, B_KN, B_NK,
                    EPI_ACCUM, EPI_BF16_OPERANDS, EPI_BF16X3, EPI_BIAS, EPI_COLSUM_A, EPI_DROPOUT, EPI_GELU, EPI_LN_FOLD, EPI_MASK_AUX, EPI_RELU, EPI_RELU_LAST,
                    EPI_RESIDUAL,
                    GemmDesc, GptBlockDesc, check, lib, ptr, stream)
@@ -277,7 +277,7 @@ def _f32c(t, name):
 
 def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=None, res=None, ldr=0,
          aux=None, ldaux=0, relu=False, gelu=False, accum=False, relu_last=False, drop_p=0.0, rng_state=None, rng_stream=0,
-         conv=None, splitk=0, tile=0, batch=1, strideA=0, strideB=0, strideC=0, ln_fold=None, colsum=None):
+         conv=None, splitk=0, tile=0, batch=1, strideA=0, strideB=0, strideC=0, ln_fold=None, colsum=None, slab_info=None):
     """colsum ([M] fp32, TN form): also the column sums of the A operand (MMFN_EPI_COLSUM_A: a Linear's bias gradient from its
     weight-gradient GEMM).
     ln_fold = (c1 [N], mean [M] or None, rstd [M] or None, eps): C = LayerNorm(A) . B^T + bias with B / bias the folded operands
@@ -349,9 +349,21 @@ def gemm(A, B, C, M, N, K, lda, ldb, ldc, a_mode=A_ROWMAJOR, b_mode=B_NK, bias=N
             pass
     if ln_fold is not None:   # the plain GEMM's tile of the same shape (table entry or the library's model); never split - a tile
         d.splitk = 1          # that does not divide M x N falls back to 64 x 64 inside the launcher
+    # slab_info (a dict): a launch that splits K leaves its slices un-combined (MMFN_EPI_KEEP_SLABS) and reports them here as
+    # slab_info["splits"] (> 1) and slab_info["slabs"] (the workspace tensor, [splits][batch][M][N]); with splits == 1 C holds the result
+    keep = slab_info is not None and flags == 0 and not bf16 and not (d.flags & (EPI_BF16X3 | EPI_BF16_OPERANDS))
+    if keep:
+        d.flags |= EPI_KEEP_SLABS
     need = L.mmfn_gemm_workspace_bytes(ctypes.byref(d))
+    wsbuf = None
     if need > 0:
-        d.workspace = ptr(workspace(need, C.device))
+        wsbuf = workspace(need, C.device)
+        d.workspace = ptr(wsbuf)
+    if slab_info is not None:
+        slab_info["splits"] = L.mmfn_gemm_f32_splits(ctypes.byref(d)) if (keep and wsbuf is not None) else 1
+        slab_info["slabs"] = wsbuf
+        if slab_info["splits"] <= 1:
+            d.flags &= ~EPI_KEEP_SLABS
     if _profiler is None or _profiler.suspended:
         check(L.mmfn_gemm_f32(ctypes.byref(d), stream()), "mmfn_gemm_f32")
         return C
@@ -653,11 +665,17 @@ def _wgrad_winograd_body(dy, x, out, v, B, H, W, Ci, Co, T, dU, V, dMt, st, bn=N
               ptr(ge_out), ptr(dMt), B, H, W, Co, st)
     else:
         _call("mmfn_wino_outgrad_f32", ptr(dy), ptr(dMt), B, H, W, Co, st)
-    gemm(dMt, V, dU, Co, Ci, T, Co, Ci, Ci, A_COLMAJOR, B_KN, batch=36, strideA=T * Co, strideB=T * Ci, strideC=Co * Ci)
-    _call("mmfn_wino_wgrad_out_f32", ptr(dU), ptr(out), Co, Ci, st)
+    # the split-K combine of this GEMM (K = tiles: thousands) runs inside the output transform, which sums the slices as it reads
+    info = {} if (WGRAD_SLABS and Ci % 64 == 0) else None
+    gemm(dMt, V, dU, Co, Ci, T, Co, Ci, Ci, A_COLMAJOR, B_KN, batch=36, strideA=T * Co, strideB=T * Ci, strideC=Co * Ci, slab_info=info)
+    if info is not None and info["splits"] > 1:
+        _call("mmfn_wino_wgrad_out_slabs_f32", ptr(info["slabs"]), info["splits"], ptr(out), Co, Ci, st)
+    else:
+        _call("mmfn_wino_wgrad_out_f32", ptr(dU), ptr(out), Co, Ci, st)
     return out
 
 
+WGRAD_SLABS = os.environ.get("MMFN_WGRAD_SLABS", "1") == "1"   # A/B switch: 0 = a split-K combine launch per Winograd weight gradient
 WINOGRAD_ADJOINT_DGRAD = True
 
 

@@ -471,3 +471,36 @@ def test_bias_gradient_from_the_weight_gradient_gemm_under_the_f32x3_table():
         ops.F32X3 = saved_flag
         ops._tuned.clear()
         ops._tuned.update(saved_table)
+
+
+@pytest.mark.parametrize("cfg", [(8, 64, 64, 64), (8, 32, 128, 128)])
+def test_winograd_weight_gradient_sums_its_split_k_slices_in_the_output_transform(cfg, monkeypatch):
+    """MMFN_EPI_KEEP_SLABS + mmfn_wino_wgrad_out_slabs_f32: the 36-batch weight-gradient GEMM (K = tiles) leaves its slices in the
+    workspace and the G^T dU G transform sums them while it reads - no combine launch.  Same result as the combine + transform pair
+    (to the rounding of a different summation order), bitwise repeatable, and the slab path is really the one taken."""
+    from mmfn_amd import ops
+    dev = _dev()
+    B, HW, Cin, Cout = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = torch.randn(B, HW, HW, Cin, generator=g).to(dev)
+    dy = torch.randn(B, HW, HW, Cout, generator=g).to(dev)
+    taken = []
+    real = ops._call
+
+    def spy(name, *a):
+        taken.append(name)
+        return real(name, *a)
+
+    monkeypatch.setattr(ops, "_call", spy)
+    monkeypatch.setattr(ops, "WGRAD_SLABS", True)
+    dw1 = ops.conv2d_wgrad_winograd(dy, x, torch.empty(Cout, 3, 3, Cin, device=dev))
+    dw1b = ops.conv2d_wgrad_winograd(dy, x, torch.empty(Cout, 3, 3, Cin, device=dev))
+    assert "mmfn_wino_wgrad_out_slabs_f32" in taken, "this shape was expected to split K"
+    assert torch.equal(dw1, dw1b)
+    monkeypatch.setattr(ops, "WGRAD_SLABS", False)
+    dw0 = ops.conv2d_wgrad_winograd(dy, x, torch.empty(Cout, 3, 3, Cin, device=dev))
+    assert (dw1 - dw0).abs().max().item() <= 2e-6 * dw0.abs().max().item()
+    xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(False)
+    wr = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wr, padding=1).backward(dy.permute(0, 3, 1, 2).double().cpu())
+    _close(dw1.permute(0, 3, 1, 2).cpu(), wr.grad.float())
