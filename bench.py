@@ -697,7 +697,8 @@ def main():
             ach = fb / (msb * 1e-3) / 1e12 if msb > 0 else 0.0
             r.update({"achieved": round(ach, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "frac": round(ach / PEAK_BF16_MFMA_TFLOPS, 4),
                       "kernel": ("gemm16_nt / gemm16_tn kernels (v_mfma_f32_32x32x16_bf16, bf16 operands in HBM staged by global_load_lds, fp32 "
-                                 "accumulate): Linear fwd / dX / dW and every trunk convolution fwd / data gradient / weight gradient"
+                                 "accumulate): Linear fwd / dX / dW and every trunk convolution fwd / data gradient / weight gradient; the 64- / 128-channel 3x3 "
+                                 "stride-1 convolutions fwd / data gradient as conv16_halo_kernel (LDS-resident halo patch, the producer's BatchNorm in the loader)"
                                  if args.dtype == "bf16" else
                                  "gemm_bf16_kernel (v_mfma_f32_32x32x16_bf16; fp32 operands in HBM rounded to bf16 on the way into LDS, "
                                  "fp32 accumulate): Linear GEMMs and direct 3x3 convolutions fwd / data gradient"),

@@ -300,11 +300,7 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d_in,
 
   int cur = 0;
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-#ifdef MMFN_GEMM_ABLATE_LOADS
-    const bool more = false;  // ablation: measure the MFMA + ds_read + barrier skeleton alone
-#else
     const bool more = (kt + 1 < kt_end);
-#endif
     if (more) {
 #pragma unroll
       for (int i = 0; i < UA; ++i) ra[i] = load_a(i, kt + 1);
@@ -338,9 +334,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d_in,
           for (int j = 0; j < 4; ++j) b[i][j] = Bs[(c * 8 + h * 4 + j) * BN + col];
         }
       }
-#ifdef MMFN_GEMM_SETPRIO
-      __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -348,9 +341,6 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(const mmfn_gemm_desc d_in,
 #pragma unroll
           for (int q = 0; q < TN; ++q)
             acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[q][j], acc[i][q], 0, 0, 0);
-#ifdef MMFN_GEMM_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
     }
     if (more) {
       float* An = smem + (cur ^ 1) * (A_ELEMS + B_ELEMS);
@@ -411,11 +401,7 @@ __device__ int g_tl_blocks = 0;
 #define TL_END() do { } while (0)
 #endif
 
-#ifdef MMFN_GEMM_NO_GLDS
-constexpr bool USE_GLDS = false;  // register-staged fallback (A/B experiment switch)
-#else
 constexpr bool USE_GLDS = true;   // +5-10 % over register staging on every shape measured (tools/gemm_bench.py)
-#endif
 // source-side slot of unit u (k-contiguous operands): the physical LDS slot u % KQ holds logical slot
 // (u % KQ) ^ swizzle(row) when the tile is written lane-linearly by global_load_lds
 #define SRCQ(u) (USE_GLDS ? kc_slot((u) / KQ, (u) % KQ) : (u) % KQ)
@@ -455,7 +441,6 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
   // entries and half of a fifth per XCD).  bz / by / bxr: the (entry, k-split, tile) this block computes.
   int bz = blockIdx.z, by = blockIdx.y, bxr = blockIdx.x;
   bool xcd_batch = false;
-#ifndef MMFN_GEMM_NO_XCD_BATCH
   if (d_in.batch > 1 && !d_in.dg_parity) {
     const int U = gridDim.x * gridDim.y, full = d_in.batch >> 3, rem = d_in.batch & 7;
     const int shares = rem ? 8 / rem : 1;
@@ -470,7 +455,6 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
       xcd_batch = true;
     }
   }
-#endif
   const mmfn_gemm_desc d = d_in.dg_parity ? d_in : batch_view(d_in, bz);
   // Stride-2 transposed convolution, decomposed by output-pixel parity (blockIdx.z = 2*py + px): an input
   // pixel (ih, iw) only receives taps with kh == (ih + pad) mod 2, kw == (iw + pad) mod 2, so each of the
@@ -528,9 +512,6 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
     }
   }
 #endif
-#ifdef MMFN_GEMM_NO_XCD_SWIZZLE
-  const int bid = blockIdx.x;
-#else
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch policy; speed only).  Give each
   // XCD a contiguous run of tiles so the blocks that share an A row-panel / B column-panel hit the same L2.
   int bid;
@@ -540,7 +521,6 @@ void gemm_f32_fast_kernel(const mmfn_gemm_desc d_in, const int kt_per_split, con
     const int nb = gridDim.x, xcd = blockIdx.x & 7, q = nb >> 3, r = nb & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
   }
-#endif
   const int m0 = (bid / tiles_n) * BM, n0 = (bid % tiles_n) * BN;
   const int nkt = Kloc / BK;
   const int kt_begin = by * kt_per_split;
@@ -1329,7 +1309,6 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
   const int zdim = ceil_div(nkt, kps);
   mmfn_gemm_desc dd = d;
   dd.splitk = zdim;
-#ifndef MMFN_GEMM_NO_FAST
   if (fast_ok(d)) {
     if (AM == MMFN_A_DGRAD && d.stride == 2 && !(d.H & 1) && !(d.W & 1) && d.batch <= 1) {
       // four output-parity classes in one launch (grid.z), no split-K: each class already has M/4 rows
@@ -1386,7 +1365,6 @@ int launch_form(const mmfn_gemm_desc& d, int tile, int splitk, hipStream_t s) {
     }
     return 0;
   }
-#endif
   if (d.flags & MMFN_EPI_LN_FOLD) return MMFN_EINVAL;   // (needs the fast kernel: 16-byte aligned operands, K a multiple of 16)
   if (tile > 4) tile = 2;
 #define MMFN_LAUNCH_TILE(BM_, BN_)                                                                              \
@@ -1588,9 +1566,6 @@ extern "C" int mmfn_gemm_f32(const mmfn_gemm_desc* dp, void* stream) {
     if (!d.colsum || d.a_mode != MMFN_A_COLMAJOR || d.b_mode != MMFN_B_KN || d.batch > 1 || !fast_ok(d) ||
         (d.flags & (MMFN_EPI_BF16_OPERANDS | MMFN_EPI_BF16X3)))
       return MMFN_EINVAL;
-#ifdef MMFN_GEMM_NO_FAST   // (an experiment build without the fast kernel would leave colsum unwritten)
-    return MMFN_EINVAL;
-#endif
   }
   hipStream_t s = (hipStream_t)stream;
   if (bf16_ok(d)) return launch_bf16(d, s);

@@ -206,8 +206,9 @@ class ConvBN(object):
     def is_stem(self):
         return self.w.shape[3] <= 4 and ops.STEM_IM2COL
 
-    def stem_conv(self, ctx, x, co, stats=None):
-        """co [B,OH,OW,Cout] = conv(x) through the patch matrix, which is kept for the weight gradient (stem_wgrad)."""
+    def stem_conv(self, ctx, x, co, stats=None, w=None, bias=None, relu=False):
+        """co [B,OH,OW,Cout] = conv(x) through the patch matrix, which is kept for the weight gradient (stem_wgrad).
+        w / bias / relu: the BatchNorm-folded filter and shift of an eval forward (Engine.fold_batchnorm)."""
         Co, KH, KW, Ci = self.w.shape
         K = KH * KW * Ci
         M = co.numel() // Co
@@ -216,9 +217,11 @@ class ConvBN(object):
         col = ctx.bufs.get(self.name + ".col", (M, KP), co.dtype)
         wp = ctx.bufs.get(self.name + ".wpad", (Co, KP), co.dtype)
         ops.im2col_small(x, col, KH, KW, self.stride, self.pad)
-        ops.repitch_rows(self.w, wp, Co, K, K, KP)
+        ops.repitch_rows(self.w if w is None else w, wp, Co, K, K, KP)
         if stats is not None:
             ops.linear_fwd(col, wp, None, out=co.view(M, Co), stats=stats)
+        elif bias is not None:
+            ops.linear_fwd(col, wp, bias, out=co.view(M, Co), relu=relu)
         else:
             ops.linear_fwd(col, wp, None, out=co.view(M, Co))
         self.saved_col = col
@@ -243,7 +246,7 @@ class ConvBN(object):
         halo = x.dtype == torch.bfloat16 and x.shape[-1] <= HALO_MAX_K and ops16.halo_ok(tuple(x.shape), tuple(self.w.shape), self.stride, self.pad) > 0
         x_bn = None
         if isinstance(x, PendingBN):
-            if halo and x.y is None and LAZY_BN_APPLY:
+            if halo and x.y is None and LAZY_BN_APPLY and not ctx.folded:
                 pend = x
                 x_bn = pend.consume(ctx, True)    # (res, mean, rstd, weight, bias, relu, y_out): y is written by this convolution
                 xin, x = pend.co, pend.y
@@ -254,6 +257,19 @@ class ConvBN(object):
         _, oshape = ops.conv_geom(x.shape, self.w.shape, self.stride, self.pad)
         M = oshape[0] * oshape[1] * oshape[2]
         stem = x.dtype == torch.float32
+        if not ctx.training and ctx.folded and (not stem or self.is_stem()):
+            # eval over BatchNorm-folded filters (Engine.fold_batchnorm; the closed-loop session): convolution + shift + skip + ReLU
+            # in ONE launch of the implicit GEMM, the folded filter as a bf16 shadow
+            assert x_bn is None
+            wf, bf, wf16 = ctx.engine.folded[self.name]
+            y = ctx.bufs.get(self.name + ".out", oshape, ctx.adt)
+            if stem:
+                self.stem_conv(ctx, x, y, w=wf, bias=bf, relu=relu)
+            elif res is None:
+                ops16.conv2d_fwd(x, wf16, self.stride, self.pad, y, bias=bf, relu=relu)
+            else:
+                ops16.conv2d_fwd(x, wf16, self.stride, self.pad, y, bias=bf, res=res.view(M, self.cout), ldr=self.cout, relu_last=relu)
+            return y
         col_stem = stem and self.is_stem()   # patch-matrix form: the stem joins the bf16 pipeline (bf16 conv output, statistics from the epilogue)
         co = ctx.bufs.get(self.name + ".conv", oshape, torch.float32 if (stem and not col_stem) else ctx.adt)
         mean = ctx.bufs.get(self.name + ".mean", (self.cout,))
@@ -397,7 +413,7 @@ class ConvBN(object):
             # eval with BatchNorm folded into the filter (Engine.fold_batchnorm): convolution + shift + skip + ReLU in ONE launch,
             # as a direct implicit GEMM (at batch 1 the Winograd form - transform, 36-batch GEMM, transform - measured slower: 4.99 vs
             # 4.59 ms per tick)
-            wf, bf = ctx.engine.folded[self.name]
+            wf, bf = ctx.engine.folded[self.name][:2]
             y = ctx.bufs.get(self.name + ".out", oshape)
             if res is None:
                 ops.conv2d_fwd(x, wf, self.stride, self.pad, out=y, bias=bf, relu=relu)
@@ -1577,9 +1593,12 @@ class Engine(object):
             for cb in trunk.convbns():
                 ent = self.folded.get(cb.name)
                 if ent is None:
-                    ent = (torch.empty_like(cb.w), torch.empty(cb.cout, dtype=torch.float32, device=self.device))
+                    ent = (torch.empty_like(cb.w), torch.empty(cb.cout, dtype=torch.float32, device=self.device),
+                           torch.empty(cb.w.shape, dtype=torch.bfloat16, device=self.device) if self.act_dtype == torch.bfloat16 else None)
                     self.folded[cb.name] = ent
                 ops.bn_fold(cb.w, cb.bn_w, cb.bn_b, cb.bn.running_mean, cb.bn.running_var, cb.bn.eps, ent[0], ent[1])
+                if ent[2] is not None:   # bf16 mode: the folded filter's shadow (the fold itself stays fp32: w * s is rounded once)
+                    ops.cast_to_bf16(ent[0], ent[2])
 
     @_in_precision
     def forward(self, inp, training, gt=None, folded=False):
@@ -1591,8 +1610,6 @@ class Engine(object):
             ctx.folded = True
         self._last = (ctx, B)
         if ctx.bf16:
-            if folded:
-                raise ValueError("BatchNorm folding is an fp32-mode option")
             self.refresh_shadows()
         if self.ln_fold_now(training) and ops.current_precision() == "f32":
             ops.ln_fold_weights(*self.ln_fold_table)

@@ -59,7 +59,7 @@ class DrivingSession(object):
         self._n_points = 0
         self._n_dev = 0
         self.graph = None
-        self.fold = fold_batchnorm and self.eng.act_dtype == torch.float32   # (folding is an fp32-mode option)
+        self.fold = fold_batchnorm   # (both arithmetic modes: fp32 filters, or their bf16 shadows in the bf16 mode)
         with torch.no_grad():
             if self.fold:
                 # eval-mode BatchNorm folded into the filters: convolution + shift + skip + ReLU is one launch instead of

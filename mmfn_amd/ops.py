@@ -675,7 +675,7 @@ def _wgrad_winograd_body(dy, x, out, v, B, H, W, Ci, Co, T, dU, V, dMt, st, bn=N
     return out
 
 
-WGRAD_SLABS = os.environ.get("MMFN_WGRAD_SLABS", "1") == "1"   # A/B switch: 0 = a split-K combine launch per Winograd weight gradient
+WGRAD_SLABS = True   # False: a split-K combine launch per Winograd weight gradient (the test of the slab path compares both)
 WINOGRAD_ADJOINT_DGRAD = True
 
 

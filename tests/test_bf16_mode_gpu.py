@@ -190,3 +190,61 @@ def test_bf16_mode_rejects_what_it_does_not_cover():
     net = MMFNImg(GlobalConfig(act_dtype="bf16", n_views=3), DEV)   # 320 tokens: K and V of a 128-wide head no longer fit LDS
     with pytest.raises(NotImplementedError, match="256 tokens"):
         net._engine_for()
+
+
+@pytest.mark.parametrize("variant", ["vec", "img"])
+def test_bf16_closed_loop_session_over_folded_batchnorms(variant):
+    """DrivingSession in the bf16 mode: the eval-mode BatchNorms folded into bf16 shadows of the filters (conv + shift + skip + ReLU in
+    one launch of the implicit GEMM), the tick one hipGraph.  Against the unfolded eager bf16 session (the folded filter w * s is
+    rounded to bf16 once instead of scaling fp32 accumulators: a bf16-sized difference), against the fp32 session (the mode's eval
+    bar: 5e-2 of the waypoint scale), and refresh() follows changed weights without a new capture."""
+    import numpy as np
+    from mmfn_amd.config import GlobalConfig
+    from mmfn_amd.inference import DrivingSession
+    from mmfn_amd.model import MMFN, MMFNImg
+    cls = {"vec": MMFN, "img": MMFNImg}[variant]
+    torch.manual_seed(7)
+    net32 = cls(GlobalConfig(), DEV)
+    with torch.no_grad():   # running statistics away from their initial (0, 1)
+        for name, b in net32.named_buffers():
+            if name.endswith("running_var"):
+                b.uniform_(0.5, 1.5)
+            elif name.endswith("running_mean"):
+                b.uniform_(-0.2, 0.2)
+    net16 = cls(GlobalConfig(act_dtype="bf16"), DEV)
+    net16.load_state_dict(net32.state_dict())
+    ref = DrivingSession(net32.eval(), max_points=1 << 14, max_lanes=16)
+    folded = DrivingSession(net16.eval(), max_points=1 << 14, max_lanes=16)
+    plain = DrivingSession(net16, max_points=1 << 14, max_lanes=16, fold_batchnorm=False, use_graph=False)
+    assert folded.fold and folded.eng.act_dtype == torch.bfloat16
+    rng = np.random.RandomState(1)
+    rgb = rng.randint(0, 256, (300, 400, 3)).astype(np.uint8)
+    pts = np.stack([rng.uniform(-20, 20, 5000), rng.uniform(-12, 28, 5000), rng.uniform(-3, 1, 5000), rng.uniform(0, 1, 5000)], 1).astype(np.float32)
+    lanes = rng.randn(6, 10, 5).astype(np.float32)
+    bev = rng.randint(0, 256, (256, 256, 3)).astype(np.uint8)
+
+    def run(sess):
+        kw = dict(merge_previous_sweep=False)
+        if variant == "img":
+            return sess.predict(rgb, pts, None, (2.0, 15.0), 3.0, map_image=bev, **kw).float().clone()
+        return sess.predict(rgb, pts, lanes, (2.0, 15.0), 3.0, **kw).float().clone()
+
+    r, a, b = run(ref), run(folded), run(plain)
+    scale = float(r.abs().max()) + 1e-6
+    dab, dar, dbr = float((a - b).abs().max()), float((a - r).abs().max()), float((b - r).abs().max())
+    print("\n[bf16 session %s] scale %.4g: folded-unfolded %.3g, folded-fp32 %.3g, unfolded-fp32 %.3g" % (variant, scale, dab, dar, dbr))
+    assert dar <= 5e-2 * scale and dab <= 5e-2 * scale, (dab, dar, dbr, scale)       # the mode's eval bar
+    assert dar <= 2.5 * dbr + 1e-2 * scale, (dab, dar, dbr, scale)                   # folding costs no more than the mode itself
+    assert torch.equal(a, run(folded))                                   # the replayed tick is deterministic
+    with torch.no_grad():
+        for name, p in net16.named_parameters():
+            if "image_encoder" in name and name.endswith("conv1.weight"):
+                p.mul_(1.05)
+    net16.weights_changed()
+    b1 = run(plain)
+    assert float((b1 - b).abs().max()) > 1e-3 * scale                   # the network did change
+    a1 = run(folded)                                                     # (predict() re-folds when the module's weight version moved)
+    scale1 = float(b1.abs().max()) + 1e-6
+    print("[bf16 session %s] after the weight change: scale %.4g, folded-unfolded %.3g, moved by %.3g" % (variant, scale1, float((a1 - b1).abs().max()),
+                                                                                                     float((b1 - b).abs().max())))
+    assert float((a1 - b1).abs().max()) <= 5e-2 * scale1
