@@ -240,7 +240,9 @@ class ConvBN(object):
         """bf16 mode.  A trunk convolution (bf16 input): direct implicit GEMM on the bf16 MFMA pipe whose epilogue also emits
         the BatchNorm batch-statistics partial sums of its fp32 accumulators (no statistics pass over the output); a stem (fp32
         input from the ingest kernels, 3 / 2 channels): the fp32 convolution, fp32 output, and the BatchNorm apply is where the
-        activation becomes bf16."""
+        activation becomes bf16.  x may be the PendingBN of the producing ConvBN: a 3x3 stride-1 convolution of up to HALO_MAX_K
+        channels then runs as mmfn_conv3x3_halo_bf16 and applies that BatchNorm (+ skip + ReLU) in its loader; lazy: return this
+        layer's own PendingBN instead of launching the apply."""
         from . import ops16
         # the LDS-resident-patch kernel (3x3 stride 1): takes the producer's PendingBN as it is and applies it in its loader
         halo = x.dtype == torch.bfloat16 and x.shape[-1] <= HALO_MAX_K and ops16.halo_ok(tuple(x.shape), tuple(self.w.shape), self.stride, self.pad) > 0
